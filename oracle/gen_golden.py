@@ -1,0 +1,421 @@
+"""Generate tests/golden/*.npz by running the REAL reference (imported from /root/reference).
+
+TEST INFRASTRUCTURE; runs only in the build container (the reference never travels to the GPU box).
+Usage:  python -m oracle.gen_golden            (from the repo root)
+
+Third-party modules that the reference imports at module level but that are absent here
+(pyvista, wandb, omegaconf, torch_geometric, torchmetrics) are registered as empty
+stubs before the import; the node-coordinate DDPM that NoiseModel.__init__ hard-loads
+(noise_model.py:62-79, checkpoint not in the repo) is replaced by a stub class.  None of that is on
+the arithmetic path being pinned.
+
+torch.multinomial has no uniform input, so inside this process ``Tensor.multinomial`` is replaced by
+the documented inverse-CDF rule (oracle.noise.inverse_cdf_draws) fed from a recorded uniform stream;
+all code around it (masking to uniform, slot-0 overwrite, triu, mirror, one-hot, .mask()) is the
+reference's own.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from oracle import fixtures as fx
+from oracle.noise import inverse_cdf_draws
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def import_reference():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Dummy:
+        def __init__(self, *a, **k):
+            pass
+
+    stub("pyvista")
+    stub("wandb", run=None)
+    stub("omegaconf", OmegaConf=_Dummy, DictConfig=_Dummy)
+    tg = stub("torch_geometric")
+    tg.utils = stub("torch_geometric.utils", to_dense_adj=None, to_dense_batch=None, remove_self_loops=None)
+    stub("torchmetrics", Metric=_Dummy, MeanSquaredError=_Dummy, MeanAbsoluteError=_Dummy,
+         MetricCollection=_Dummy, KLDivergence=_Dummy)
+
+    class _CoordModel:
+        def __init__(self, device=None):
+            self.model = SimpleNamespace(load_state_dict=lambda *_a, **_k: None, eval=lambda: None)
+
+        def to_cuda_device(self, *_a):
+            pass
+
+        def sample(self, pos, node_mask):
+            return pos * node_mask[..., None]
+
+    for ds in ("cow", "atm"):
+        stub(f"src.bootstrap.node_coordinate_diffusion.{ds}_diff_nodes_with_3d_checks",
+             NodeCoordsDiffusionModel=_CoordModel)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import src.ConStruct.utils as U
+    from src.ConStruct.models import transformer_model as TM
+    from src.ConStruct.models import layers as LY
+    from src.ConStruct.diffusion import diffusion_utils as DU, extra_features as EF, noise_model as NM
+    return SimpleNamespace(U=U, TM=TM, LY=LY, DU=DU, EF=EF, NM=NM)
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    conv = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def sd_arrays(sd, prefix="sd/"):
+    return {prefix + k: v for k, v in sd.items()}
+
+
+# --------------------------------------------------------------------------------------------
+def gen_block_and_layer(R):
+    """F1/F2: one NodeEdgeBlock and one XEyTransformerLayer (eval) at tiny dims, ragged batch."""
+    torch.manual_seed(11)
+    dx, de, dy, h = 32, 32, 16, 4
+    mask = fx.ragged_mask([7, 4, 1], 7)
+    B, n = mask.shape
+    X = torch.randn(B, n, dx)
+    E = torch.randn(B, n, n, de)
+    E = 0.5 * (E + E.transpose(1, 2))
+    y = torch.randn(B, dy)
+    ph = R.U.PlaceHolder(X=X, E=E, y=y, node_mask=mask).mask()
+    X, E = ph.X, ph.E
+    for predicts_y in (True, False):
+        blk = R.TM.NodeEdgeBlock(dx, de, dy, h, predicts_y=predicts_y).eval()
+        sd = fx.make_state_dict({k: v.shape for k, v in blk.state_dict().items()}, seed=21)
+        blk.load_state_dict(sd)
+        with torch.no_grad():
+            nX, nE, ny = blk(X, E, y, mask)
+        save(f"f1_node_edge_block_y{int(predicts_y)}", X=X, E=E, y=y, node_mask=mask, n_head=h,
+             newX=nX, newE=nE, new_y=ny if ny is not None else np.zeros(0), **sd_arrays(sd))
+    lay = R.TM.XEyTransformerLayer(dx, de, dy, h, dim_ffX=40, dim_ffE=64, dim_ffy=24).eval()
+    sd = fx.make_state_dict({k: v.shape for k, v in lay.state_dict().items()}, seed=22)
+    lay.load_state_dict(sd)
+    with torch.no_grad():
+        out = lay(R.U.PlaceHolder(X=X, E=E, y=y, node_mask=mask))
+    save("f2_xey_layer", X=X, E=E, y=y, node_mask=mask, n_head=h, outX=out.X, outE=out.E, outy=out.y,
+         **sd_arrays(sd))
+
+
+def _gt_case(R, name, dims, in_dims, out_dims, n_layers, n_nodes, seed, store_weights, symmetric_E=True,
+             onehot_C=None):
+    torch.manual_seed(seed)
+    mask = fx.ragged_mask(n_nodes)
+    B, n = mask.shape
+    model = R.TM.GraphTransformer(n_layers=n_layers, input_dims=fx.dims_ns(*in_dims),
+                                  hidden_mlp_dims=dims["hidden_mlp_dims"], hidden_dims=dims["hidden_dims"],
+                                  output_dims=fx.dims_ns(*out_dims), dropout=0.1).eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = fx.make_state_dict(shapes, seed=seed)
+    model.load_state_dict(sd)
+    X = torch.randn(B, n, in_dims[0])
+    E = torch.randn(B, n, n, in_dims[1])
+    if symmetric_E:
+        E = 0.5 * (E + E.transpose(1, 2))
+    if onehot_C is not None:  # realistic sampling input: masked one-hot labels in the first C channels
+        lab = fx.random_labels(mask, onehot_C, 0.15, seed)
+        E[..., :onehot_C] = fx.one_hot_edges(lab, mask, onehot_C)
+    y = torch.randn(B, in_dims[2])
+    with torch.no_grad():
+        out = model(SimpleNamespace(X=X, E=E, y=y, node_mask=mask))
+    arrays = dict(X=X, E=E, y=y, node_mask=mask, outX=out.X, outE=out.E,
+                  outy=out.y if out.y is not None else np.zeros(0),
+                  n_layers=n_layers, seed=seed, in_dims=np.array(in_dims), out_dims=np.array(out_dims),
+                  shape_keys=np.array(sorted(shapes)),
+                  shape_vals=np.array([",".join(map(str, shapes[k])) for k in sorted(shapes)]))
+    if store_weights:
+        arrays.update(sd_arrays(sd))
+    save(name, **arrays)
+
+
+def gen_graph_transformer(R):
+    """F3: full GraphTransformer forward."""
+    # tiny, weights stored, non-symmetric E input, y output requested
+    _gt_case(R, "f3_gt_tiny", fx.TINY_DIMS, (5, 9, 6), (3, 4, 2), 2, [9, 5, 2], 31, True, symmetric_E=False)
+    # tiny, CoW-like class counts, no y output (last layer has no y modules)
+    _gt_case(R, "f3_gt_tiny_noy", fx.TINY_DIMS, (4, 11, 7), (1, 6, 0), 3, [6, 10, 3, 1], 32, True, onehot_C=6)
+    # ConStruct dims, CoW shapes with extra-feature widths (X=10,E=25,y=43) -> (1,14,0); weights by recipe
+    _gt_case(R, "f3_gt_construct_cow", fx.CONSTRUCT_DIMS, (10, 25, 43), (1, 14, 0), 5, [12, 7], 33, False, onehot_C=14)
+    # vessel dims, ATM shapes without extra features (X=1,E=5,y=1) -> (1,5,0)
+    _gt_case(R, "f3_gt_vessel_atm", fx.VESSEL_DIMS, (1, 5, 1), (1, 5, 0), 5, [12, 9], 34, False, onehot_C=5)
+    # n > 32 exercises the multi-chunk key loop of the fused kernel
+    _gt_case(R, "f3_gt_vessel_n40", fx.VESSEL_DIMS, (1, 5, 1), (1, 5, 0), 2, [40, 33], 35, False, onehot_C=5)
+
+
+def gen_pooling(R):
+    """F4: Xtoy / Etoy pooled statistics and masked_softmax (incl. the all-masked case)."""
+    torch.manual_seed(41)
+    mask = fx.ragged_mask([6, 3, 1], 6)
+    B, n = mask.shape
+    X = torch.randn(B, n, 8) * mask[..., None]
+    E = torch.randn(B, n, n, 4)
+    E = R.U.PlaceHolder(X=X, E=0.5 * (E + E.transpose(1, 2)), y=None, node_mask=mask).mask().E
+    xt, et = R.LY.Xtoy(8, 5), R.LY.Etoy(4, 5)
+    with torch.no_grad():
+        xt.lin.weight.copy_(torch.eye(5, 32)); xt.lin.bias.zero_()
+        et.lin.weight.copy_(torch.eye(5, 16)); et.lin.bias.zero_()
+    # capture the pooled z by hooking lin's input
+    zs = {}
+    xt.lin.register_forward_hook(lambda m, i, o: zs.__setitem__("x", i[0].detach().clone()))
+    et.lin.register_forward_hook(lambda m, i, o: zs.__setitem__("e", i[0].detach().clone()))
+    xm = mask[..., None]
+    with torch.no_grad():
+        xt(X, xm)
+        et(E, xm.unsqueeze(2), xm.unsqueeze(1))
+    Y = torch.randn(B, n, n, 2, 3)
+    sm = R.LY.masked_softmax(Y, xm.unsqueeze(1).expand(-1, n, -1, 2), dim=2)
+    sm0 = R.LY.masked_softmax(Y, torch.zeros(B, n, n, 2, dtype=torch.bool), dim=2)
+    save("f4_pooling", X=X, E=E, node_mask=mask, zx=zs["x"], ze=zs["e"], Y=Y, softmax=sm, softmax_allmasked=sm0)
+
+
+def _hand_graphs():
+    """Small labelled graphs: path/tree, C3..C6 cycles, disconnected, empty, dense."""
+    def edges_to(n, edges):
+        a = np.zeros((n, n), dtype=np.int64)
+        for k, (i, j) in enumerate(edges):
+            a[i, j] = a[j, i] = 1 + (k % 3)
+        return a
+    n = 8
+    gs = [
+        (6, [(0, 1), (1, 2), (2, 3), (1, 4), (4, 5)]),                      # tree
+        (3, [(0, 1), (1, 2), (2, 0)]),                                      # C3
+        (4, [(0, 1), (1, 2), (2, 3), (3, 0)]),                              # C4
+        (5, [(i, (i + 1) % 5) for i in range(5)]),                          # C5
+        (6, [(i, (i + 1) % 6) for i in range(6)]),                          # C6
+        (8, [(0, 1), (1, 2), (2, 0), (3, 4), (5, 6), (6, 7), (7, 5), (5, 3)]),   # two components
+        (5, []),                                                            # empty
+        (6, [(i, j) for i in range(6) for j in range(i + 1, 6)]),           # K6
+        (7, [(0, 1), (0, 2), (0, 3), (3, 4), (4, 5), (5, 3), (5, 6), (1, 2)]),
+    ]
+    labs = np.zeros((len(gs), n, n), dtype=np.int64)
+    nn_ = []
+    for b, (k, ed) in enumerate(gs):
+        labs[b, :k, :k] = edges_to(k, ed)
+        nn_.append(k)
+    return torch.from_numpy(labs), torch.tensor(nn_), n
+
+
+def gen_extra_features(R):
+    """F5/F6: AdjacencyFeatures + EigenFeatures + full ExtraFeatures on hand-built graphs."""
+    labs, nn_, n = _hand_graphs()
+    mask = fx.ragged_mask(nn_, n)
+    C = 4
+    E = fx.one_hot_edges(labs, mask, C)
+    X = mask[..., None].float()
+    cfg = SimpleNamespace(model=SimpleNamespace(eigenfeatures=True, num_degree=10, max_degree=10, cycle_features=True,
+                                                num_eigenvectors=5, num_eigenvalues=9))
+    ef = R.EF.ExtraFeatures(cfg, SimpleNamespace(max_n_nodes=n))
+    data = SimpleNamespace(X=X, E=E, y=torch.zeros(len(nn_), 0), node_mask=mask)
+    torch.manual_seed(51)
+    out = ef(data)
+    ax, ay, ae = ef.adj_features(data)
+    torch.manual_seed(51)
+    evl, evc = ef.eigenfeatures.compute_features(data)
+    dims = ef.update_input_dims(fx.dims_ns(1, 14, 1))
+    save("f5_extra_features", labels=labs, n_nodes=nn_, node_mask=mask, C=C, X=X, E=E,
+         adj_x=ax, adj_y=ay, adj_e=ae, eval_feat=evl, evec_feat=evc,
+         out_X=out.X, out_E=out.E, out_y=out.y, kpowers=ef.adj_features.k,
+         upd_dims=np.array([dims.X, dims.E, dims.y]))
+    # a random sparse batch at CoW-like size
+    mask = fx.ragged_mask([20, 13, 17, 9], 20)
+    labs = fx.random_labels(mask, 14, 0.12, 52)
+    E = fx.one_hot_edges(labs, mask, 14)
+    X = mask[..., None].float()
+    data = SimpleNamespace(X=X, E=E, y=torch.zeros(4, 0), node_mask=mask)
+    ef2 = R.EF.ExtraFeatures(cfg, SimpleNamespace(max_n_nodes=32))
+    ax, ay, ae = ef2.adj_features(data)
+    torch.manual_seed(52)
+    evl, evc = ef2.eigenfeatures.compute_features(data)
+    save("f5_extra_features_random", labels=labs, node_mask=mask, C=14, X=X, E=E, adj_x=ax, adj_y=ay, adj_e=ae,
+         eval_feat=evl, evec_feat=evc)
+
+
+def _noise_model(R, transition, dataset, C_e, top_k, T=500, e_marg=None):
+    cfg = SimpleNamespace(
+        model=SimpleNamespace(nu=dict(x=1, c=1, e=1, y=1, e_small=1, e_mid=1, e_large=1), transition=transition,
+                              diffusion_steps=T, top_k=top_k),
+        dataset=SimpleNamespace(name=dataset))
+    xm = torch.ones(1)
+    em = torch.ones(C_e) / C_e if e_marg is None else e_marg
+    cm = torch.zeros(0)
+    real_load = torch.load
+    torch.load = lambda *a, **k: {}
+    try:
+        if transition == "absorbing_edges":
+            nm = R.NM.AbsorbingEdgesTransition(cfg, xm, em, cm, 0)
+        elif transition == "marginal":
+            nm = R.NM.MarginalTransition(cfg, xm, em, cm, 0)
+        elif transition == "uniform":
+            nm = R.NM.DiscreteUniformTransition(cfg, fx.dims_ns(1, C_e, 0, 0))
+        elif transition == "absorbing":
+            nm = R.NM.AbsorbingTransition(cfg, fx.dims_ns(1, C_e, 0, 0))
+    finally:
+        torch.load = real_load
+    return nm
+
+
+def gen_schedules(R):
+    """F7: beta / alpha_bar tables and Qt / Qt_bar samples."""
+    arrays = {}
+    ts = torch.tensor([[500], [499], [250], [2], [1], [0]])
+    for tr in ("absorbing_edges", "marginal", "uniform", "absorbing"):
+        em = torch.tensor([0.7, 0.1, 0.1, 0.05, 0.05]) if tr in ("marginal", "absorbing_edges") else None
+        nm = _noise_model(R, tr, "cow", 5, 4, e_marg=em)
+        arrays[f"{tr}/betas"] = nm._betas
+        arrays[f"{tr}/alphas_bar"] = nm._alphas_bar
+        if tr == "absorbing_edges":
+            arrays[f"{tr}/betas_abs"] = nm._betas_abs
+            arrays[f"{tr}/alphas_abs_bar"] = nm._alphas_abs_bar
+        qt, qtb = nm.get_Qt(ts), nm.get_Qt_bar(ts)
+        arrays[f"{tr}/Qt_E"], arrays[f"{tr}/Qtb_E"] = qt.E, qtb.E
+        arrays[f"{tr}/Qt_X"], arrays[f"{tr}/Qtb_X"] = qt.X, qtb.X
+    save("f7_schedules", t=ts, e_marginals=np.array([0.7, 0.1, 0.1, 0.05, 0.05], dtype=np.float32), **arrays)
+
+
+class _UniformFeed:
+    """Replaces Tensor.multinomial inside the oracle process (see module docstring)."""
+
+    def __init__(self):
+        self.queue = []
+
+    def install(self):
+        feed = self
+        self._orig = torch.Tensor.multinomial
+
+        def patched(t, num_samples, replacement=False, *, generator=None):
+            u = feed.queue.pop(0)
+            assert u.shape == (t.shape[0], num_samples), (u.shape, t.shape, num_samples)
+            return torch.from_numpy(inverse_cdf_draws(t.detach().numpy(), u))
+        torch.Tensor.multinomial = patched
+
+    def remove(self):
+        torch.Tensor.multinomial = self._orig
+
+
+def gen_reverse_step(R):
+    """F8/F9: prob_X/prob_E and sampled E_s / extra_info of sample_zs_from_zt_and_pred under injected uniforms."""
+    feed = _UniformFeed()
+    for name, tr, C, top_k in (("cow_abs", "absorbing_edges", 14, 4), ("atm_abs", "absorbing_edges", 5, 4),
+                               ("marg", "marginal", 5, 4)):
+        em = torch.tensor([0.7, 0.1, 0.1, 0.05, 0.05]) if tr == "marginal" else None
+        nm = _noise_model(R, tr, "cow", C, top_k, e_marg=em)
+        mask = fx.ragged_mask([9, 5, 1, 12], 12)
+        B, n = mask.shape
+        arrays = dict(node_mask=mask, C=C, top_k=-1 if top_k is None else top_k, transition=tr)
+        if em is not None:
+            arrays["e_marginals"] = em
+        for t in (500, 499, 250, 2, 1):
+            g = torch.Generator().manual_seed(1000 + t)
+            lab = fx.random_labels(mask, C, 0.0 if t == 500 else 0.25 * (1 - t / 500) + 0.05, 2000 + t)
+            ztE = fx.one_hot_edges(lab, mask, C)
+            ztX = mask[..., None].float()
+            logits = torch.randn(B, n, n, C, generator=g) * 2.0
+            logits = 0.5 * (logits + logits.transpose(1, 2))
+            predX = torch.randn(B, n, 1, generator=g)
+            ux = torch.rand(B * n, 1, generator=g).numpy()
+            u0 = torch.rand(B * n * n, 1, generator=g).numpy()
+            k = top_k if top_k is not None else 0
+            uk = torch.rand(B * n * n, max(k, 1), generator=g).numpy()
+            z_t = R.U.PlaceHolder(X=ztX, charges=torch.zeros(B, n, 0), E=ztE, y=torch.zeros(B, 0),
+                                  t_int=torch.full((B, 1), t), t=torch.full((B, 1), t / 500.0), node_mask=mask,
+                                  pos=torch.zeros(B, n, 3))
+            pred = R.U.PlaceHolder(X=predX, charges=torch.zeros(B, n, 0), E=logits, y=None, node_mask=mask)
+            s_int = torch.full((B, 1), t - 1)
+            # capture prob_X / prob_E as handed to sample_discrete_features (before its in-place edits)
+            captured = {}
+            orig_sdf = R.DU.sample_discrete_features
+
+            def spy(probX, probE, prob_charges, node_mask, top_k=None):
+                captured["pX"], captured["pE"] = probX.clone(), probE.clone()
+                return orig_sdf(probX, probE, prob_charges, node_mask=node_mask, top_k=top_k)
+            R.DU.sample_discrete_features = spy
+            feed.queue = [ux, u0] + ([uk] if top_k is not None else [])
+            feed.install()
+            try:
+                z_s = nm.sample_zs_from_zt_and_pred(z_t, pred, s_int)
+            finally:
+                feed.remove()
+                R.DU.sample_discrete_features = orig_sdf
+            assert not feed.queue
+            p = f"t{t}/"
+            arrays.update({p + "labels_t": lab, p + "logits_E": logits, p + "pred_X": predX,
+                           p + "ux": ux.reshape(B, n), p + "u0": u0.reshape(B, n, n),
+                           p + "uk": uk.reshape(B, n, n, -1), p + "prob_X": captured["pX"], p + "prob_E": captured["pE"],
+                           p + "X_s": z_s.X, p + "E_s": z_s.E,
+                           p + "extra_info": z_s.extra_info if z_s.extra_info is not None else np.zeros(0)})
+        save(f"f8_reverse_step_{name}", **arrays)
+
+
+def gen_sample_discrete(R):
+    """F9b: sample_discrete_features called directly, without top_k (the apply_noise / training form;
+    the reference's reverse step itself requires top_k, noise_model.py:433)."""
+    feed = _UniformFeed()
+    g = torch.Generator().manual_seed(77)
+    mask = fx.ragged_mask([6, 11, 2], 11)
+    B, n = mask.shape
+    C = 5
+    pE = torch.rand(B, n, n, C, generator=g)
+    pE[..., 3] = 0                       # a zero-probability class
+    pE = pE / pE.sum(-1, keepdim=True)
+    pX = torch.rand(B, n, 3, generator=g)
+    pX = pX / pX.sum(-1, keepdim=True)
+    ux = torch.rand(B * n, 1, generator=g).numpy()
+    u0 = torch.rand(B * n * n, 1, generator=g).numpy()
+    feed.queue = [ux, u0]
+    feed.install()
+    try:
+        out = R.DU.sample_discrete_features(pX.clone(), pE.clone(), torch.zeros(B, n, 0), mask)
+    finally:
+        feed.remove()
+    save("f9_sample_discrete_notopk", node_mask=mask, prob_X=pX, prob_E=pE, ux=ux.reshape(B, n), u0=u0.reshape(B, n, n),
+         X=out.X, E=out.E)
+
+
+def gen_placeholder(R):
+    """F11: PlaceHolder.mask / collapse."""
+    torch.manual_seed(61)
+    mask = fx.ragged_mask([5, 3], 5)
+    X, E = torch.randn(2, 5, 3), torch.randn(2, 5, 5, 4)
+    E = 0.5 * (E + E.transpose(1, 2))
+    pos = torch.randn(2, 5, 3)
+    ph = R.U.PlaceHolder(X=X.clone(), E=E.clone(), y=torch.zeros(2, 0), charges=torch.zeros(2, 5, 0), node_mask=mask,
+                         pos=pos.clone()).mask()
+    col = ph.collapse(None)
+    save("f11_placeholder", X=X, E=E, pos=pos, node_mask=mask, mX=ph.X, mE=ph.E, mpos=ph.pos, cX=col.X, cE=col.E)
+
+
+def main():
+    R = import_reference()
+    gen_block_and_layer(R)
+    gen_graph_transformer(R)
+    gen_pooling(R)
+    gen_extra_features(R)
+    gen_schedules(R)
+    gen_reverse_step(R)
+    gen_sample_discrete(R)
+    gen_placeholder(R)
+
+
+if __name__ == "__main__":
+    main()

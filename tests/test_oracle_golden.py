@@ -1,0 +1,189 @@
+"""The CPU oracle (oracle/) against the golden vectors produced by the real reference
+(oracle/gen_golden.py).  Runs without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, golden_sd, golden_shapes
+from oracle import denoiser as D
+from oracle import extra_features as XF
+from oracle import fixtures as fx
+from oracle import noise as N
+
+T = torch.from_numpy
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("py", [1, 0])
+def test_node_edge_block(py):
+    g = load_golden(f"f1_node_edge_block_y{py}")
+    sd = golden_sd(g)
+    nX, nE, ny = D.node_edge_block(sd, "", int(g["n_head"]), T(g["X"]), T(g["E"]), T(g["y"]), T(g["node_mask"]), bool(py))
+    close(nX, g["newX"], 1e-5, 1e-5)
+    close(nE, g["newE"], 1e-5, 1e-5)
+    if py:
+        close(ny, g["new_y"], 1e-5, 1e-5)
+    else:
+        assert ny is None
+
+
+def test_xey_layer():
+    g = load_golden("f2_xey_layer")
+    X, E, y = D.xey_layer(golden_sd(g), "", int(g["n_head"]), T(g["X"]), T(g["E"]), T(g["y"]), T(g["node_mask"]))
+    close(X, g["outX"], 1e-5, 1e-5)
+    close(E, g["outE"], 1e-5, 1e-5)
+    close(y, g["outy"], 1e-5, 1e-5)
+
+
+GT_CASES = [("f3_gt_tiny", fx.TINY_DIMS), ("f3_gt_tiny_noy", fx.TINY_DIMS), ("f3_gt_construct_cow", fx.CONSTRUCT_DIMS),
+            ("f3_gt_vessel_atm", fx.VESSEL_DIMS), ("f3_gt_vessel_n40", fx.VESSEL_DIMS)]
+
+
+def gt_state_dict(g):
+    sd = golden_sd(g)
+    return sd if sd else fx.make_state_dict(golden_shapes(g), int(g["seed"]))
+
+
+@pytest.mark.parametrize("name,dims", GT_CASES)
+def test_graph_transformer(name, dims):
+    g = load_golden(name)
+    od = [int(v) for v in g["out_dims"]]
+    dd = D.DenoiserDims(int(g["n_layers"]), dims["hidden_dims"]["n_head"], od[0], od[1], od[2], od[3] if len(od) > 3 else 0)
+    oX, oc, oE, oy = D.graph_transformer_forward(gt_state_dict(g), dd, T(g["X"]), T(g["E"]), T(g["y"]), T(g["node_mask"]))
+    close(oX, g["outX"], 1e-4, 1e-5)
+    close(oE, g["outE"], 1e-4, 1e-5)
+    if od[2] > 0:
+        close(oy, g["outy"], 1e-4, 1e-5)
+    else:
+        assert oy is None
+
+
+def test_pooling_and_softmax():
+    g = load_golden("f4_pooling")
+    m = T(g["node_mask"])
+    close(D.pooled_stats_nodes(T(g["X"]), m), g["zx"], 1e-5, 1e-6)
+    close(D.pooled_stats_edges(T(g["E"]), m), g["ze"], 1e-5, 1e-6)
+    Y = T(g["Y"])
+    sm = torch.softmax(Y.masked_fill(~m[:, None, :, None, None], float("-inf")), dim=2)
+    close(sm, g["softmax"], 1e-6, 1e-7)
+    close(Y, g["softmax_allmasked"])          # layers.py:47-48: returned unchanged
+
+
+@pytest.mark.parametrize("name,maxn", [("f5_extra_features", 8), ("f5_extra_features_random", 32)])
+def test_adjacency_features(name, maxn):
+    g = load_golden(name)
+    x, y, e = XF.adjacency_features(T(g["X"]), T(g["E"]), T(g["node_mask"]))
+    close(x, g["adj_x"], 1e-6, 1e-6)
+    close(y, g["adj_y"], 1e-6, 1e-6)
+    close(e, g["adj_e"], 1e-5, 1e-6)
+    evl, evc = XF.eigen_features(T(g["E"]), T(g["node_mask"]))
+    close(evl, g["eval_feat"], 1e-4, 2e-5)
+    assert evc.shape == g["evec_feat"].shape
+
+
+def test_extra_features_full():
+    g = load_golden("f5_extra_features")
+    X, E, y = XF.extra_features(T(g["X"]), T(g["E"]), T(g["node_mask"]), max_n_nodes=8)
+    assert list(X.shape) == list(g["out_X"].shape) and list(y.shape) == list(g["out_y"].shape)
+    close(E, g["out_E"], 1e-5, 1e-6)
+    close(X[..., :3], g["out_X"][..., :3], 1e-6, 1e-6)
+    close(y, g["out_y"], 1e-4, 2e-5)
+    close(XF.adjacency_powers(XF.adjacency(T(g["E"])), 10), g["kpowers"], 0, 0)
+    # eigenvector features: compared where the spectrum is simple (connected graphs: C3..K6 are degenerate,
+    # so only the LCC indicator is pinned there); the tree (graph 0) has simple low eigenvalues up to sign
+    ref = g["out_X"][..., 3:]
+    np.testing.assert_array_equal(X[..., 3].numpy()[[0, 1, 2, 3, 4, 7]], ref[..., 0][[0, 1, 2, 3, 4, 7]])
+    a, b = X[0, :, 4:6].numpy(), ref[0, :, 1:3]
+    for k in range(2):
+        s = np.sign((a[:, k] * b[:, k]).sum())
+        np.testing.assert_allclose(a[:, k] * s, b[:, k], atol=2e-4)
+    assert list(g["upd_dims"]) == [10, 25, 43]           # update_input_dims on CoW (1,14,1)
+
+
+@pytest.mark.parametrize("tr", ["absorbing_edges", "marginal", "uniform", "absorbing"])
+def test_schedules_and_Q(tr):
+    g = load_golden("f7_schedules")
+    nu = dict(x=1, c=1, e=1, y=1, e_small=1, e_mid=1, e_large=1)
+    s = N.Schedule(500, tr, nu)
+    close(s.betas, g[f"{tr}/betas"], 1e-12, 0)
+    close(s.alphas_bar, g[f"{tr}/alphas_bar"], 1e-12, 0)
+    if tr == "absorbing_edges":
+        close(s.betas_abs, g[f"{tr}/betas_abs"], 1e-12, 0)
+        close(s.alphas_abs_bar, g[f"{tr}/alphas_abs_bar"], 1e-12, 0)
+    if tr in ("marginal", "absorbing_edges"):
+        em = g["e_marginals"]
+    elif tr == "uniform":
+        em = np.ones(5, np.float32) / 5
+    else:
+        em = np.array([1, 0, 0, 0, 0], np.float32)
+    t = T(g["t"])
+    trn = N.Transition(s, [1.0], em)
+    qx, qe = trn.Qt(t)
+    qbx, qbe = trn.Qt_bar(t)
+    close(qe, g[f"{tr}/Qt_E"], 1e-6, 1e-7)
+    close(qbe, g[f"{tr}/Qtb_E"], 1e-6, 1e-7)
+    close(qx, g[f"{tr}/Qt_X"], 1e-6, 1e-7)
+    close(qbx, g[f"{tr}/Qtb_X"], 1e-6, 1e-7)
+
+
+@pytest.mark.parametrize("name", ["cow_abs", "atm_abs", "marg"])
+def test_reverse_step(name):
+    g = load_golden(f"f8_reverse_step_{name}")
+    tr_name = str(g["transition"])
+    C, top_k = int(g["C"]), int(g["top_k"])
+    nu = dict(x=1, c=1, e=1, y=1, e_small=1, e_mid=1, e_large=1)
+    em = g["e_marginals"] if "e_marginals" in g else np.ones(C, np.float32) / C
+    trn = N.Transition(N.Schedule(500, tr_name, nu), [1.0], em)
+    m = T(g["node_mask"])
+    B, n = m.shape
+    for t in (500, 499, 250, 2, 1):
+        p = f"t{t}/"
+        ztE = fx.one_hot_edges(T(g[p + "labels_t"]), m, C)
+        ztX = m[..., None].float()
+        r = N.reverse_step(trn, ztX, ztE, T(g[p + "pred_X"]), T(g[p + "logits_E"]), m,
+                           torch.full((B, 1), t), torch.full((B, 1), t - 1), g[p + "ux"], g[p + "u0"], g[p + "uk"])
+        close(r["prob_E"], g[p + "prob_E"], 1e-5, 1e-7)
+        close(r["prob_X"], g[p + "prob_X"], 1e-6, 1e-7)
+        # bit-exact sampling: feed the reference's own probabilities to the oracle sampler
+        es, extra = N.sample_edges(T(g[p + "prob_E"]), m, g[p + "u0"], g[p + "uk"])
+        pm = (m[:, :, None] & m[:, None, :]) & ~torch.eye(n, dtype=torch.bool)[None]
+        E_s = torch.nn.functional.one_hot(es, C).float() * pm[..., None]
+        np.testing.assert_array_equal(E_s.numpy(), g[p + "E_s"])
+        np.testing.assert_array_equal((extra * pm[..., None]).numpy(), g[p + "extra_info"])
+        # and end to end (own probabilities): identical here as well
+        np.testing.assert_array_equal(r["E_s"].numpy(), g[p + "E_s"])
+        np.testing.assert_array_equal(r["extra_info"].numpy(), g[p + "extra_info"])
+        np.testing.assert_array_equal(r["X_s"].numpy(), g[p + "X_s"])
+
+
+def test_sample_discrete_without_topk():
+    g = load_golden("f9_sample_discrete_notopk")
+    m = T(g["node_mask"])
+    e, extra = N.sample_edges(T(g["prob_E"]), m, g["u0"], None)
+    assert extra is None
+    np.testing.assert_array_equal(e.numpy(), g["E"])
+    np.testing.assert_array_equal(N.sample_nodes(T(g["prob_X"]), m, g["ux"]).numpy(), g["X"])
+
+
+def test_placeholder_mask():
+    g = load_golden("f11_placeholder")
+    X, E = D.mask_xe(T(g["X"]), T(g["E"]), T(g["node_mask"]))
+    close(X, g["mX"], 0, 0)
+    close(E, g["mE"], 0, 0)
+
+
+def test_philox_known_answer():
+    # Random123 known-answer vectors for philox4x32-10
+    z = np.zeros((1, 4), np.uint32)
+    out = N.philox4x32_10(z, np.zeros(2, np.uint32))[0]
+    assert [hex(int(v)) for v in out] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    f = np.full((1, 4), 0xFFFFFFFF, np.uint32)
+    out = N.philox4x32_10(f, np.full(2, 0xFFFFFFFF, np.uint32))[0]
+    assert [hex(int(v)) for v in out] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    pi = np.array([[0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344]], np.uint32)
+    out = N.philox4x32_10(pi, np.array([0xA4093822, 0x299F31D0], np.uint32))[0]
+    assert [hex(int(v)) for v in out] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
