@@ -1,0 +1,130 @@
+/* scgg.h -- C ABI of the MI355X (gfx950) discrete edge-diffusion hot path.
+ *
+ * The reference (chinmay5/semantically_consistent_graph_generation) is pure Python and has no FFI layer; its
+ * boundary for this path is four Python call sites in src/ConStruct/diffusion_model_discrete_3d.py
+ * (SURVEY.md section 8b).  Each entry point below names the reference interface it replaces.  The Python modules
+ * of semantically_consistent_graph_generation_amd/ bind these symbols with ctypes (INTEGRATION.md shows the stub)
+ * and keep the reference's class / method names on top.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP, current device) unless its name ends in _host;
+ *   - tensors are dense row-major fp32 with the reference's axis order: X[B,n,d], E[B,n,n,d], y[B,d];
+ *   - node_mask is uint8 [B,n] (torch.bool storage);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work and never
+ *     synchronise; after scgg_denoiser_finalize none of the compute calls allocates;
+ *   - return value 0 = ok, negative = error; scgg_last_error() gives the message of the calling thread's last
+ *     failure.  Nothing here falls back to a CPU path.
+ */
+#ifndef SCGG_H
+#define SCGG_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int scgg_version(void);
+const char* scgg_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Denoiser: GraphTransformer  (src/ConStruct/models/transformer_model.py:251-389; layers :15-248;
+ * pooling src/ConStruct/models/layers.py:5-51; masking src/ConStruct/utils.py:134-167).
+ * Constructed at diffusion_model_discrete_3d.py:111-132 and called at :201.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct scgg_denoiser scgg_denoiser;
+
+typedef struct scgg_denoiser_config {
+  int32_t n_layers;
+  int32_t in_X, in_E, in_y;            /* input_dims.X (+charges), .E, .y                      (:282,:291,:299) */
+  int32_t out_X, out_E, out_y;         /* output_dims.X + output_dims.charges, .E, .y          (:326,:333,:341) */
+  int32_t hid_X, hid_E, hid_y;         /* hidden_mlp_dims                                                    */
+  int32_t dx, de, dy, n_head;          /* hidden_dims                                                        */
+  int32_t dim_ffX, dim_ffE, dim_ffy;   /* dim_ffy: the layer's real lin_y1 width (2048 in the reference, :34) */
+} scgg_denoiser_config;
+
+/* replaces GraphTransformer.__init__ (:257-342).  Returns NULL on unsupported dims (scgg_last_error says why). */
+scgg_denoiser* scgg_denoiser_create(const scgg_denoiser_config* cfg);
+void scgg_denoiser_destroy(scgg_denoiser* h);
+
+/* Borrow one parameter tensor by its reference state_dict name ("tf_layers.0.self_attn.q.weight", ...;
+ * SURVEY.md section 8b lists them).  The pointer must stay valid; the data is read at finalize / refresh time. */
+int scgg_denoiser_set_param(scgg_denoiser* h, const char* name, const float* data, int64_t numel);
+
+/* Checks that every parameter is present, allocates the packed-weight arena (the only allocation) and packs.
+ * scgg_denoiser_refresh re-packs from the same borrowed pointers after the caller changed the weights. */
+int scgg_denoiser_finalize(scgg_denoiser* h, void* stream);
+int scgg_denoiser_refresh(scgg_denoiser* h, void* stream);
+
+size_t scgg_denoiser_workspace_bytes(const scgg_denoiser* h, int32_t B, int32_t n);
+
+/* replaces GraphTransformer.forward (:344-389), eval mode.
+ *   X[B,n,in_X] E[B,n,n,in_E] y[B,in_y] node_mask[B,n]
+ *   out_X[B,n,out_X] (X and charges concatenated, masked), out_E[B,n,n,out_E] (symmetric, zero diagonal, masked),
+ *   out_y[B,out_y] (may be NULL when out_y == 0).  Inputs are not modified.  workspace: >= workspace_bytes(B,n),
+ *   256-byte aligned, contents irrelevant. */
+int scgg_denoiser_forward(scgg_denoiser* h, const float* X, const float* E, const float* y, const uint8_t* node_mask,
+                          int32_t B, int32_t n, float* out_X, float* out_E, float* out_y, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* Debug / test tap: runs the input MLPs and the first `n_run_layers` layers of the same network and returns the
+ * hidden state as the reference holds it after that layer (transformer_model.py:360-369): hid_X[B,n,dx],
+ * hid_E[B,n,n,de] (symmetrised, masked), hid_y[B,dy].  Any output pointer may be NULL. */
+int scgg_denoiser_forward_hidden(scgg_denoiser* h, const float* X, const float* E, const float* y,
+                                 const uint8_t* node_mask, int32_t B, int32_t n, int32_t n_run_layers, float* hid_X,
+                                 float* hid_E, float* hid_y, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Reverse step: NoiseModel.sample_zs_from_zt_and_pred (src/ConStruct/diffusion/noise_model.py:342-447) with
+ * sample_discrete_features (src/ConStruct/diffusion/diffusion_utils.py:200-285).  Called at
+ * diffusion_model_discrete_3d.py:749.
+ *
+ * Edge state is carried as int8 labels [B,n,n]: class index, or -1 where the reference's one-hot row is the zero
+ * vector (diagonal and padded pairs, utils.py:154).  Randomness: either explicit uniforms (u0[B,n,n] for the single
+ * draw, uk[B,n,n,top_k] for the top-k draw) or, when u0 == NULL, Philox4x32-10 keyed by (seed; i, j,
+ * graph_id_base + b, step).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct scgg_rng {
+  const float* u0;
+  const float* uk;
+  uint64_t seed;
+  uint32_t step;
+  uint32_t graph_id_base;
+} scgg_rng;
+
+/* E branch of sample_zs_from_zt_and_pred for every transition of the form Q = a I + (1-a) 1 m^T
+ * (uniform, marginal, absorbing, absorbing_edges):  beta_tab / abar_tab are the [T+1] fp32 tables of the E branch
+ * (get_Qt :101-125 / :524-537, get_Qt_bar :127-154 / :539-552), marginals = limit distribution m[C].
+ * t_int / s_int are int32 [B].  prob_out (optional) receives prob_E as handed to the sampler. */
+int scgg_reverse_step_edges(const float* logits_E, const int8_t* labels_t, const uint8_t* node_mask,
+                            const int32_t* t_int, const int32_t* s_int, const float* beta_tab, const float* abar_tab,
+                            const float* marginals, int32_t B, int32_t n, int32_t C, int32_t top_k,
+                            const scgg_rng* rng, int8_t* labels_s, int8_t* cands_s, float* prob_out, void* stream);
+
+/* E branch of sample_discrete_features alone (probabilities given): used by apply_noise (noise_model.py:207)
+ * and by the bit-exactness tests.  top_k == 0 -> no candidates (diffusion_utils.py:275-277). */
+int scgg_sample_edges_from_probs(const float* prob_E, const uint8_t* node_mask, int32_t B, int32_t n, int32_t C,
+                                 int32_t top_k, const scgg_rng* rng, int8_t* labels, int8_t* cands, void* stream);
+
+/* conversions between the int8 state and the reference's tensors: one-hot float E (zero rows where label < 0) and
+ * int64 extra_info (noise_model.py:412,:445; utils.py:154,:166) */
+int scgg_labels_to_onehot(const int8_t* labels, const int8_t* cands, int64_t n_pairs, int32_t C, int32_t top_k,
+                          float* E_onehot, int64_t* extra_info, void* stream);
+int scgg_onehot_to_labels(const float* E_onehot, int64_t n_pairs, int32_t C, int8_t* labels, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Extra features: ExtraFeatures.__call__ without the eigen part (src/ConStruct/diffusion/extra_features.py:60-77,
+ * AdjacencyFeatures :198-385).  Called at diffusion_model_discrete_3d.py:186.
+ *   labels int8 [B,n,n] (adjacency = label > 0), node_mask.
+ *   x_out[B,n,3]  y_out[B, 4 + (num_degree+2) + 1 + C]  (cycles | degree hist | node hist (1 class) | edge hist)
+ *   e_out[B,n,n,max_degree+1]  (reachability A^1..A^max_degree | Adamic-Adar)
+ *   lap_out[B,n,n] (optional): the padded Laplacian EigenFeatures hands to eigh (:88-94).
+ * ---------------------------------------------------------------------------------------------------------- */
+int scgg_adjacency_features(const int8_t* labels, const uint8_t* node_mask, int32_t B, int32_t n, int32_t C,
+                            int32_t num_degree, int32_t max_degree, int32_t cycle_features, float* x_out,
+                            float* y_out, float* e_out, float* lap_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCGG_H */

@@ -1,0 +1,85 @@
+"""ctypes binding of libscgg.so (C ABI: include/scgg.h).  Fails loudly when the library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscgg.so")
+
+c_f32p = C.c_void_p
+_i32, _i64, _vp, _sz = C.c_int32, C.c_int64, C.c_void_p, C.c_size_t
+
+
+class DenoiserConfig(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in (
+        "n_layers", "in_X", "in_E", "in_y", "out_X", "out_E", "out_y", "hid_X", "hid_E", "hid_y",
+        "dx", "de", "dy", "n_head", "dim_ffX", "dim_ffE", "dim_ffy")]
+
+
+class Rng(C.Structure):
+    _fields_ = [("u0", C.c_void_p), ("uk", C.c_void_p), ("seed", C.c_uint64), ("step", C.c_uint32),
+                ("graph_id_base", C.c_uint32)]
+
+
+SIGNATURES = {
+    "scgg_version": (C.c_int, []),
+    "scgg_last_error": (C.c_char_p, []),
+    "scgg_denoiser_create": (_vp, [C.POINTER(DenoiserConfig)]),
+    "scgg_denoiser_destroy": (None, [_vp]),
+    "scgg_denoiser_set_param": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),
+    "scgg_denoiser_finalize": (C.c_int, [_vp, _vp]),
+    "scgg_denoiser_refresh": (C.c_int, [_vp, _vp]),
+    "scgg_denoiser_workspace_bytes": (_sz, [_vp, _i32, _i32]),
+    "scgg_denoiser_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "scgg_denoiser_forward_hidden": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "scgg_reverse_step_edges": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
+                                          C.POINTER(Rng), _vp, _vp, _vp, _vp]),
+    "scgg_sample_edges_from_probs": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(Rng), _vp, _vp, _vp]),
+    "scgg_labels_to_onehot": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "scgg_onehot_to_labels": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    "scgg_adjacency_features": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class ScggError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libscgg.so once.  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ScggError(f"{LIB_PATH} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()' "
+                            f"or make -C {_HERE}/csrc).  There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "scgg"):
+    if rc != 0:
+        raise ScggError(f"{what}: {lib().scgg_last_error().decode()}")
+
+
+def ptr(t):
+    """device pointer of a contiguous CUDA(HIP) tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ScggError("scgg kernels need tensors on the GPU (there is no CPU path)")
+    if not t.is_contiguous():
+        raise ScggError("scgg kernels need contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,511 @@
+// Host-side engine behind scgg_denoiser_* (include/scgg.h): owns the packed-weight arena, lays out the caller's
+// workspace and enqueues the kernels of one GraphTransformer forward on one HIP stream.  No torch types, no
+// synchronisation, no allocation after finalize.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/scgg.h"
+#include "kernels.h"
+#include "sampling.h"
+
+namespace scgg {
+
+static thread_local char g_err[512] = "";
+
+int fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return -1;
+}
+const char* last_error() { return g_err; }
+
+static int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail("%s: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+static inline int pad32(int v) { return (v + 31) / 32 * 32; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Param {
+  const float* p;
+  int64_t numel;
+};
+
+struct PackedLinear {   // chain-kernel operand
+  f32x4_t* W = nullptr;
+  float* b = nullptr;
+  int N = 0, K = 0;
+};
+
+struct LayerPack {
+  bool predicts_y = true;
+  PackedLinear e_mul, e_add, e_out, ff1, ff2;
+  float *ln1_g, *ln1_b, *ln2_g, *ln2_b;      // padded copies
+  float *Wqkv, *bqkv;                        // [3dx,dx]
+  float *Wfilm, *bfilm;                      // [4dx,dy]
+  float *Wycat, *bycat;                      // [dy, dy+4dx+4de]
+};
+
+}  // namespace scgg
+
+using namespace scgg;
+
+struct scgg_denoiser {
+  scgg_denoiser_config c;
+  std::map<std::string, Param> params;
+  bool finalized = false;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  PackedLinear in_E1, in_E2, out_E1, out_E2;
+  std::vector<LayerPack> layers;
+};
+
+namespace {
+
+struct Arena {   // two-pass bump allocator: first pass measures, second pass hands out pointers
+  char* base;
+  size_t off = 0;
+  explicit Arena(char* b) : base(b) {}
+  template <typename T>
+  T* take(size_t count) {
+    off = align_up(off, 256);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+const Param* find(const scgg_denoiser* h, const std::string& name, int64_t numel) {
+  auto it = h->params.find(name);
+  if (it == h->params.end()) {
+    fail("missing parameter '%s'", name.c_str());
+    return nullptr;
+  }
+  if (it->second.numel != numel) {
+    fail("parameter '%s' has %lld elements, expected %lld", name.c_str(), (long long)it->second.numel,
+         (long long)numel);
+    return nullptr;
+  }
+  return &it->second;
+}
+
+// allocate (+ optionally fill) one packed Linear for the chain kernels
+int pack_linear(scgg_denoiser* h, Arena& ar, bool fill, const std::string& name, int N, int K, float bias_add,
+                PackedLinear& out, hipStream_t st) {
+  const int NB = (N + 31) / 32, KB = (K + 31) / 32;
+  out.N = N;
+  out.K = K;
+  out.W = ar.take<f32x4_t>((size_t)NB * KB * 256);
+  out.b = ar.take<float>((size_t)NB * 32);
+  if (!fill) return 0;
+  const Param* w = find(h, name + ".weight", (int64_t)N * K);
+  const Param* b = find(h, name + ".bias", N);
+  if (!w || !b) return -1;
+  PackArgs pa{w->p, out.W, N, K, NB, KB};
+  launch_pack_linear(pa, st);
+  launch_pad_vec(b->p, out.b, N, NB * 32, bias_add, st);
+  return check_launch("pack_linear");
+}
+
+int pad_vec(scgg_denoiser* h, Arena& ar, bool fill, const std::string& name, int n, float*& out, hipStream_t st) {
+  out = ar.take<float>((size_t)pad32(n));
+  if (!fill) return 0;
+  const Param* v = find(h, name, n);
+  if (!v) return -1;
+  launch_pad_vec(v->p, out, n, pad32(n), 0.f, st);
+  return check_launch("pad_vec");
+}
+
+// dst[N, ldd] columns [col0, col0+K) <- W[N,K]
+int put_cols(scgg_denoiser* h, const std::string& name, int N, int K, float* dst, int ldd, int col0, hipStream_t st) {
+  const Param* w = find(h, name, (int64_t)N * K);
+  if (!w) return -1;
+  launch_copy_cols(w->p, K, dst + col0, ldd, N, K, st);
+  return 0;
+}
+
+__global__ void vec_sum3_kernel(const float* a, const float* b, const float* c, float* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + b[i] + c[i];
+}
+
+int build(scgg_denoiser* h, bool fill, hipStream_t st) {
+  const scgg_denoiser_config& c = h->c;
+  Arena ar(fill ? h->arena : nullptr);
+  if (pack_linear(h, ar, fill, "mlp_in_E.0", c.hid_E, c.in_E, 0.f, h->in_E1, st)) return -1;
+  if (pack_linear(h, ar, fill, "mlp_in_E.3", c.de, c.hid_E, 0.f, h->in_E2, st)) return -1;
+  if (pack_linear(h, ar, fill, "mlp_out_E.0", c.hid_E, c.de, 0.f, h->out_E1, st)) return -1;
+  if (pack_linear(h, ar, fill, "mlp_out_E.3", c.out_E, c.hid_E, 0.f, h->out_E2, st)) return -1;
+  h->layers.resize(c.n_layers);
+  const int dx = c.dx, de = c.de, dy = c.dy;
+  const int kcat = dy + 4 * dx + 4 * de;
+  for (int l = 0; l < c.n_layers; ++l) {
+    LayerPack& L = h->layers[l];
+    L.predicts_y = (l != c.n_layers - 1) || c.out_y > 0;
+    const std::string p = "tf_layers." + std::to_string(l) + ".";
+    const std::string sa = p + "self_attn.";
+    if (pack_linear(h, ar, fill, sa + "e_mul", dx, de, 1.0f, L.e_mul, st)) return -1;   // bias + 1
+    if (pack_linear(h, ar, fill, sa + "e_add", dx, de, 0.f, L.e_add, st)) return -1;
+    if (pack_linear(h, ar, fill, sa + "e_out", de, dx, 0.f, L.e_out, st)) return -1;
+    if (pack_linear(h, ar, fill, p + "linE1", c.dim_ffE, de, 0.f, L.ff1, st)) return -1;
+    if (pack_linear(h, ar, fill, p + "linE2", de, c.dim_ffE, 0.f, L.ff2, st)) return -1;
+    if (pad_vec(h, ar, fill, p + "normE1.weight", de, L.ln1_g, st)) return -1;
+    if (pad_vec(h, ar, fill, p + "normE1.bias", de, L.ln1_b, st)) return -1;
+    if (pad_vec(h, ar, fill, p + "normE2.weight", de, L.ln2_g, st)) return -1;
+    if (pad_vec(h, ar, fill, p + "normE2.bias", de, L.ln2_b, st)) return -1;
+    L.Wqkv = ar.take<float>((size_t)3 * dx * dx);
+    L.bqkv = ar.take<float>((size_t)3 * dx);
+    L.Wfilm = ar.take<float>((size_t)4 * dx * dy);
+    L.bfilm = ar.take<float>((size_t)4 * dx);
+    L.Wycat = ar.take<float>((size_t)dy * kcat);
+    L.bycat = ar.take<float>((size_t)dy);
+    if (!fill) continue;
+    const char* qkv[3] = {"q", "k", "v"};
+    for (int t = 0; t < 3; ++t) {
+      if (put_cols(h, sa + qkv[t] + ".weight", dx, dx, L.Wqkv + (size_t)t * dx * dx, dx, 0, st)) return -1;
+      if (put_cols(h, sa + qkv[t] + ".bias", 1, dx, L.bqkv + (size_t)t * dx, dx, 0, st)) return -1;
+    }
+    const char* fl[4] = {"y_e_add", "y_e_mul", "y_x_add", "y_x_mul"};
+    for (int t = 0; t < 4; ++t) {
+      if (put_cols(h, sa + fl[t] + ".weight", dx, dy, L.Wfilm + (size_t)t * dx * dy, dy, 0, st)) return -1;
+      if (put_cols(h, sa + fl[t] + ".bias", 1, dx, L.bfilm + (size_t)t * dx, dx, 0, st)) return -1;
+    }
+    if (L.predicts_y) {
+      if (put_cols(h, sa + "y_y.weight", dy, dy, L.Wycat, kcat, 0, st)) return -1;
+      if (put_cols(h, sa + "x_y.lin.weight", dy, 4 * dx, L.Wycat, kcat, dy, st)) return -1;
+      if (put_cols(h, sa + "e_y.lin.weight", dy, 4 * de, L.Wycat, kcat, dy + 4 * dx, st)) return -1;
+      const Param* b0 = find(h, sa + "y_y.bias", dy);
+      const Param* b1 = find(h, sa + "x_y.lin.bias", dy);
+      const Param* b2 = find(h, sa + "e_y.lin.bias", dy);
+      if (!b0 || !b1 || !b2) return -1;
+      hipLaunchKernelGGL(vec_sum3_kernel, dim3((dy + 255) / 256), dim3(256), 0, st, b0->p, b1->p, b2->p, L.bycat, dy);
+    }
+    if (check_launch("concat weights")) return -1;
+  }
+  h->arena_bytes = align_up(ar.off, 256);
+  return 0;
+}
+
+struct Workspace {
+  float *Xh, *qkv, *newX, *t1, *t2, *E0, *E1, *y, *ycat, *yt1, *yt2, *film, *hidX, *hidy, *xo;
+  size_t bytes;
+};
+
+Workspace carve(const scgg_denoiser_config& c, int B, int n, char* base) {
+  Arena ar(base);
+  Workspace w;
+  const size_t M = (size_t)B * n, P = M * n;
+  const int kcat = c.dy + 4 * c.dx + 4 * c.de;
+  w.Xh = ar.take<float>(M * c.dx);
+  w.qkv = ar.take<float>(M * 3 * c.dx);
+  w.newX = ar.take<float>(M * c.dx);
+  w.t1 = ar.take<float>(M * c.dx);
+  w.t2 = ar.take<float>(M * (size_t)(c.dim_ffX > c.hid_X ? c.dim_ffX : c.hid_X));
+  w.E0 = ar.take<float>(P * c.de);
+  w.E1 = ar.take<float>(P * c.de);
+  w.y = ar.take<float>((size_t)B * c.dy);
+  w.ycat = ar.take<float>((size_t)B * kcat);
+  w.yt1 = ar.take<float>((size_t)B * c.dy);
+  const int ywide = c.dim_ffy > c.hid_y ? c.dim_ffy : c.hid_y;
+  w.yt2 = ar.take<float>((size_t)B * (ywide > c.dy ? ywide : c.dy));
+  w.film = ar.take<float>((size_t)B * 4 * c.dx);
+  w.hidX = ar.take<float>(M * c.hid_X);
+  w.hidy = ar.take<float>((size_t)B * c.hid_y);
+  w.xo = ar.take<float>(M * (size_t)(c.out_X > 0 ? c.out_X : 1));
+  w.bytes = align_up(ar.off, 256);
+  return w;
+}
+
+int gemm(const float* A, int lda, const Param* W, const Param* bias, float* C, int ldc, int M, int N, int K, int flags,
+         const uint8_t* rowmask, hipStream_t st) {
+  if (!W || !bias) return -1;
+  GemmArgs g{A, W->p, bias->p, C, rowmask, M, N, K, lda, K, ldc, flags, 0, 0, 0, 0};
+  return launch_gemm(g, st);
+}
+
+int gemm_raw(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K,
+             int flags, const uint8_t* rowmask, hipStream_t st, int lo = 0, int hi = 0, int lo2 = 0, int hi2 = 0) {
+  GemmArgs g{A, W, bias, C, rowmask, M, N, K, lda, K, ldc, flags, lo, hi, lo2, hi2};
+  return launch_gemm(g, st);
+}
+
+const Param* P_(scgg_denoiser* h, const std::string& name, int64_t numel) { return find(h, name, numel); }
+
+// sym + mask copy of an unsymmetrised hidden E into a caller buffer (debug tap only)
+__global__ void sym_copy_kernel(const float* E, const uint8_t* mask, float* out, int B, int n, int de) {
+  const long long idx = blockIdx.x * 256ll + threadIdx.x;
+  const long long total = (long long)B * n * n * de;
+  if (idx >= total) return;
+  const int c = idx % de;
+  const long long pr = idx / de;
+  const int j = pr % n;
+  const long long bi = pr / n;
+  const int i = bi % n, b = bi / n;
+  const bool live = i != j && mask[b * n + i] && mask[b * n + j];
+  out[idx] = live ? 0.5f * (E[idx] + E[(((long long)b * n + j) * n + i) * de + c]) : 0.f;
+}
+
+int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y, const uint8_t* mask, int B, int n,
+                int n_run_layers, bool tap, float* o1, float* o2, float* o3, void* workspace, size_t ws_bytes,
+                hipStream_t st) {
+  if (!h || !h->finalized) return fail("denoiser not finalized");
+  if (B <= 0 || n <= 0) return fail("bad batch shape B=%d n=%d", B, n);
+  const scgg_denoiser_config& c = h->c;
+  if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) return fail("workspace must be 256-byte aligned");
+  Workspace w = carve(c, B, n, static_cast<char*>(workspace));
+  if (ws_bytes < w.bytes) return fail("workspace too small: %zu < %zu", ws_bytes, w.bytes);
+  const int M = B * n;
+  const int dx = c.dx, de = c.de, dy = c.dy;
+  const int kcat = dy + 4 * dx + 4 * de;
+
+  // ---- input MLPs (transformer_model.py:358-366)
+  if (gemm(X, c.in_X, P_(h, "mlp_in_X.0.weight", (int64_t)c.hid_X * c.in_X), P_(h, "mlp_in_X.0.bias", c.hid_X), w.hidX,
+           c.hid_X, M, c.hid_X, c.in_X, GEMM_RELU, nullptr, st)) return -1;
+  if (gemm(w.hidX, c.hid_X, P_(h, "mlp_in_X.3.weight", (int64_t)dx * c.hid_X), P_(h, "mlp_in_X.3.bias", dx), w.Xh, dx, M,
+           dx, c.hid_X, GEMM_RELU | GEMM_ROWMASK, mask, st)) return -1;
+  if (gemm(y, c.in_y, P_(h, "mlp_in_y.0.weight", (int64_t)c.hid_y * c.in_y), P_(h, "mlp_in_y.0.bias", c.hid_y), w.hidy,
+           c.hid_y, B, c.hid_y, c.in_y, GEMM_RELU, nullptr, st)) return -1;
+  if (gemm(w.hidy, c.hid_y, P_(h, "mlp_in_y.3.weight", (int64_t)dy * c.hid_y), P_(h, "mlp_in_y.3.bias", dy), w.y, dy, B,
+           dy, c.hid_y, GEMM_RELU, nullptr, st)) return -1;
+  {
+    EdgeMlpInArgs a{E, mask, h->in_E1.W, h->in_E1.b, h->in_E2.W, h->in_E2.b, w.E0, B, n, c.in_E};
+    if (launch_edge_mlp_in(a, c.in_E, c.hid_E, de, st)) return fail("edge_mlp_in: unsupported dims");
+  }
+  float* Ecur = w.E0;
+  float* Enext = w.E1;
+
+  // ---- layers (transformer_model.py:76-112, :165-248)
+  for (int l = 0; l < n_run_layers; ++l) {
+    LayerPack& L = h->layers[l];
+    const std::string p = "tf_layers." + std::to_string(l) + ".";
+    const std::string sa = p + "self_attn.";
+    // q|k|v masked, y-FiLM vectors (with the +1 folded in)
+    if (gemm_raw(w.Xh, dx, L.Wqkv, L.bqkv, w.qkv, 3 * dx, M, 3 * dx, dx, GEMM_ROWMASK, mask, st)) return -1;
+    if (gemm_raw(w.y, dy, L.Wfilm, L.bfilm, w.film, 4 * dx, B, 4 * dx, dy, GEMM_ADD_ONE_COLS, nullptr, st, dx, 2 * dx,
+                 3 * dx, 4 * dx)) return -1;
+    if (L.predicts_y) {   // pooled statistics of the layer INPUT (transformer_model.py:239-243)
+      launch_copy_cols(w.y, dy, w.ycat, kcat, B, dy, st);
+      NodeStatsArgs ns{w.Xh, mask, w.ycat, B, n, dx, kcat, dy};
+      launch_node_stats(ns, st);
+      EdgeStatsArgs es{Ecur, mask, w.ycat, B, n, de, kcat, dy + 4 * dx};
+      if (launch_edge_stats(es, st)) return fail("edge_stats: unsupported de=%d", de);
+    }
+    {
+      EdgeLayerArgs a;
+      a.E_in = Ecur; a.E_out = Enext; a.mask = mask;
+      a.Q = w.qkv; a.K = w.qkv + dx; a.V = w.qkv + 2 * dx; a.ldqkv = 3 * dx;
+      a.film = w.film; a.newX_pre = w.newX;
+      a.W_mul = L.e_mul.W; a.W_add = L.e_add.W; a.W_out = L.e_out.W; a.W_ff1 = L.ff1.W; a.W_ff2 = L.ff2.W;
+      a.b_mul1 = L.e_mul.b; a.b_add = L.e_add.b; a.b_out = L.e_out.b; a.b_ff1 = L.ff1.b; a.b_ff2 = L.ff2.b;
+      a.ln1_g = L.ln1_g; a.ln1_b = L.ln1_b; a.ln2_g = L.ln2_g; a.ln2_b = L.ln2_b;
+      a.inv_sqrt_df = 1.0f / sqrtf((float)(dx / c.n_head));
+      a.B = B; a.n = n;
+      if (launch_edge_layer(a, dx, de, c.dim_ffE, st)) return fail("edge_layer: unsupported dims dx=%d de=%d ffE=%d", dx, de, c.dim_ffE);
+    }
+    // X path (transformer_model.py:234-235, :88-92)
+    if (gemm(w.newX, dx, P_(h, sa + "x_out.weight", (int64_t)dx * dx), P_(h, sa + "x_out.bias", dx), w.t1, dx, M, dx, dx,
+             GEMM_ROWMASK, mask, st)) return -1;
+    {
+      const Param* g1 = P_(h, p + "normX1.weight", dx); const Param* b1 = P_(h, p + "normX1.bias", dx);
+      const Param* g2 = P_(h, p + "normX2.weight", dx); const Param* b2 = P_(h, p + "normX2.bias", dx);
+      if (!g1 || !b1 || !g2 || !b2) return -1;
+      AddLnArgs ln1{w.Xh, w.t1, g1->p, b1->p, nullptr, w.Xh, M, dx};
+      if (launch_add_layernorm(ln1, st)) return fail("layernorm width %d unsupported", dx);
+      if (gemm(w.Xh, dx, P_(h, p + "linX1.weight", (int64_t)c.dim_ffX * dx), P_(h, p + "linX1.bias", c.dim_ffX), w.t2,
+               c.dim_ffX, M, c.dim_ffX, dx, GEMM_RELU, nullptr, st)) return -1;
+      if (gemm(w.t2, c.dim_ffX, P_(h, p + "linX2.weight", (int64_t)dx * c.dim_ffX), P_(h, p + "linX2.bias", dx), w.t1, dx,
+               M, dx, c.dim_ffX, 0, nullptr, st)) return -1;
+      AddLnArgs ln2{w.Xh, w.t1, g2->p, b2->p, mask, w.Xh, M, dx};
+      launch_add_layernorm(ln2, st);
+    }
+    // y path (transformer_model.py:239-246, :101-106)
+    if (L.predicts_y) {
+      if (gemm_raw(w.ycat, kcat, L.Wycat, L.bycat, w.yt1, dy, B, dy, kcat, 0, nullptr, st)) return -1;
+      if (gemm(w.yt1, dy, P_(h, sa + "y_out.0.weight", (int64_t)dy * dy), P_(h, sa + "y_out.0.bias", dy), w.yt2, dy, B, dy,
+               dy, GEMM_RELU, nullptr, st)) return -1;
+      if (gemm(w.yt2, dy, P_(h, sa + "y_out.2.weight", (int64_t)dy * dy), P_(h, sa + "y_out.2.bias", dy), w.yt1, dy, B, dy,
+               dy, 0, nullptr, st)) return -1;
+      const Param* g1 = P_(h, p + "norm_y1.weight", dy); const Param* b1 = P_(h, p + "norm_y1.bias", dy);
+      const Param* g2 = P_(h, p + "norm_y2.weight", dy); const Param* b2 = P_(h, p + "norm_y2.bias", dy);
+      if (!g1 || !b1 || !g2 || !b2) return -1;
+      AddLnArgs ln1{w.y, w.yt1, g1->p, b1->p, nullptr, w.y, B, dy};
+      launch_add_layernorm(ln1, st);
+      if (gemm(w.y, dy, P_(h, p + "lin_y1.weight", (int64_t)c.dim_ffy * dy), P_(h, p + "lin_y1.bias", c.dim_ffy), w.yt2,
+               c.dim_ffy, B, c.dim_ffy, dy, GEMM_RELU, nullptr, st)) return -1;
+      if (gemm(w.yt2, c.dim_ffy, P_(h, p + "lin_y2.weight", (int64_t)dy * c.dim_ffy), P_(h, p + "lin_y2.bias", dy), w.yt1,
+               dy, B, dy, c.dim_ffy, 0, nullptr, st)) return -1;
+      AddLnArgs ln2{w.y, w.yt1, g2->p, b2->p, nullptr, w.y, B, dy};
+      launch_add_layernorm(ln2, st);
+    }
+    float* t = Ecur; Ecur = Enext; Enext = t;
+    if (check_launch("layer")) return -1;
+  }
+
+  if (tap) {
+    if (o1) launch_copy_cols(w.Xh, dx, o1, dx, M, dx, st);
+    if (o2) {
+      const long long total = (long long)M * n * de;
+      hipLaunchKernelGGL(sym_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ecur, mask, o2, B, n, de);
+    }
+    if (o3) launch_copy_cols(w.y, dy, o3, dy, B, dy, st);
+    return check_launch("tap");
+  }
+
+  // ---- output MLPs (transformer_model.py:371-389)
+  if (c.out_X > 0) {
+    if (gemm(w.Xh, dx, P_(h, "mlp_out_X.0.weight", (int64_t)c.hid_X * dx), P_(h, "mlp_out_X.0.bias", c.hid_X), w.hidX,
+             c.hid_X, M, c.hid_X, dx, GEMM_RELU, nullptr, st)) return -1;
+    if (gemm(w.hidX, c.hid_X, P_(h, "mlp_out_X.3.weight", (int64_t)c.out_X * c.hid_X), P_(h, "mlp_out_X.3.bias", c.out_X),
+             w.xo, c.out_X, M, c.out_X, c.hid_X, 0, nullptr, st)) return -1;
+    launch_x_out_residual(w.xo, X, c.in_X, mask, o1, M, c.out_X, st);
+  }
+  {
+    EdgeMlpOutArgs a{Ecur, E, mask, h->out_E1.W, h->out_E1.b, h->out_E2.W, h->out_E2.b, o2, B, n, c.in_E, c.out_E};
+    if (launch_edge_mlp_out(a, de, c.hid_E, st)) return fail("edge_mlp_out: unsupported dims");
+  }
+  if (c.out_y > 0) {
+    if (!o3) return fail("out_y requested by the config but out_y pointer is NULL");
+    if (gemm(w.y, dy, P_(h, "mlp_out_y.0.weight", (int64_t)c.hid_y * dy), P_(h, "mlp_out_y.0.bias", c.hid_y), w.hidy,
+             c.hid_y, B, c.hid_y, dy, GEMM_RELU, nullptr, st)) return -1;
+    if (gemm(w.hidy, c.hid_y, P_(h, "mlp_out_y.3.weight", (int64_t)c.out_y * c.hid_y), P_(h, "mlp_out_y.3.bias", c.out_y),
+             w.yt1, c.out_y, B, c.out_y, c.hid_y, 0, nullptr, st)) return -1;
+    launch_x_out_residual(w.yt1, y, c.in_y, nullptr, o3, B, c.out_y, st);
+  }
+  return check_launch("forward");
+}
+
+}  // namespace
+
+// ====================================================================================================== C ABI
+extern "C" {
+
+int scgg_version(void) { return 1; }
+const char* scgg_last_error(void) { return last_error(); }
+
+scgg_denoiser* scgg_denoiser_create(const scgg_denoiser_config* cfg) {
+  if (!cfg) { fail("null config"); return nullptr; }
+  const scgg_denoiser_config& c = *cfg;
+  if (c.n_layers < 1 || c.dx % 32 || c.de % 32 || c.dim_ffE % 32 || c.hid_E % 32 || c.n_head < 1 || c.dx % c.n_head ||
+      c.out_E < 1 || c.out_E > 32 || c.in_E < c.out_E || c.in_E > 64 || c.in_X < c.out_X || c.in_y < c.out_y) {
+    fail("unsupported denoiser dims (need dx,de,dim_ffE,hid_E multiples of 32, out_E<=32, in_E<=64, in>=out)");
+    return nullptr;
+  }
+  scgg_denoiser* h = new scgg_denoiser();
+  h->c = c;
+  return h;
+}
+
+void scgg_denoiser_destroy(scgg_denoiser* h) {
+  if (!h) return;
+  if (h->arena) (void)hipFree(h->arena);
+  delete h;
+}
+
+int scgg_denoiser_set_param(scgg_denoiser* h, const char* name, const float* data, int64_t numel) {
+  if (!h || !name || !data) return fail("set_param: null argument");
+  h->params[name] = Param{data, numel};
+  return 0;
+}
+
+int scgg_denoiser_finalize(scgg_denoiser* h, void* stream) {
+  if (!h) return fail("null handle");
+  if (build(h, false, nullptr)) return -1;   // measure
+  if (h->arena) (void)hipFree(h->arena);
+  h->arena = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&h->arena), h->arena_bytes) != hipSuccess)
+    return fail("hipMalloc of %zu bytes for the packed weights failed", h->arena_bytes);
+  if (build(h, true, static_cast<hipStream_t>(stream))) return -1;
+  h->finalized = true;
+  return 0;
+}
+
+int scgg_denoiser_refresh(scgg_denoiser* h, void* stream) {
+  if (!h || !h->finalized) return fail("denoiser not finalized");
+  return build(h, true, static_cast<hipStream_t>(stream));
+}
+
+size_t scgg_denoiser_workspace_bytes(const scgg_denoiser* h, int32_t B, int32_t n) {
+  if (!h || B <= 0 || n <= 0) return 0;
+  return carve(h->c, B, n, nullptr).bytes;
+}
+
+int scgg_denoiser_forward(scgg_denoiser* h, const float* X, const float* E, const float* y, const uint8_t* node_mask,
+                          int32_t B, int32_t n, float* out_X, float* out_E, float* out_y, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  if (!X || !E || !y || !node_mask || !out_E) return fail("forward: null tensor");
+  if (h && h->c.out_X > 0 && !out_X) return fail("forward: out_X is NULL");
+  return run_forward(h, X, E, y, node_mask, B, n, h ? h->c.n_layers : 0, false, out_X, out_E, out_y, workspace,
+                     workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int scgg_denoiser_forward_hidden(scgg_denoiser* h, const float* X, const float* E, const float* y,
+                                 const uint8_t* node_mask, int32_t B, int32_t n, int32_t n_run_layers, float* hid_X,
+                                 float* hid_E, float* hid_y, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!X || !E || !y || !node_mask) return fail("forward_hidden: null tensor");
+  if (!h || n_run_layers < 0 || n_run_layers > h->c.n_layers) return fail("forward_hidden: bad layer count");
+  return run_forward(h, X, E, y, node_mask, B, n, n_run_layers, true, hid_X, hid_E, hid_y, workspace, workspace_bytes,
+                     static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------------------- reverse step
+static SampleRng to_rng(const scgg_rng* r) {
+  SampleRng g{nullptr, nullptr, 0, 0, 0};
+  if (r) { g.u0 = r->u0; g.uk = r->uk; g.seed = r->seed; g.step = r->step; g.graph_id_base = r->graph_id_base; }
+  return g;
+}
+
+int scgg_reverse_step_edges(const float* logits_E, const int8_t* labels_t, const uint8_t* node_mask,
+                            const int32_t* t_int, const int32_t* s_int, const float* beta_tab, const float* abar_tab,
+                            const float* marginals, int32_t B, int32_t n, int32_t C, int32_t top_k,
+                            const scgg_rng* rng, int8_t* labels_s, int8_t* cands_s, float* prob_out, void* stream) {
+  if (!logits_E || !labels_t || !node_mask || !t_int || !s_int || !beta_tab || !abar_tab || !marginals || !labels_s)
+    return fail("reverse_step: null argument");
+  if (B <= 0 || n <= 0 || n > 65535 || C < 1 || C > 32 || top_k < 0 || top_k > 8 || top_k > C)
+    return fail("reverse_step: unsupported shape B=%d n=%d C=%d top_k=%d", B, n, C, top_k);
+  if (top_k > 0 && !cands_s) return fail("reverse_step: top_k > 0 needs a candidate buffer");
+  if (rng && rng->u0 && top_k > 0 && !rng->uk) return fail("reverse_step: u0 given without uk");
+  ReverseStepArgs a{logits_E, labels_t, node_mask, t_int, s_int, beta_tab, abar_tab, marginals, prob_out, to_rng(rng),
+                    SampleOut{labels_s, cands_s}, B, n, C, top_k};
+  if (launch_reverse_step(a, static_cast<hipStream_t>(stream))) return fail("reverse_step: launch rejected");
+  return check_launch("reverse_step");
+}
+
+int scgg_sample_edges_from_probs(const float* prob_E, const uint8_t* node_mask, int32_t B, int32_t n, int32_t C,
+                                 int32_t top_k, const scgg_rng* rng, int8_t* labels, int8_t* cands, void* stream) {
+  if (!prob_E || !node_mask || !labels) return fail("sample_edges: null argument");
+  if (B <= 0 || n <= 0 || n > 65535 || C < 1 || C > 32 || top_k < 0 || top_k > 8 || top_k > C)
+    return fail("sample_edges: unsupported shape B=%d n=%d C=%d top_k=%d", B, n, C, top_k);
+  if (top_k > 0 && !cands) return fail("sample_edges: top_k > 0 needs a candidate buffer");
+  if (rng && rng->u0 && top_k > 0 && !rng->uk) return fail("sample_edges: u0 given without uk");
+  SampleProbsArgs a{prob_E, node_mask, to_rng(rng), SampleOut{labels, cands}, B, n, C, top_k};
+  if (launch_sample_from_probs(a, static_cast<hipStream_t>(stream))) return fail("sample_edges: launch rejected");
+  return check_launch("sample_edges");
+}
+
+int scgg_labels_to_onehot(const int8_t* labels, const int8_t* cands, int64_t n_pairs, int32_t C, int32_t top_k,
+                          float* E_onehot, int64_t* extra_info, void* stream) {
+  if (!labels || !E_onehot || n_pairs <= 0) return fail("labels_to_onehot: bad argument");
+  if (extra_info && !cands) return fail("labels_to_onehot: extra_info needs cands");
+  launch_labels_to_onehot(labels, cands, n_pairs, C, top_k, E_onehot, reinterpret_cast<long long*>(extra_info),
+                          static_cast<hipStream_t>(stream));
+  return check_launch("labels_to_onehot");
+}
+
+int scgg_onehot_to_labels(const float* E_onehot, int64_t n_pairs, int32_t C, int8_t* labels, void* stream) {
+  if (!labels || !E_onehot || n_pairs <= 0) return fail("onehot_to_labels: bad argument");
+  launch_onehot_to_labels(E_onehot, n_pairs, C, labels, static_cast<hipStream_t>(stream));
+  return check_launch("onehot_to_labels");
+}
+
+}  // extern "C"

@@ -1,0 +1,378 @@
+// Edge-path kernels of the GraphTransformer denoiser for gfx950 (MI355X), fp32 on v_mfma_f32_32x32x2_f32.
+//
+//   edge_mlp_in_kernel   mlp_in_E                        transformer_model.py:290-297, :358
+//   edge_layer_kernel    NodeEdgeBlock (E part + attention) + XEyTransformerLayer E path
+//                                                        transformer_model.py:165-227, :94-99
+//   edge_mlp_out_kernel  mlp_out_E + residual + diagonal mask + symmetrise + mask
+//                                                        transformer_model.py:372-376, :387-389
+//   edge_stats_kernel    Etoy pooling (mean|min|max|var) layers.py:34-41
+//
+// One wave owns one query row (b, i) and walks its keys j in chunks of 32 (pair on the lane, channel in the
+// register: see mfma_chain.h).  Everything between the load of E[b,i,j,:] and the store of the layer's output
+// for that pair happens in registers; the only cross-lane work is the per-channel softmax over j and the
+// two LayerNorm reductions.
+#include "mfma_chain.h"
+#include "kernels.h"
+
+namespace scgg {
+
+// =====================================================================================================
+// mlp_in_E : relu(W2 relu(W1 e + b1) + b2), written unsymmetrised for valid off-diagonal pairs, 0 elsewhere.
+// =====================================================================================================
+template <int KIB, int HB, int NEB>   // input blocks (ceil(dE_in/32)), hidden blocks, output blocks
+__global__ __launch_bounds__(256, 2) void edge_mlp_in_kernel(EdgeMlpInArgs a) {
+  const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.B * a.n) return;
+  const int b = row / a.n, i = row - b * a.n;
+  const bool vi = a.mask[row] != 0;
+  const int nchunks = (a.n + 31) >> 5;
+  for (int jc = 0; jc < nchunks; ++jc) {
+    const int j = jc * 32 + p;
+    const bool inb = j < a.n;
+    const bool live = vi && inb && a.mask[b * a.n + (inb ? j : 0)] != 0 && j != i;
+    const long long pair = (long long)row * a.n + (inb ? j : 0);
+    f32x16 out[NEB];
+    if (vi) {   // wave-uniform
+      f32x16 x[KIB];
+      const float* src = a.E_in + pair * a.dE_in;
+#pragma unroll
+      for (int kb = 0; kb < KIB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = 32 * kb + ch_of(r, h);
+          x[kb][r] = (live && c < a.dE_in) ? src[c] : 0.f;
+        }
+      f32x16 hid[HB];
+#pragma unroll
+      for (int rb = 0; rb < HB; ++rb) {
+        hid[rb] = load_vec_block(a.b1 + 32 * rb, h);
+        linear_rb<KIB>(hid[rb], a.W1, rb, x, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hid[rb][r] = fmaxf(hid[rb][r], 0.f);
+      }
+#pragma unroll
+      for (int rb = 0; rb < NEB; ++rb) {
+        out[rb] = load_vec_block(a.b2 + 32 * rb, h);
+        linear_rb<HB>(out[rb], a.W2, rb, hid, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[rb][r] = live ? fmaxf(out[rb][r], 0.f) : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int rb = 0; rb < NEB; ++rb) out[rb] = splat16(0.f);
+    }
+    if (inb) {
+      float* dst = a.E_out + pair * (32 * NEB);
+#pragma unroll
+      for (int rb = 0; rb < NEB; ++rb) store_vec_block(dst + 32 * rb, h, out[rb]);
+    }
+  }
+}
+
+// =====================================================================================================
+// fused XEy layer, edge part
+// =====================================================================================================
+template <int NXB, int NEB, int NFB>   // dx/32, de/32, ffE/32
+__global__ __launch_bounds__(256, 2) void edge_layer_kernel(EdgeLayerArgs a) {
+  constexpr int DX = 32 * NXB, DE = 32 * NEB;
+  __shared__ float run[4][3][DX];   // per-wave running (max, sum, weighted sum) for rows with > 32 keys
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.B * a.n) return;
+  const int b = row / a.n, i = row - b * a.n;
+  if (a.mask[row] == 0) return;      // padded query row: nothing downstream ever reads it (consumers select by mask)
+  const int n = a.n;
+  const int nchunks = (n + 31) >> 5;
+  const float* Qi = a.Q + (long long)row * a.ldqkv;
+  const float* film = a.film + (long long)b * (4 * DX);   // [ye_add | ye_mul+1 | yx_add | yx_mul+1]
+  float* mrun = run[wave][0];
+  float* srun = run[wave][1];
+  float* arun = run[wave][2];
+
+  for (int jc = 0; jc < nchunks; ++jc) {
+    const int j = jc * 32 + p;
+    const bool inb = j < n;
+    const int jj = inb ? j : 0;
+    const bool vj = inb && a.mask[b * n + jj] != 0;
+    const bool live = vj && j != i;
+    const long long off_ij = ((long long)row * n + jj) * DE;
+    const long long off_ji = (((long long)b * n + jj) * n + i) * DE;
+    const float* Kj = a.K + ((long long)b * n + jj) * a.ldqkv;
+    const float* Vj = a.V + ((long long)b * n + jj) * a.ldqkv;
+
+    f32x16 e[NEB];
+    load_sym_tile<NEB>(e, a.E_in, off_ij, off_ji, live, h);
+
+    f32x16 accO[NEB];
+#pragma unroll
+    for (int rb = 0; rb < NEB; ++rb) accO[rb] = load_vec_block(a.b_out + 32 * rb, h);
+
+#pragma unroll 1
+    for (int cb = 0; cb < NXB; ++cb) {
+      f32x16 a1 = load_vec_block(a.b_mul1 + 32 * cb, h);   // bias + 1
+      f32x16 a2 = load_vec_block(a.b_add + 32 * cb, h);
+      linear_rb<NEB>(a1, a.W_mul, cb, e, lane);
+      linear_rb<NEB>(a2, a.W_add, cb, e, lane);
+      const f32x16 q = load_vec_block(Qi + 32 * cb, h);
+      f32x16 k = load_vec_block(Kj + 32 * cb, h);
+      f32x16 v = load_vec_block(Vj + 32 * cb, h);
+      const f32x16 yea = load_vec_block(film + 32 * cb, h);
+      const f32x16 yem = load_vec_block(film + DX + 32 * cb, h);
+      f32x16 z;
+      float wv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float kk = vj ? k[r] : 0.f;
+        const float y = (q[r] * kk) * a.inv_sqrt_df * a1[r] + a2[r];      // Y = QK/sqrt(df) * (E1+1) + E2
+        z[r] = yea[r] + yem[r] * y;                                      // FiLM by y before e_out
+        // per-channel softmax over the keys of this chunk
+        const float ym = vj ? y : -INFINITY;
+        const float mx = half_max(ym);
+        const float pexp = vj ? __expf(y - mx) : 0.f;
+        const float s = half_sum(pexp);
+        const float av = half_sum(pexp * (vj ? v[r] : 0.f));
+        if (nchunks == 1) {
+          wv[r] = av / s;
+        } else {
+          const int c = 32 * cb + ch_of(r, h);
+          if (p == 0) {
+            if (jc == 0) {
+              mrun[c] = mx; srun[c] = s; arun[c] = av;
+            } else {
+              const float mo = mrun[c], mn = fmaxf(mo, mx);
+              const float fo = mo == -INFINITY ? 0.f : __expf(mo - mn);
+              const float fn = mx == -INFINITY ? 0.f : __expf(mx - mn);
+              mrun[c] = mn;
+              srun[c] = srun[c] * fo + s * fn;
+              arun[c] = arun[c] * fo + av * fn;
+            }
+          }
+          wv[r] = 0.f;
+        }
+      }
+      if (nchunks == 1 && p == 0) {
+        // newX_pre = yx_add + (yx_mul + 1) * weighted_V   (transformer_model.py:230-232)
+        const f32x16 yxa = load_vec_block(film + 2 * DX + 32 * cb, h);
+        const f32x16 yxm = load_vec_block(film + 3 * DX + 32 * cb, h);
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = yxa[r] + yxm[r] * wv[r];
+        store_vec_block(a.newX_pre + (long long)row * DX + 32 * cb, h, o);
+      }
+      // newE += W_out[:, block cb] . z
+#pragma unroll
+      for (int rb = 0; rb < NEB; ++rb) mfma_block<NXB>(accO[rb], a.W_out, rb, cb, z, lane);
+    }
+
+    // E <- LN1(E + newE)   (newE is masked by m_i m_j: identical for live pairs; dead pairs are zeroed at the store)
+#pragma unroll
+    for (int rb = 0; rb < NEB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) e[rb][r] += accO[rb][r];
+    layernorm_c<NEB>(e, a.ln1_g, a.ln1_b, h);
+    // FFN
+    f32x16 hid[NFB];
+#pragma unroll
+    for (int rb = 0; rb < NFB; ++rb) {
+      hid[rb] = load_vec_block(a.b_ff1 + 32 * rb, h);
+      linear_rb<NEB>(hid[rb], a.W_ff1, rb, e, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hid[rb][r] = fmaxf(hid[rb][r], 0.f);
+    }
+#pragma unroll
+    for (int rb = 0; rb < NEB; ++rb) {
+      f32x16 f = load_vec_block(a.b_ff2 + 32 * rb, h);
+      linear_rb<NFB>(f, a.W_ff2, rb, hid, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) e[rb][r] += f[r];
+    }
+    layernorm_c<NEB>(e, a.ln2_g, a.ln2_b, h);
+    if (inb) {
+      float* dst = a.E_out + off_ij;
+#pragma unroll
+      for (int rb = 0; rb < NEB; ++rb) {
+        if (!live) e[rb] = splat16(0.f);
+        store_vec_block(dst + 32 * rb, h, e[rb]);
+      }
+    }
+  }
+
+  if (nchunks > 1) {
+    // finish the multi-chunk rows: every lane of the wave takes channels lane, lane+64, ...
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane; c < DX; c += 64) {
+      const float wv = arun[c] / srun[c];
+      a.newX_pre[(long long)row * DX + c] = film[2 * DX + c] + film[3 * DX + c] * wv;
+    }
+  }
+}
+
+// =====================================================================================================
+// mlp_out_E + residual + diag mask + symmetrise + mask  ->  logits[B,n,n,C]
+// =====================================================================================================
+template <int NEB, int HB>
+__global__ __launch_bounds__(256, 2) void edge_mlp_out_kernel(EdgeMlpOutArgs a) {
+  constexpr int DE = 32 * NEB;
+  const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.B * a.n) return;
+  const int n = a.n;
+  const int b = row / n, i = row - b * n;
+  const bool vi = a.mask[row] != 0;
+  const int nchunks = (n + 31) >> 5;
+  for (int jc = 0; jc < nchunks; ++jc) {
+    const int j = jc * 32 + p;
+    const bool inb = j < n;
+    const int jj = inb ? j : 0;
+    const bool live = vi && inb && a.mask[b * n + jj] != 0 && j != i;
+    const long long pij = (long long)row * n + jj;
+    const long long pji = ((long long)b * n + jj) * n + i;
+    f32x16 o = splat16(0.f);
+    if (vi) {   // wave-uniform
+      f32x16 e[NEB];
+      load_sym_tile<NEB>(e, a.E_hid, pij * DE, pji * DE, live, h);
+      f32x16 hid[HB];
+#pragma unroll
+      for (int rb = 0; rb < HB; ++rb) {
+        hid[rb] = load_vec_block(a.b1 + 32 * rb, h);
+        linear_rb<NEB>(hid[rb], a.W1, rb, e, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hid[rb][r] = fmaxf(hid[rb][r], 0.f);
+      }
+      o = load_vec_block(a.b2, h);
+      linear_rb<HB>(o, a.W2, 0, hid, lane);
+      // (mlp + E_in[ij]) and (mlp + E_in[ji]) averaged: the hidden E is symmetric after the sym-load, so the
+      // MLP term is bit-identical for (i,j) and (j,i); only the residual needs both orientations.
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = ch_of(r, h);
+        float val = 0.f;
+        if (live && c < a.C) {
+          const float rij = a.E_in[pij * a.dE_in + c];
+          const float rji = a.E_in[pji * a.dE_in + c];
+          val = 0.5f * ((o[r] + rij) + (o[r] + rji));
+        }
+        o[r] = val;
+      }
+    }
+    if (inb) {
+      float* dst = a.logits + pij * a.C;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = ch_of(r, h);
+        if (c < a.C) dst[c] = o[r];
+      }
+    }
+  }
+}
+
+// =====================================================================================================
+// Etoy pooling over the symmetrised, masked hidden E (diagonal included as zeros): z[b] = [mean|min|max|var]
+// one workgroup (256 threads) per graph; thread = (channel c = tid % DE, slice s = tid / DE)
+// =====================================================================================================
+__global__ __launch_bounds__(256) void edge_stats_kernel(EdgeStatsArgs a) {
+  __shared__ float red[3][256];
+  __shared__ float s_mean[256];
+  const int b = blockIdx.x, n = a.n, DE = a.de;
+  const int tid = threadIdx.x;
+  const int c = tid % DE, s = tid / DE, S = 256 / DE;
+  const uint8_t* m = a.mask + b * n;
+  int nv = 0;
+  for (int t = 0; t < n; ++t) nv += m[t] != 0;
+  const float* E = a.E + (long long)b * n * n * DE;
+  float sum = 0.f, mn = INFINITY, mx = -INFINITY;
+  for (int pr = s; pr < n * n; pr += S) {
+    const int i = pr / n, j = pr - i * n;
+    if (!m[i] || !m[j]) continue;
+    float v = 0.f;
+    if (i != j) v = 0.5f * (E[(long long)pr * DE + c] + E[((long long)j * n + i) * DE + c]);
+    sum += v;
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+  }
+  red[0][tid] = sum; red[1][tid] = mn; red[2][tid] = mx;
+  __syncthreads();
+  const float cnt = (float)nv * (float)nv;
+  if (s == 0) {
+    for (int t = 1; t < S; ++t) {
+      sum += red[0][t * DE + c];
+      mn = fminf(mn, red[1][t * DE + c]);
+      mx = fmaxf(mx, red[2][t * DE + c]);
+    }
+    const float mean = sum / cnt;
+    s_mean[c] = mean;
+    float* z = a.z + (long long)b * a.z_stride + a.z_offset;
+    z[c] = mean; z[DE + c] = mn; z[2 * DE + c] = mx;
+  }
+  __syncthreads();
+  const float mean = s_mean[c];
+  float q = 0.f;
+  for (int pr = s; pr < n * n; pr += S) {
+    const int i = pr / n, j = pr - i * n;
+    if (!m[i] || !m[j]) continue;
+    float v = 0.f;
+    if (i != j) v = 0.5f * (E[(long long)pr * DE + c] + E[((long long)j * n + i) * DE + c]);
+    const float d = v - mean;
+    q += d * d;
+  }
+  __syncthreads();
+  red[0][tid] = q;
+  __syncthreads();
+  if (s == 0) {
+    for (int t = 1; t < S; ++t) q += red[0][t * DE + c];
+    float* z = a.z + (long long)b * a.z_stride + a.z_offset;
+    z[3 * DE + c] = q / cnt;
+  }
+}
+
+// =====================================================================================================
+// launchers
+// =====================================================================================================
+static inline int row_blocks(int B, int n) { return (B * n + 3) / 4; }
+
+int launch_edge_mlp_in(const EdgeMlpInArgs& a, int dE_in, int hid, int de, hipStream_t st) {
+  const int kib = (dE_in + 31) / 32;
+  dim3 g(row_blocks(a.B, a.n)), blk(256);
+#define CASE(KIB, HB, NEB)                                                       \
+  if (kib == KIB && hid == 32 * HB && de == 32 * NEB) {                          \
+    hipLaunchKernelGGL((edge_mlp_in_kernel<KIB, HB, NEB>), g, blk, 0, st, a);    \
+    return 0;                                                                    \
+  }
+  CASE(1, 4, 2) CASE(2, 4, 2) CASE(1, 1, 1)
+#undef CASE
+  return -1;
+}
+
+int launch_edge_layer(const EdgeLayerArgs& a, int dx, int de, int ffe, hipStream_t st) {
+  dim3 g(row_blocks(a.B, a.n)), blk(256);
+#define CASE(NXB, NEB, NFB)                                                      \
+  if (dx == 32 * NXB && de == 32 * NEB && ffe == 32 * NFB) {                     \
+    hipLaunchKernelGGL((edge_layer_kernel<NXB, NEB, NFB>), g, blk, 0, st, a);    \
+    return 0;                                                                    \
+  }
+  CASE(8, 2, 4) CASE(4, 2, 4) CASE(1, 1, 2)
+#undef CASE
+  return -1;
+}
+
+int launch_edge_mlp_out(const EdgeMlpOutArgs& a, int de, int hid, hipStream_t st) {
+  dim3 g(row_blocks(a.B, a.n)), blk(256);
+#define CASE(NEB, HB)                                                            \
+  if (de == 32 * NEB && hid == 32 * HB) {                                        \
+    hipLaunchKernelGGL((edge_mlp_out_kernel<NEB, HB>), g, blk, 0, st, a);        \
+    return 0;                                                                    \
+  }
+  CASE(2, 4) CASE(1, 1)
+#undef CASE
+  return -1;
+}
+
+int launch_edge_stats(const EdgeStatsArgs& a, hipStream_t st) {
+  if (a.de > 256 || 256 % a.de != 0) return -1;
+  hipLaunchKernelGGL(edge_stats_kernel, dim3(a.B), dim3(256), 0, st, a);
+  return 0;
+}
+
+}  // namespace scgg

@@ -1,0 +1,122 @@
+// Internal kernel argument blocks and launcher prototypes (not part of the C ABI; see include/scgg.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace scgg {
+
+int fail(const char* fmt, ...);      // records the thread's last error, returns -1
+const char* last_error();
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+struct EdgeMlpInArgs {
+  const float* E_in;      // [B,n,n,dE_in]
+  const uint8_t* mask;    // [B,n]
+  const f32x4_t* W1;      // packed [hid x dE_in]
+  const float* b1;        // padded
+  const f32x4_t* W2;      // packed [de x hid]
+  const float* b2;
+  float* E_out;           // [B,n,n,de]  unsymmetrised, zero on dead pairs
+  int B, n, dE_in;
+};
+
+struct EdgeLayerArgs {
+  const float* E_in;      // [B,n,n,de]  (unsymmetrised producer output)
+  float* E_out;           // [B,n,n,de]
+  const uint8_t* mask;    // [B,n]
+  const float* Q;         // [B,n,dx] masked
+  const float* K;
+  const float* V;
+  int ldqkv;              // row stride of Q/K/V (they are column slices of one [B*n, 3*dx] buffer)
+  const float* film;      // [B,4*dx] = [y_e_add | y_e_mul+1 | y_x_add | y_x_mul+1]
+  float* newX_pre;        // [B,n,dx] = y_x_add + (y_x_mul+1)*weighted_V   (valid rows only)
+  const f32x4_t* W_mul;   // packed [dx x de]
+  const f32x4_t* W_add;
+  const f32x4_t* W_out;   // packed [de x dx]
+  const f32x4_t* W_ff1;   // packed [ffE x de]
+  const f32x4_t* W_ff2;   // packed [de x ffE]
+  const float* b_mul1;    // e_mul.bias + 1
+  const float* b_add;
+  const float* b_out;
+  const float* b_ff1;
+  const float* b_ff2;
+  const float* ln1_g;
+  const float* ln1_b;
+  const float* ln2_g;
+  const float* ln2_b;
+  float inv_sqrt_df;
+  int B, n;
+};
+
+struct EdgeMlpOutArgs {
+  const float* E_hid;     // [B,n,n,de]
+  const float* E_in;      // [B,n,n,dE_in] original model input (residual uses channels [0,C))
+  const uint8_t* mask;
+  const f32x4_t* W1;      // packed [hid x de]
+  const float* b1;
+  const f32x4_t* W2;      // packed [C x hid] (one row block)
+  const float* b2;
+  float* logits;          // [B,n,n,C]
+  int B, n, dE_in, C;
+};
+
+struct EdgeStatsArgs {
+  const float* E;         // [B,n,n,de] unsymmetrised
+  const uint8_t* mask;
+  float* z;               // row b at z + b*z_stride + z_offset : [mean|min|max|var] (4*de floats)
+  int B, n, de, z_stride, z_offset;
+};
+
+int launch_edge_mlp_in(const EdgeMlpInArgs& a, int dE_in, int hid, int de, hipStream_t st);
+int launch_edge_layer(const EdgeLayerArgs& a, int dx, int de, int ffe, hipStream_t st);
+int launch_edge_mlp_out(const EdgeMlpOutArgs& a, int de, int hid, hipStream_t st);
+int launch_edge_stats(const EdgeStatsArgs& a, hipStream_t st);
+
+// ---- node / global path -------------------------------------------------------------------------
+enum GemmFlags : int { GEMM_RELU = 1, GEMM_ROWMASK = 2, GEMM_ADD_ONE_COLS = 4 };
+
+struct GemmArgs {
+  const float* A;         // [M,K] row-major, lda
+  const float* W;         // [N,K] torch Linear layout, ldw
+  const float* bias;      // [N] or null
+  float* C;               // [M,N], ldc
+  const uint8_t* rowmask; // [M] (GEMM_ROWMASK: zero masked rows)
+  int M, N, K, lda, ldw, ldc;
+  int flags;
+  int one_lo, one_hi;     // GEMM_ADD_ONE_COLS: columns in [one_lo,one_hi) and [one_lo2,one_hi2) get +1
+  int one_lo2, one_hi2;
+};
+int launch_gemm(const GemmArgs& a, hipStream_t st);
+
+struct AddLnArgs {        // out = LN(x + r) * rowmask
+  const float* x;
+  const float* r;
+  const float* gamma;
+  const float* beta;
+  const uint8_t* rowmask; // or null
+  float* out;
+  int M, D;
+};
+int launch_add_layernorm(const AddLnArgs& a, hipStream_t st);
+
+struct NodeStatsArgs {    // Xtoy pooling: z[b] = [mean|min|max|var] over valid nodes
+  const float* X;         // [B,n,dx]
+  const uint8_t* mask;
+  float* z;
+  int B, n, dx, z_stride, z_offset;
+};
+int launch_node_stats(const NodeStatsArgs& a, hipStream_t st);
+
+struct PackArgs {
+  const float* W;         // [N,K]
+  f32x4_t* Wp;
+  int N, K, NB, KB;
+};
+int launch_pack_linear(const PackArgs& a, hipStream_t st);
+int launch_pad_vec(const float* src, float* dst, int n, int n_pad, float add, hipStream_t st);
+int launch_copy_cols(const float* src, int lds, float* dst, int ldd, int M, int ncols, hipStream_t st);
+int launch_x_out_residual(const float* mlp, const float* X_in, int dX_in, const uint8_t* mask, float* out,
+                          int M, int nout, hipStream_t st);
+
+}  // namespace scgg

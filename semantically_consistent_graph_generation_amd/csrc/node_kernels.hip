@@ -1,0 +1,245 @@
+// Node / global-feature path kernels (gfx950): dense fp32 GEMM on v_mfma_f32_32x32x2_f32 with a fused
+// bias / ReLU / row-mask epilogue, residual + LayerNorm, Xtoy pooling, and the weight packers.
+//
+// These serve q/k/v, x_out, linX1/2, the y-FiLM vectors, the whole y path and the X in/out MLPs
+// (transformer_model.py:179-180,218,230-246,88-92,101-106,281-305,322-342); they are O(B*n*d^2) and small next
+// to the edge path, but still dense contractions, so they run on the matrix cores in exact fp32.
+#include "mfma_chain.h"
+#include "kernels.h"
+
+namespace scgg {
+
+// ------------------------------------------------------------------------------------------------
+// C[M,N] = epi(A[M,K] . W[N,K]^T + bias).  Block = 4 waves (2x2), wave tile 64(m) x 64(n), no LDS: operands are
+// L2-resident and each float4 load feeds 4 MFMAs (k-steps kc+4h .. kc+4h+3 for lane half h).
+// ------------------------------------------------------------------------------------------------
+template <bool FAST>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+  const int m_base = blockIdx.x * 128 + (wave >> 1) * 64;
+  const int n_base = blockIdx.y * 128 + (wave & 1) * 64;
+  if (m_base >= a.M || n_base >= a.N) return;
+  f32x16 acc[2][2];   // [nt][mt]
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = splat16(0.f);
+
+  int mrow[2], nrow[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    mrow[t] = min(m_base + 32 * t + p, a.M - 1);
+    nrow[t] = min(n_base + 32 * t + p, a.N - 1);
+  }
+  const bool n1 = n_base + 32 < a.N, m1 = m_base + 32 < a.M;   // wave-uniform: second tile present?
+
+  for (int kc = 0; kc < a.K; kc += 8) {
+    f32x4 av[2], wv[2];
+    const int k0 = kc + 4 * h;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (FAST) {
+        av[t] = *reinterpret_cast<const f32x4*>(a.A + (long long)mrow[t] * a.lda + k0);
+        wv[t] = *reinterpret_cast<const f32x4*>(a.W + (long long)nrow[t] * a.ldw + k0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = k0 + e < a.K;
+          av[t][e] = ok ? a.A[(long long)mrow[t] * a.lda + k0 + e] : 0.f;
+          wv[t][e] = ok ? a.W[(long long)nrow[t] * a.ldw + k0 + e] : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[0][e], av[0][e], acc[0][0], 0, 0, 0);
+      if (m1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[0][e], av[1][e], acc[0][1], 0, 0, 0);
+      if (n1) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[1][e], av[0][e], acc[1][0], 0, 0, 0);
+      if (n1 && m1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[1][e], av[1][e], acc[1][1], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int m = m_base + 32 * mt + p;
+    if (m >= a.M) continue;
+    const bool keep = !(a.flags & GEMM_ROWMASK) || a.rowmask[m] != 0;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int nn = n_base + 32 * nt + ch_of(r, h);
+        if (nn >= a.N) continue;
+        float v = acc[nt][mt][r];
+        if (a.bias) v += a.bias[nn];
+        if (a.flags & GEMM_RELU) v = fmaxf(v, 0.f);
+        if (a.flags & GEMM_ADD_ONE_COLS)
+          if ((nn >= a.one_lo && nn < a.one_hi) || (nn >= a.one_lo2 && nn < a.one_hi2)) v += 1.0f;
+        a.C[(long long)m * a.ldc + nn] = keep ? v : 0.f;
+      }
+    }
+  }
+}
+
+int launch_gemm(const GemmArgs& a, hipStream_t st) {
+  if (a.M <= 0 || a.N <= 0) return 0;
+  dim3 g((a.M + 127) / 128, (a.N + 127) / 128), b(256);
+  const bool fast = (a.K % 8 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.W)) % 16 == 0);
+  if (fast) hipLaunchKernelGGL(gemm_kernel<true>, g, b, 0, st, a);
+  else hipLaunchKernelGGL(gemm_kernel<false>, g, b, 0, st, a);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// out = LayerNorm(x + r) (eps 1e-5), optionally zeroing masked rows.  One wave per row, D <= 1024.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void add_layernorm_kernel(AddLnArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= a.M) return;
+  const int D = a.D;
+  float v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int c = lane + 64 * t;
+    v[t] = 0.f;
+    if (c < D) {
+      v[t] = a.x[(long long)row * D + c] + a.r[(long long)row * D + c];
+      s += v[t];
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m);
+  const float mean = s / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int c = lane + 64 * t;
+    if (c < D) {
+      const float d = v[t] - mean;
+      q += d * d;
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) q += __shfl_xor(q, m);
+  const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
+  const bool keep = a.rowmask == nullptr || a.rowmask[row] != 0;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int c = lane + 64 * t;
+    if (c < D) a.out[(long long)row * D + c] = keep ? (v[t] - mean) * rstd * a.gamma[c] + a.beta[c] : 0.f;
+  }
+}
+
+int launch_add_layernorm(const AddLnArgs& a, hipStream_t st) {
+  if (a.D > 1024) return -1;
+  hipLaunchKernelGGL(add_layernorm_kernel, dim3((a.M + 3) / 4), dim3(256), 0, st, a);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Xtoy pooling (layers.py:11-19): [mean|min|max|biased variance] over the valid nodes of each graph
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void node_stats_kernel(NodeStatsArgs a) {
+  const int b = blockIdx.x;
+  const uint8_t* m = a.mask + b * a.n;
+  for (int c = threadIdx.x; c < a.dx; c += 256) {
+    const float* X = a.X + (long long)b * a.n * a.dx + c;
+    float s = 0.f, mn = INFINITY, mx = -INFINITY;
+    int cnt = 0;
+    for (int i = 0; i < a.n; ++i) {
+      if (!m[i]) continue;
+      const float v = X[(long long)i * a.dx];
+      s += v; mn = fminf(mn, v); mx = fmaxf(mx, v); ++cnt;
+    }
+    const float mean = s / (float)cnt;
+    float q = 0.f;
+    for (int i = 0; i < a.n; ++i) {
+      if (!m[i]) continue;
+      const float d = X[(long long)i * a.dx] - mean;
+      q += d * d;
+    }
+    float* z = a.z + (long long)b * a.z_stride + a.z_offset;
+    z[c] = mean; z[a.dx + c] = mn; z[2 * a.dx + c] = mx; z[3 * a.dx + c] = q / (float)cnt;
+  }
+}
+
+int launch_node_stats(const NodeStatsArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(node_stats_kernel, dim3(a.B), dim3(256), 0, st, a);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// packers
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_linear_kernel(PackArgs a) {
+  const long long total = (long long)a.NB * a.KB * 4 * 64;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int lane = idx & 63;
+    const int g = (idx >> 6) & 3;
+    const long long rk = idx >> 8;
+    const int kb = rk % a.KB, rb = rk / a.KB;
+    const int nn = 32 * rb + (lane & 31);
+    f32x4_t v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = 32 * kb + 8 * g + 4 * (lane >> 5) + e;
+      v[e] = (nn < a.N && k < a.K) ? a.W[(long long)nn * a.K + k] : 0.f;
+    }
+    a.Wp[idx] = v;
+  }
+}
+
+int launch_pack_linear(const PackArgs& a, hipStream_t st) {
+  const long long total = (long long)a.NB * a.KB * 256;
+  hipLaunchKernelGGL(pack_linear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+  return 0;
+}
+
+__global__ void pad_vec_kernel(const float* src, float* dst, int n, int n_pad, float add) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pad) dst[i] = i < n ? src[i] + add : 0.f;
+}
+
+int launch_pad_vec(const float* src, float* dst, int n, int n_pad, float add, hipStream_t st) {
+  hipLaunchKernelGGL(pad_vec_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, st, src, dst, n, n_pad, add);
+  return 0;
+}
+
+__global__ void copy_cols_kernel(const float* src, int lds, float* dst, int ldd, int M, int ncols) {
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= (long long)M * ncols) return;
+  const int m = idx / ncols, c = idx - (long long)m * ncols;
+  dst[(long long)m * ldd + c] = src[(long long)m * lds + c];
+}
+
+int launch_copy_cols(const float* src, int lds, float* dst, int ldd, int M, int ncols, hipStream_t st) {
+  const long long total = (long long)M * ncols;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, lds, dst, ldd, M,
+                     ncols);
+  return 0;
+}
+
+// X_out = (mlp_out_X(X) + X_in[..., :nout]) * mask     (transformer_model.py:374, :387-389)
+__global__ void x_out_residual_kernel(const float* mlp, const float* X_in, int dX_in, const uint8_t* mask,
+                                      float* out, int M, int nout) {
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= (long long)M * nout) return;
+  const int m = idx / nout, c = idx - (long long)m * nout;
+  const bool keep = mask == nullptr || mask[m] != 0;
+  out[idx] = keep ? mlp[idx] + X_in[(long long)m * dX_in + c] : 0.f;
+}
+
+int launch_x_out_residual(const float* mlp, const float* X_in, int dX_in, const uint8_t* mask, float* out, int M,
+                          int nout, hipStream_t st) {
+  const long long total = (long long)M * nout;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(x_out_residual_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, mlp, X_in, dX_in,
+                     mask, out, M, nout);
+  return 0;
+}
+
+}  // namespace scgg
