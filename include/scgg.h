@@ -113,16 +113,22 @@ int scgg_labels_to_onehot(const int8_t* labels, const int8_t* cands, int64_t n_p
 int scgg_onehot_to_labels(const float* E_onehot, int64_t n_pairs, int32_t C, int8_t* labels, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Extra features: ExtraFeatures.__call__ without the eigen part (src/ConStruct/diffusion/extra_features.py:60-77,
- * AdjacencyFeatures :198-385).  Called at diffusion_model_discrete_3d.py:186.
- *   labels int8 [B,n,n] (adjacency = label > 0), node_mask.
- *   x_out[B,n,3]  y_out[B, 4 + (num_degree+2) + 1 + C]  (cycles | degree hist | node hist (1 class) | edge hist)
- *   e_out[B,n,n,max_degree+1]  (reachability A^1..A^max_degree | Adamic-Adar)
- *   lap_out[B,n,n] (optional): the padded Laplacian EigenFeatures hands to eigh (:88-94).
+ * Extra features: the AdjacencyFeatures part of ExtraFeatures.__call__
+ * (src/ConStruct/diffusion/extra_features.py:60-77, :198-385) plus the Laplacian that EigenFeatures hands to
+ * eigh (:88-94).  Called at diffusion_model_discrete_3d.py:186.  Works on the int8 edge state.
+ *   labels int8 [B,n,n] (adjacency = label > 0), node_labels int8 [B,n] or NULL (single node class), node_mask.
+ *   x_out[B,n,3]                                      3/4/5-cycle counts per node, clamp(.,0,5)/5, masked
+ *   y_out[B, 4 + (num_degree+2) + Cx + C]             cycles per graph | degree hist | node hist | edge hist
+ *   e_out: for pair p the max_degree+1 features (reachability A^1..A^max_degree, Adamic-Adar index) go to
+ *          e_out[p*e_ld + e_off ...]; with onehot_out != NULL the masked one-hot of the label goes to
+ *          onehot_out[p*e_ld + 0..C)  (so the denoiser's E input [one-hot | extra] is assembled in one pass)
+ *   lap_out[B,n,n] (optional)                         padded combinatorial Laplacian
+ * n <= 32 in this round.
  * ---------------------------------------------------------------------------------------------------------- */
-int scgg_adjacency_features(const int8_t* labels, const uint8_t* node_mask, int32_t B, int32_t n, int32_t C,
-                            int32_t num_degree, int32_t max_degree, int32_t cycle_features, float* x_out,
-                            float* y_out, float* e_out, float* lap_out, void* stream);
+int scgg_adjacency_features(const int8_t* labels, const int8_t* node_labels, const uint8_t* node_mask, int32_t B,
+                            int32_t n, int32_t C, int32_t Cx, int32_t num_degree, int32_t max_degree,
+                            int32_t cycle_features, float* x_out, float* y_out, float* e_out, int32_t e_ld,
+                            int32_t e_off, float* onehot_out, float* lap_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,139 @@
+"""The reverse-sampling driver of the hot path: ``forward`` (reference diffusion_model_discrete_3d.py:184-201),
+``sample_zs_from_zt`` (:745-751) and the T-step loop of ``sample_batch`` (:583-684), without the Lightning /
+visualisation glue around them.
+
+Two equivalent routes through the same kernels:
+  * PlaceHolder route (``forward`` / ``sample_zs_from_zt``): reference types in, reference types out (one-hot float E,
+    int64 extra_info) -- what an unmodified caller or a host-side projector sees;
+  * state route (``sample_batch`` with no projector): the graph state stays int8 on the device, the denoiser input
+    ``[one-hot | extra features]`` is assembled by the feature kernel straight into a persistent buffer, and no step
+    synchronises with the host (the reference forces ~30 syncs per step).
+Graph chains are independent: a multi-GPU run shards the list of graphs and passes ``graph_id_base`` so that every
+graph draws the same Philox stream whatever the sharding.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .extra_features import DummyExtraFeatures, ExtraFeatures
+from .noise_model import NoiseModel, Rng
+from .placeholder import PlaceHolder
+from .transformer_model import model_input
+
+
+class DiscreteSampler:
+    def __init__(self, model, noise_model: NoiseModel, extra_features=None, faster_sampling: int = 1):
+        self.model = model
+        self.noise_model = noise_model
+        self.extra_features = extra_features if extra_features is not None else DummyExtraFeatures()
+        self.T = noise_model.T
+        self.faster_sampling = faster_sampling
+
+    # ---------------------------------------------------------------------------------------- PlaceHolder route
+    def forward(self, z_t):
+        """reference :184-201: concatenate [z_t | extra features | t] and run the denoiser."""
+        extra = self.extra_features(z_t)
+        X = torch.cat((z_t.X, z_t.charges, extra.X), dim=2).float()
+        E = torch.cat((z_t.E, extra.E), dim=3).float()
+        y = torch.hstack((z_t.y, extra.y, z_t.t)).float()
+        return self.model(model_input(X, E, y, z_t.node_mask))
+
+    def sample_zs_from_zt(self, z_t, s_int, rng: Rng = None):
+        """reference :745-751."""
+        pred = self.forward(z_t)
+        return self.noise_model.sample_zs_from_zt_and_pred(z_t=z_t, pred=pred, s_int=s_int, rng=rng)
+
+    # --------------------------------------------------------------------------------------------- state route
+    def _alloc_state(self, node_mask):
+        B, n = node_mask.shape
+        dev = node_mask.device
+        nm, m = self.noise_model, self.model
+        C_e = nm.E_classes
+        top_k = nm.top_k or 0
+        st = {
+            "E_in": torch.zeros(B, n, n, m.in_dim_E, device=dev),
+            "X_in": torch.zeros(B, n, m.in_dim_X, device=dev),
+            "y_in": torch.zeros(B, m.in_dim_y, device=dev),
+            "labels": [torch.empty(B, n, n, dtype=torch.int8, device=dev) for _ in range(2)],
+            "cands": [torch.empty(B, n, n, max(top_k, 1), dtype=torch.int8, device=dev) for _ in range(2)],
+            "t_all": torch.arange(self.T + 1, dtype=torch.int32, device=dev)[:, None].expand(-1, B).contiguous(),
+        }
+        st["X_in"][..., 0] = node_mask.float()            # single node class: masked one-hot
+        return st
+
+    def _build_inputs(self, st, labels, node_mask, t):
+        """Assemble the denoiser input of step t from the int8 state (reference forward :190-199)."""
+        nm = self.noise_model
+        B, n = node_mask.shape
+        C_e = nm.E_classes
+        ef = self.extra_features
+        if isinstance(ef, ExtraFeatures):
+            x, y, _, lap = ef.adjacency_features(labels, node_mask, C_e, e_dst=st["E_in"], e_off=C_e, want_onehot=True)
+            evl, evc = ef.eigen_features(lap, node_mask)
+            st["X_in"][..., 1:4] = x
+            st["X_in"][..., 4:] = evc
+            yi = st["y_in"]
+            yi[:, 0:1] = node_mask.sum(dim=1, keepdim=True) / ef.max_n_nodes
+            k = y.shape[1]
+            yi[:, 1:1 + k] = y
+            yi[:, 1 + k:1 + k + evl.shape[1]] = evl
+            yi[:, -1] = t / self.T
+        else:
+            _lib.check(_lib.lib().scgg_labels_to_onehot(_lib.ptr(labels), None, B * n * n, C_e, 0, _lib.ptr(st["E_in"]), None,
+                                                        _lib.stream_ptr()), "labels_to_onehot")
+            st["y_in"][:, -1] = t / self.T
+        return model_input(st["X_in"], st["E_in"], st["y_in"], node_mask)
+
+    @torch.no_grad()
+    def sample_batch(self, n_nodes, seed: int = 0, graph_id_base: int = 0, projector=None, n_max=None,
+                     steps=None, return_state=False):
+        """reference sample_batch :583-684 (loop :653-663, collapse :684) for one batch of graphs.
+
+        n_nodes: list / tensor of node counts.  Returns the collapsed PlaceHolder (X, E integer labels, -1 padding,
+        pos) -- or the raw int8 state with ``return_state``.  ``steps`` limits the number of reverse steps (tests)."""
+        dev = next(self.model.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.ScggError("sampling runs on the MI355X only; move the model to the GPU")
+        n_nodes = torch.as_tensor(n_nodes, device=dev).long()
+        B = n_nodes.numel()
+        n = int(n_max) if n_max is not None else int(n_nodes.max())
+        node_mask = (torch.arange(n, device=dev)[None, :] < n_nodes[:, None]).contiguous()
+        nm = self.noise_model
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        z_T = nm.sample_limit_dist(node_mask, generator=gen, with_onehot=projector is not None)
+        st = self._alloc_state(node_mask)
+        cur = 0
+        st["labels"][0].copy_(z_T._labels)
+        pos = z_T.pos
+        s_values = list(reversed(range(0, self.T, self.faster_sampling)))
+        if steps is not None:
+            s_values = s_values[:steps]
+        proj = projector(z_T, dev) if projector is not None else None
+        t = self.T
+        for s in s_values:
+            labels_t = st["labels"][cur]
+            inp = self._build_inputs(st, labels_t, node_mask, t)
+            pred = self.model(inp)
+            rng = Rng(seed=seed, step=s, graph_id_base=graph_id_base)
+            nm.reverse_step_state(pred.E, labels_t, node_mask, st["t_all"][t], st["t_all"][s], rng,
+                                  labels_out=st["labels"][cur ^ 1], cands_out=st["cands"][cur ^ 1])
+            cur ^= 1
+            if proj is not None:   # host-side validity projector: reference types in, in-place edit of z_s.E
+                s_int = torch.full((B, 1), s, dtype=torch.long, device=dev)
+                z_s = nm._to_placeholder(st["labels"][cur], st["cands"][cur], node_mask, s_int, pos, B)
+                proj.project(z_s)
+                z_s._labels = None
+                st["labels"][cur].copy_(NoiseModel._labels_of(z_s, nm.E_classes))
+            t = s
+        labels = st["labels"][cur]
+        if return_state:
+            return labels, st["cands"][cur], node_mask, pos
+        E = labels.long()                                  # collapse (utils.py:169-195): diag of valid nodes -> argmax of a
+        eye = torch.eye(n, dtype=torch.bool, device=dev)[None]          # zero row = 0, padded pairs -> -1
+        valid = node_mask[:, :, None] & node_mask[:, None, :]
+        E = torch.where(valid & eye, torch.zeros_like(E), E)
+        E = torch.where(valid, E, torch.full_like(E, -1))
+        X = torch.where(node_mask, torch.zeros_like(n_nodes[:, None].expand(-1, n)), torch.full((B, n), -1, device=dev))
+        return PlaceHolder(X=X, charges=torch.where(node_mask, 0, 1000), E=E, y=torch.zeros(B, 0, device=dev),
+                           node_mask=node_mask, pos=pos)

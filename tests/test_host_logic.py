@@ -1,0 +1,132 @@
+"""CPU-side checks of the product's host logic (no GPU, no compute calls): schedule tables and transition matrices
+against the reference's golden vectors, PlaceHolder semantics, the drop-in state_dict layout, input-dim bookkeeping,
+and that libscgg.so loads and exports every symbol include/scgg.h declares."""
+import ctypes
+import os
+import re
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, golden_shapes
+from oracle import fixtures as fx
+
+PKG = "semantically_consistent_graph_generation_amd"
+
+
+def cfg(transition, T=500, top_k=4):
+    return SimpleNamespace(model=SimpleNamespace(nu=dict(x=1, c=1, e=1, y=1, e_small=1, e_mid=1, e_large=1),
+                                                 transition=transition, diffusion_steps=T, top_k=top_k),
+                           dataset=SimpleNamespace(name="cow"))
+
+
+def make_noise_model(tr, C=5, e_marg=None, T=500, top_k=4):
+    from semantically_consistent_graph_generation_amd import noise_model as NM
+    xm, cm = torch.ones(1), torch.zeros(0)
+    em = torch.ones(C) / C if e_marg is None else torch.as_tensor(e_marg)
+    if tr == "absorbing_edges":
+        return NM.AbsorbingEdgesTransition(cfg(tr, T, top_k), xm, em, cm, 0)
+    if tr == "marginal":
+        return NM.MarginalTransition(cfg(tr, T, top_k), xm, em, cm, 0)
+    if tr == "uniform":
+        return NM.DiscreteUniformTransition(cfg(tr, T, top_k), fx.dims_ns(1, C, 0, 0))
+    return NM.AbsorbingTransition(cfg(tr, T, top_k), fx.dims_ns(1, C, 0, 0))
+
+
+@pytest.mark.parametrize("tr", ["absorbing_edges", "marginal", "uniform", "absorbing"])
+def test_noise_model_tables_and_Q(tr):
+    g = load_golden("f7_schedules")
+    em = g["e_marginals"] if tr in ("marginal", "absorbing_edges") else None
+    nm = make_noise_model(tr, 5, em)
+    np.testing.assert_allclose(nm._betas.numpy(), g[f"{tr}/betas"], rtol=1e-12)
+    np.testing.assert_allclose(nm._alphas_bar.numpy(), g[f"{tr}/alphas_bar"], rtol=1e-12)
+    if tr == "absorbing_edges":
+        np.testing.assert_allclose(nm._betas_abs.numpy(), g[f"{tr}/betas_abs"], rtol=1e-12)
+        np.testing.assert_allclose(nm._alphas_abs_bar.numpy(), g[f"{tr}/alphas_abs_bar"], rtol=1e-12)
+    t = torch.from_numpy(g["t"])
+    qt, qtb = nm.get_Qt(t), nm.get_Qt_bar(t)
+    np.testing.assert_allclose(qt.E.numpy(), g[f"{tr}/Qt_E"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(qtb.E.numpy(), g[f"{tr}/Qtb_E"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(qt.X.numpy(), g[f"{tr}/Qt_X"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(qtb.X.numpy(), g[f"{tr}/Qtb_X"], rtol=1e-6, atol=1e-7)
+    # the fp32 tables handed to the kernel are exactly what get_Qt / get_Qt_bar index
+    beta, abar = nm._edge_tables()
+    k = 1 if tr != "absorbing" else 1
+    np.testing.assert_allclose(qt.E[:, k, 0].numpy() / max(float(nm.E_marginals[0]), 1e-30) if nm.E_marginals[0] > 0 else beta[t[:, 0]].numpy(),
+                               beta[t[:, 0]].numpy(), rtol=1e-6)
+    assert nm.T == 500 and nm.E_classes == 5 and nm.X_classes == 1
+
+
+def test_placeholder_mask_and_collapse():
+    from semantically_consistent_graph_generation_amd import PlaceHolder
+    g = load_golden("f11_placeholder")
+    m = torch.from_numpy(g["node_mask"])
+    ph = PlaceHolder(X=torch.from_numpy(g["X"]), E=torch.from_numpy(g["E"]), y=torch.zeros(2, 0),
+                     charges=torch.zeros(2, 5, 0), node_mask=m, pos=torch.from_numpy(g["pos"])).mask(check_symmetry=True)
+    np.testing.assert_array_equal(ph.X.numpy(), g["mX"])
+    np.testing.assert_array_equal(ph.E.numpy(), g["mE"])
+    np.testing.assert_allclose(ph.pos.numpy(), g["mpos"], atol=1e-7)
+    col = ph.collapse(None)
+    np.testing.assert_array_equal(col.X.numpy(), g["cX"])
+    np.testing.assert_array_equal(col.E.numpy(), g["cE"])
+    parts = ph.split()
+    assert [p.X.shape[0] for p in parts] == [5, 3] and parts[1].E.shape == (3, 3, 4)
+
+
+@pytest.mark.parametrize("name,dims", [("f3_gt_construct_cow", fx.CONSTRUCT_DIMS), ("f3_gt_vessel_atm", fx.VESSEL_DIMS),
+                                       ("f3_gt_tiny", fx.TINY_DIMS), ("f3_gt_tiny_noy", fx.TINY_DIMS)])
+def test_state_dict_layout_matches_reference(name, dims):
+    from semantically_consistent_graph_generation_amd.transformer_model import GraphTransformer
+    g = load_golden(name)
+    model = GraphTransformer(int(g["n_layers"]), fx.dims_ns(*[int(v) for v in g["in_dims"]]), dims["hidden_mlp_dims"],
+                             dims["hidden_dims"], fx.dims_ns(*[int(v) for v in g["out_dims"]]))
+    assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == golden_shapes(g)
+    # dim_ffy of the yaml is ignored: lin_y1 is dy -> 2048 (quirk 3)
+    assert model.tf_layers[0].lin_y1.out_features == 2048
+
+
+def test_forward_refuses_to_run_without_gpu_tensors():
+    from semantically_consistent_graph_generation_amd import _lib
+    from semantically_consistent_graph_generation_amd.transformer_model import GraphTransformer, model_input
+    model = GraphTransformer(2, fx.dims_ns(5, 9, 6), fx.TINY_DIMS["hidden_mlp_dims"], fx.TINY_DIMS["hidden_dims"],
+                             fx.dims_ns(3, 4, 2)).eval()
+    with pytest.raises(_lib.ScggError):
+        model(model_input(torch.zeros(1, 3, 5), torch.zeros(1, 3, 3, 9), torch.zeros(1, 6), torch.ones(1, 3, dtype=torch.bool)))
+
+
+def test_update_input_dims_and_dummy():
+    from semantically_consistent_graph_generation_amd.extra_features import ExtraFeatures, DummyExtraFeatures
+    c = SimpleNamespace(model=SimpleNamespace(num_degree=10, max_degree=10, cycle_features=True, num_eigenvectors=5,
+                                              num_eigenvalues=9, eigenfeatures=True))
+    ef = ExtraFeatures(c, SimpleNamespace(max_n_nodes=32))
+    d = ef.update_input_dims(fx.dims_ns(1, 14, 1))
+    assert (d.X, d.E, d.y) == (10, 25, 43)                       # CoW, SURVEY.md section 8
+    d = ef.update_input_dims(fx.dims_ns(1, 5, 1))
+    assert (d.X, d.E, d.y) == (10, 16, 34)                       # ATM
+    out = DummyExtraFeatures()(SimpleNamespace(X=torch.zeros(2, 3, 1), E=torch.zeros(2, 3, 3, 5), y=torch.zeros(2, 0)))
+    assert out.X.shape == (2, 3, 0) and out.E.shape == (2, 3, 3, 0) and out.y.shape == (2, 0)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "scgg.h")).read()
+    declared = sorted(set(re.findall(r"\b(scgg_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 15
+    so = os.path.join(ROOT, PKG, "libscgg.so")
+    assert os.path.exists(so), "build the library first (__graft_entry__.build())"
+    lib = ctypes.CDLL(so)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/scgg.h but not exported"
+    from semantically_consistent_graph_generation_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared
+    assert _lib.lib().scgg_version() >= 1
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, PKG)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
