@@ -1,0 +1,179 @@
+"""Benchmark of the north-star path on MI355X: sampled graphs/sec for the full T-step reverse diffusion.
+
+A "step" is one complete reverse chain (T = 500 denoiser forwards + extra features + reverse steps) over one batch of
+B = 512 synthetic CoW-shaped graphs per GPU (BASELINE.json configs[1]: ConStruct dims, extra features on, n <= 32,
+projector None).  N > 1 (launched by torch.distributed.run) shards independent graph batches: every rank samples its
+own B graphs (weak scaling), no collective on the data path; the timed region is bracketed by barrier +
+synchronize and the MAX over ranks is reported.
+
+Also printed in the same JSON line:
+  roofline      the fused edge-layer kernel (dominant): achieved fp32 TFLOP/s = algorithmic flops of one launch
+                (valid pairs x (6 de dx + 4 de ffE)) / its average duration, measured live with HIP events on the
+                launch stream inside the timed region (every 16th forward); peak = 157.3 TFLOP/s fp32 MFMA.
+  cpu_baseline  the CPU oracle (eager torch fp32 "port" of the reference algorithm) timed on this host for a bounded
+                sample (B = 32 graphs, a few reverse steps), extrapolated to graphs/s for the full chain.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+DIMS = dict(hidden_mlp_dims={"X": 256, "E": 128, "y": 128},
+            hidden_dims={"dx": 256, "de": 64, "dy": 64, "n_head": 8, "dim_ffX": 256, "dim_ffE": 128, "dim_ffy": 128})
+C_E, N_LAYERS, TOP_K, N_MAX = 14, 5, 4, 32
+NU = dict(x=1, c=1, e=1, y=1, e_small=1, e_mid=1, e_large=1)
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def ns(X, E, y, charges=0):
+    return SimpleNamespace(X=X, E=E, y=y, charges=charges)
+
+
+def node_counts(B, rank):
+    g = torch.Generator().manual_seed(1234 + rank)
+    n = torch.randint(12, N_MAX + 1, (B,), generator=g)
+    n[0] = N_MAX
+    return n
+
+
+def build_sampler(T, device):
+    from semantically_consistent_graph_generation_amd import noise_model as NM
+    from semantically_consistent_graph_generation_amd.extra_features import ExtraFeatures
+    from semantically_consistent_graph_generation_amd.sampling import DiscreteSampler
+    from semantically_consistent_graph_generation_amd.transformer_model import GraphTransformer
+    cfg = SimpleNamespace(model=SimpleNamespace(nu=NU, transition="absorbing_edges", diffusion_steps=T, top_k=TOP_K,
+                                                num_degree=10, max_degree=10, cycle_features=True, num_eigenvectors=5,
+                                                num_eigenvalues=9, eigenfeatures=True))
+    ef = ExtraFeatures(cfg, SimpleNamespace(max_n_nodes=N_MAX))
+    in_dims = ef.update_input_dims(ns(1, C_E, 1))
+    torch.manual_seed(0)
+    model = GraphTransformer(N_LAYERS, in_dims, DIMS["hidden_mlp_dims"], DIMS["hidden_dims"], ns(1, C_E, 0)).eval().to(device)
+    nm = NM.AbsorbingEdgesTransition(cfg, torch.ones(1), torch.ones(C_E) / C_E, torch.zeros(0), 0)
+    return DiscreteSampler(model, nm, ef), model
+
+
+def cpu_baseline(T, budget_steps=8, B=32):
+    """The oracle's reverse step (extra features + denoiser + posterior + sampling) on the host cores."""
+    import numpy as np
+    from oracle import denoiser as D, extra_features as XF, fixtures as fx, noise as N
+    from semantically_consistent_graph_generation_amd.transformer_model import GraphTransformer
+    torch.manual_seed(0)
+    shapes = GraphTransformer(N_LAYERS, ns(10, 25, 43), DIMS["hidden_mlp_dims"], DIMS["hidden_dims"], ns(1, C_E, 0)).state_dict()
+    sd = {k: v.clone() for k, v in shapes.items()}
+    m = fx.ragged_mask(node_counts(B, 0), N_MAX)
+    n = N_MAX
+    live = (m[:, :, None] & m[:, None, :]) & ~torch.eye(n, dtype=torch.bool)[None]
+    tr = N.Transition(N.Schedule(T, "absorbing_edges", NU), [1.0], np.ones(C_E, np.float32) / C_E)
+    dd = D.DenoiserDims(N_LAYERS, 8, 1, C_E, 0)
+    lab = torch.where(live, 0, -1)
+    X = m[..., None].float()
+    times = []
+    with torch.no_grad():
+        for k in range(budget_steps + 1):
+            s = T - 1 - k
+            t0 = time.perf_counter()
+            E = fx.one_hot_edges(lab.clamp(min=0), m, C_E)
+            xe, ee, ye = XF.extra_features(X, E, m, N_MAX)
+            y = torch.cat([ye, torch.full((B, 1), (s + 1) / T)], dim=1)
+            _, _, logits, _ = D.graph_transformer_forward(sd, dd, torch.cat([X, xe], -1), torch.cat([E, ee], -1), y, m)
+            u0, uk = N.philox_edge_uniforms(0, s, np.arange(B), n, TOP_K)
+            lab = N.reverse_step(tr, X, E, torch.zeros(B, n, 1), logits, m, torch.full((B, 1), s + 1),
+                                 torch.full((B, 1), s), np.zeros((B, n), np.float32), u0, uk)["labels_E"]
+            if k > 0:
+                times.append(time.perf_counter() - t0)
+    step = sorted(times)[len(times) // 2]
+    return {"value": B / (T * step), "unit": "graphs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (eager torch fp32) reverse step, B={B} CoW-shaped graphs, median of {budget_steps} steps "
+                      f"({step * 1e3:.0f} ms/step) extrapolated to the {T}-step chain"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--T", type=int, default=500, help="diffusion steps per chain (BASELINE: 500)")
+    ap.add_argument("--batch", type=int, default=512, help="graphs per GPU per chain (BASELINE: 512)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    sampler, model = build_sampler(a.T, dev)
+    n_nodes = node_counts(a.batch, rank)
+    valid_pairs = int((n_nodes.long() ** 2).sum())
+    hd = DIMS["hidden_dims"]
+    flops_per_launch = valid_pairs * (6 * hd["de"] * hd["dx"] + 4 * hd["de"] * hd["dim_ffE"])
+
+    def chain(k):
+        return sampler.sample_batch(n_nodes, seed=1000 + k, graph_id_base=rank * a.batch, n_max=N_MAX, return_state=True)
+
+    for k in range(a.warmup):
+        chain(k)
+    if a.warmup == 0:
+        sampler.sample_batch(n_nodes, seed=1, n_max=N_MAX, steps=1, return_state=True)   # builds the engine
+    torch.cuda.synchronize()
+    model.profile_edge_layer(16, 4096)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        labels = chain(a.warmup + k)[0]
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+    n_launch, ms = model.read_edge_layer_profile()
+    edges = int((labels > 0).sum()) // 2
+
+    if rank == 0:
+        kernel_ms = ms / max(n_launch, 1)
+        achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12 if n_launch else 0.0
+        out = {
+            "metric": "sampled graphs/sec (full T-step reverse diffusion)", "value": world * a.batch * a.steps / elapsed,
+            "unit": "graphs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"CoW-shaped full {a.T}-step reverse sampling, B={a.batch}/GPU, n<=32 (n_i~U[12,32]), "
+                                   "ConStruct dims (dx256 de64 dy64 h8, 5 layers), extra features on, C=14, top_k=4, "
+                                   "absorbing_edges, projector None (BASELINE configs[1])",
+                       "graphs_per_gpu": a.batch, "diffusion_steps": a.T, "valid_pairs_per_forward": valid_pairs,
+                       "sampled_edges_last_chain": edges},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "scgg::edge_layer_kernel<8,2,4> (fused XEy layer, edge path, fp32 MFMA)",
+                         "avg_launch_ms": kernel_ms, "launches_timed": n_launch,
+                         "algorithmic_flops_per_launch": flops_per_launch,
+                         "edge_stream_GBps": 2 * valid_pairs * hd["de"] * 4 / (kernel_ms * 1e-3) / 1e9 if n_launch else 0.0},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(a.T)
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,13 @@ int scgg_denoiser_forward_hidden(scgg_denoiser* h, const float* X, const float* 
                                  const uint8_t* node_mask, int32_t B, int32_t n, int32_t n_run_layers, float* hid_X,
                                  float* hid_E, float* hid_y, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Measurement aid (no counterpart in the reference): time the dominant kernel (the fused edge-layer kernel) with HIP
+ * events recorded on the launch stream around its launches in every `every_n_forwards`-th forward (0 = off).  At most
+ * max_launches launches are timed between two reads.  scgg_denoiser_profile allocates the events (call it outside
+ * the timed region); scgg_denoiser_profile_read needs the stream synchronised and returns count and summed ms. */
+int scgg_denoiser_profile(scgg_denoiser* h, int32_t every_n_forwards, int32_t max_launches);
+int scgg_denoiser_profile_read(scgg_denoiser* h, int32_t* n_launches, double* total_ms);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Reverse step: NoiseModel.sample_zs_from_zt_and_pred (src/ConStruct/diffusion/noise_model.py:342-447) with
  * sample_discrete_features (src/ConStruct/diffusion/diffusion_utils.py:200-285).  Called at

@@ -69,6 +69,11 @@ struct scgg_denoiser {
   size_t arena_bytes = 0;
   PackedLinear in_E1, in_E2, out_E1, out_E2;
   std::vector<LayerPack> layers;
+  // optional live timing of the dominant kernel (edge_layer_kernel): HIP events on the launch stream
+  int prof_every = 0;            // 0 = off; k = time the layer launches of every k-th forward
+  long long prof_forwards = 0;
+  std::vector<hipEvent_t> prof_ev;   // pairs (start, stop), created by scgg_denoiser_profile
+  size_t prof_used = 0;
 };
 
 namespace {
@@ -284,6 +289,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   }
   float* Ecur = w.E0;
   float* Enext = w.E1;
+  const bool prof_now = !tap && h->prof_every > 0 && (h->prof_forwards++ % h->prof_every) == 0;
 
   // ---- layers (transformer_model.py:76-112, :165-248)
   for (int l = 0; l < n_run_layers; ++l) {
@@ -311,7 +317,10 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       a.ln1_g = L.ln1_g; a.ln1_b = L.ln1_b; a.ln2_g = L.ln2_g; a.ln2_b = L.ln2_b;
       a.inv_sqrt_df = 1.0f / sqrtf((float)(dx / c.n_head));
       a.B = B; a.n = n;
+      const bool timed = prof_now && h->prof_used + 2 <= h->prof_ev.size();
+      if (timed) (void)hipEventRecord(h->prof_ev[h->prof_used], st);
       if (launch_edge_layer(a, dx, de, c.dim_ffE, st)) return fail("edge_layer: unsupported dims dx=%d de=%d ffE=%d", dx, de, c.dim_ffE);
+      if (timed) { (void)hipEventRecord(h->prof_ev[h->prof_used + 1], st); h->prof_used += 2; }
     }
     // X path (transformer_model.py:234-235, :88-92)
     if (gemm(w.newX, dx, P_(h, sa + "x_out.weight", (int64_t)dx * dx), P_(h, sa + "x_out.bias", dx), w.t1, dx, M, dx, dx,
@@ -408,6 +417,7 @@ scgg_denoiser* scgg_denoiser_create(const scgg_denoiser_config* cfg) {
 
 void scgg_denoiser_destroy(scgg_denoiser* h) {
   if (!h) return;
+  for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
   if (h->arena) (void)hipFree(h->arena);
   delete h;
 }
@@ -456,6 +466,35 @@ int scgg_denoiser_forward_hidden(scgg_denoiser* h, const float* X, const float* 
   if (!h || n_run_layers < 0 || n_run_layers > h->c.n_layers) return fail("forward_hidden: bad layer count");
   return run_forward(h, X, E, y, node_mask, B, n, n_run_layers, true, hid_X, hid_E, hid_y, workspace, workspace_bytes,
                      static_cast<hipStream_t>(stream));
+}
+
+int scgg_denoiser_profile(scgg_denoiser* h, int32_t every_n_forwards, int32_t max_launches) {
+  if (!h || every_n_forwards < 0 || max_launches < 0) return fail("profile: bad argument");
+  for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
+  h->prof_ev.clear();
+  h->prof_used = 0;
+  h->prof_forwards = 0;
+  h->prof_every = every_n_forwards;
+  if (every_n_forwards == 0) return 0;
+  h->prof_ev.resize((size_t)2 * max_launches);
+  for (hipEvent_t& e : h->prof_ev)
+    if (hipEventCreate(&e) != hipSuccess) return fail("profile: hipEventCreate failed");
+  return 0;
+}
+
+int scgg_denoiser_profile_read(scgg_denoiser* h, int32_t* n_launches, double* total_ms) {
+  if (!h || !n_launches || !total_ms) return fail("profile_read: null argument");
+  double tot = 0.0;
+  for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->prof_ev[i], h->prof_ev[i + 1]) != hipSuccess)
+      return fail("profile_read: events not complete (synchronise the stream first)");
+    tot += ms;
+  }
+  *n_launches = (int32_t)(h->prof_used / 2);
+  *total_ms = tot;
+  h->prof_used = 0;
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------- reverse step

@@ -216,6 +216,23 @@ class GraphTransformer(nn.Module):
         return hX, hE, hy
 
 
+def _profile(self, every_n_forwards, max_launches=4096):
+    """Live HIP-event timing of the fused edge-layer kernel (bench.py's roofline leg)."""
+    if self._engine is None:
+        raise _lib.ScggError("run one forward before enabling the profile")
+    _lib.check(_lib.lib().scgg_denoiser_profile(self._engine, every_n_forwards, max_launches), "profile")
+
+
+def _profile_read(self):
+    n, ms = C.c_int32(0), C.c_double(0.0)
+    _lib.check(_lib.lib().scgg_denoiser_profile_read(self._engine, C.byref(n), C.byref(ms)), "profile_read")
+    return n.value, ms.value
+
+
+GraphTransformer.profile_edge_layer = _profile
+GraphTransformer.read_edge_layer_profile = _profile_read
+
+
 def model_input(X, E, y, node_mask):
     """Convenience: the minimal object GraphTransformer.forward needs."""
     return SimpleNamespace(X=X, E=E, y=y, node_mask=node_mask)
