@@ -124,18 +124,33 @@ int scgg_onehot_to_labels(const float* E_onehot, int64_t n_pairs, int32_t C, int
  * (src/ConStruct/diffusion/extra_features.py:60-77, :198-385) plus the Laplacian that EigenFeatures hands to
  * eigh (:88-94).  Called at diffusion_model_discrete_3d.py:186.  Works on the int8 edge state.
  *   labels int8 [B,n,n] (adjacency = label > 0), node_labels int8 [B,n] or NULL (single node class), node_mask.
- *   x_out[B,n,3]                                      3/4/5-cycle counts per node, clamp(.,0,5)/5, masked
- *   y_out[B, 4 + (num_degree+2) + Cx + C]             cycles per graph | degree hist | node hist | edge hist
- *   e_out: for pair p the max_degree+1 features (reachability A^1..A^max_degree, Adamic-Adar index) go to
- *          e_out[p*e_ld + e_off ...]; with onehot_out != NULL the masked one-hot of the label goes to
- *          onehot_out[p*e_ld + 0..C)  (so the denoiser's E input [one-hot | extra] is assembled in one pass)
+ *   x_out: node (b,i) gets its 3 features (3/4/5-cycle counts, clamp(.,0,5)/5, masked) at x_out[(b*n+i)*x_ld + x_off ..]
+ *   y_out: graph b gets 4 + (num_degree+2) + Cx + C features (cycles per graph | degree hist | node hist | edge
+ *          hist) at y_out[b*y_ld + y_off ..]
+ *   e_out: pair p gets its max_degree+1 features (reachability A^1..A^max_degree, Adamic-Adar index) at
+ *          e_out[p*e_ld + e_off ..]; with onehot_out != NULL the masked one-hot of the label goes to
+ *          onehot_out[p*e_ld + 0..C)  (so the denoiser's inputs [state | extra] are assembled in one pass)
  *   lap_out[B,n,n] (optional)                         padded combinatorial Laplacian
  * n <= 32 in this round.
  * ---------------------------------------------------------------------------------------------------------- */
 int scgg_adjacency_features(const int8_t* labels, const int8_t* node_labels, const uint8_t* node_mask, int32_t B,
                             int32_t n, int32_t C, int32_t Cx, int32_t num_degree, int32_t max_degree,
-                            int32_t cycle_features, float* x_out, float* y_out, float* e_out, int32_t e_ld,
-                            int32_t e_off, float* onehot_out, float* lap_out, void* stream);
+                            int32_t cycle_features, float* x_out, int32_t x_ld, int32_t x_off, float* y_out,
+                            int32_t y_ld, int32_t y_off, float* e_out, int32_t e_ld, int32_t e_off, float* onehot_out,
+                            float* lap_out, void* stream);
+
+/* EigenFeatures.compute_features after the Laplacian (extra_features.py:96-112, :138-195), including the
+ * eigendecomposition the reference delegates to torch.linalg.eigh (:96): batched Jacobi, one wave per graph.
+ *   eval_feat: graph b gets [#connected components | first num_eigenvalues non-zero eigenvalues / n_valid (padded
+ *              with 2)] at eval_feat[b*ld_ev + off_ev ..]
+ *   evec_feat: node (b,i) gets [not-in-largest-component indicator | first num_eigenvectors eigenvectors] at
+ *              evec_feat[(b*n+i)*ld_vec + off_vec ..]
+ *   w_out[B,n] ascending eigenvalues, v_out[B,n,n] eigenvectors in columns (both optional, as torch.linalg.eigh).
+ * Eigenvectors inside a degenerate eigenspace are basis-dependent in the reference too; see DESIGN.md.  n <= 32. */
+int scgg_eigen_features(const float* laplacian, const uint8_t* node_mask, int32_t B, int32_t n,
+                        int32_t num_eigenvalues, int32_t num_eigenvectors, float* eval_feat, int32_t ld_ev,
+                        int32_t off_ev, float* evec_feat, int32_t ld_vec, int32_t off_vec, float* w_out, float* v_out,
+                        void* stream);
 
 #ifdef __cplusplus
 }

@@ -42,8 +42,9 @@ SIGNATURES = {
     "scgg_sample_edges_from_probs": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(Rng), _vp, _vp, _vp]),
     "scgg_labels_to_onehot": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "scgg_onehot_to_labels": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
-    "scgg_adjacency_features": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32,
-                                          _vp, _vp, _vp]),
+    "scgg_adjacency_features": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp,
+                                          _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "scgg_eigen_features": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
 }
 
 _lib = None

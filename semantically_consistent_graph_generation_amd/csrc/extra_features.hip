@@ -28,7 +28,7 @@ struct AdjArgs {
   float* e_out;            // pair stride e_ld, channel offset e_off, max_degree+1 channels
   float* onehot_out;       // optional: one-hot of the labels into the same destination rows, channels [0,C)
   float* lap_out;          // [B,n,n] or null
-  int B, n, C, Cx, num_degree, max_degree, cycle_features, e_ld, e_off;
+  int B, n, C, Cx, num_degree, max_degree, cycle_features, e_ld, e_off, x_ld, x_off, y_ld, y_off;
 };
 
 __device__ __forceinline__ float clamp05(float v) { return fminf(fmaxf(v, 0.f), 5.f) * 0.2f; }
@@ -137,7 +137,8 @@ __global__ __launch_bounds__(256) void adjacency_features_kernel(AdjArgs a) {
 
   // ---- per-node cycle counts and the graph-level sums (one wave)
   const int ny = 4 + a.num_degree + 2 + a.Cx + a.C;
-  float* y = a.y_out + (long long)b * ny;
+  float* y = a.y_out + (long long)b * a.y_ld + a.y_off;
+  (void)ny;
   if (tid < 64) {
     const int i = tid;
     float c3 = 0.f, c4 = 0.f, c5 = 0.f, d2 = 0.f, d3 = 0.f, d4 = 0.f, d6 = 0.f;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void adjacency_features_kernel(AdjArgs a) {
       c4 = d4 - d * (d - 1.f) - Ad;
       c5 = dg[4][i] - 2.f * d3 * d - At + d3;
       if (i < n) {
-        float* x = a.x_out + ((long long)b * n + i) * 3;
+        float* x = a.x_out + ((long long)b * n + i) * a.x_ld + a.x_off;
         const float keep = (m[i] && a.cycle_features) ? 1.f : 0.f;
         x[0] = clamp05(c3 * 0.5f) * keep;
         x[1] = clamp05(c4 * 0.5f) * keep;
@@ -209,17 +210,19 @@ using namespace scgg;
 
 extern "C" int scgg_adjacency_features(const int8_t* labels, const int8_t* node_labels, const uint8_t* node_mask,
                                        int32_t B, int32_t n, int32_t C, int32_t Cx, int32_t num_degree,
-                                       int32_t max_degree, int32_t cycle_features, float* x_out, float* y_out,
-                                       float* e_out, int32_t e_ld, int32_t e_off, float* onehot_out, float* lap_out,
-                                       void* stream) {
+                                       int32_t max_degree, int32_t cycle_features, float* x_out, int32_t x_ld,
+                                       int32_t x_off, float* y_out, int32_t y_ld, int32_t y_off, float* e_out,
+                                       int32_t e_ld, int32_t e_off, float* onehot_out, float* lap_out, void* stream) {
   if (!labels || !node_mask || !x_out || !y_out || !e_out) return fail("adjacency_features: null argument");
   if (B <= 0 || n <= 0) return fail("adjacency_features: bad shape");
   if (n > NT) return fail("adjacency_features: n=%d > 32 is not built yet (LDS-tile kernel only)", n);
   if (max_degree < 6 || max_degree > 32 || num_degree + 2 > 64 || C > 64 || Cx > 64 || C < 1 || Cx < 1)
     return fail("adjacency_features: unsupported max_degree=%d num_degree=%d C=%d Cx=%d", max_degree, num_degree, C, Cx);
-  if (e_ld < e_off + max_degree + 1 || (onehot_out && e_off < C)) return fail("adjacency_features: bad destination stride");
+  if (e_ld < e_off + max_degree + 1 || (onehot_out && e_off < C) || x_ld < x_off + 3 ||
+      y_ld < y_off + 4 + num_degree + 2 + Cx + C)
+    return fail("adjacency_features: bad destination stride");
   AdjArgs a{labels, node_mask, node_labels, x_out, y_out, e_out, onehot_out, lap_out,
-            B, n, C, Cx, num_degree, max_degree, cycle_features, e_ld, e_off};
+            B, n, C, Cx, num_degree, max_degree, cycle_features, e_ld, e_off, x_ld, x_off, y_ld, y_off};
   hipLaunchKernelGGL(adjacency_features_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail("adjacency_features: %s", hipGetErrorString(e));

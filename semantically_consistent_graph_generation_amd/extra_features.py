@@ -2,10 +2,10 @@
 ``update_input_dims`` and ``__call__(noisy_data) -> PlaceHolder(X, E, y)``; ``DummyExtraFeatures``.
 
 The O(n^2)/O(n^3) part (adjacency powers, cycle counts, reachability, Adamic-Adar index, histograms, Laplacian)
-runs in libscgg.so (``scgg_adjacency_features``) on the int8 edge state.  The eigendecomposition is the library call
-the reference uses (``torch.linalg.eigh`` -> rocSOLVER); the O(n) gathers around it are torch ops on the device and
-free of host syncs (the reference's Python ``max()`` over device tensors, :149/:178, is replaced by always padding
-with k columns, which selects the same entries).
+runs in libscgg.so (``scgg_adjacency_features``) on the int8 edge state.  The eigendecomposition the reference
+delegates to ``torch.linalg.eigh`` and the feature extraction around it run in ``scgg_eigen_features`` (batched Jacobi,
+one wave per graph): rocSOLVER's eigh costs 50 ms per step at B=512, n=32 (profiles/r01_b).  No host syncs (the
+reference's Python ``max()`` over device tensors, :149/:178, disappears: out-of-range columns are the padding value).
 """
 from __future__ import annotations
 
@@ -57,55 +57,55 @@ class ExtraFeatures:
         return input_dims
 
     # -------------------------------------------------------------------------------------------------------
-    def adjacency_features(self, labels, node_mask, C_e, e_dst=None, e_off=0, want_onehot=False, want_lap=True):
-        """Device call: -> (x[B,n,3], y[B,4+nd+2+1+C], e_dst, lap or None).  ``e_dst`` [B,n,n,ld] receives the edge
-        features at channel offset ``e_off`` (and the one-hot labels at [0,C) when ``want_onehot``)."""
+    def adjacency_features(self, labels, node_mask, C_e, e_dst=None, e_off=0, want_onehot=False, want_lap=True,
+                           x_dst=None, x_off=0, y_dst=None, y_off=0):
+        """Device call: -> (x, y, e_dst, lap or None).  The three feature groups are written at a channel offset into
+        caller buffers when given (``x_dst`` [B,n,ldx], ``y_dst`` [B,ldy], ``e_dst`` [B,n,n,lde]; with ``want_onehot``
+        the masked one-hot labels also go to ``e_dst[..., :C]``), else into fresh tensors x[B,n,3], y[B,4+nd+2+1+C],
+        e[B,n,n,max_degree+1]."""
         B, n = node_mask.shape
         dev = node_mask.device
-        kE = self.max_degree + 1
         if e_dst is None:
-            e_dst = torch.empty(B, n, n, kE, device=dev)
-        ld = e_dst.shape[-1]
-        x = torch.empty(B, n, 3, device=dev)
-        y = torch.empty(B, 4 + self.num_degree + 2 + 1 + C_e, device=dev)
+            e_dst = torch.empty(B, n, n, self.max_degree + 1, device=dev)
+        if x_dst is None:
+            x_dst = torch.empty(B, n, 3, device=dev)
+        if y_dst is None:
+            y_dst = torch.empty(B, 4 + self.num_degree + 2 + 1 + C_e, device=dev)
         lap = torch.empty(B, n, n, device=dev) if want_lap else None
         _lib.check(_lib.lib().scgg_adjacency_features(
             _lib.ptr(labels), None, _lib.ptr(node_mask.view(torch.uint8)), B, n, C_e, 1, self.num_degree, self.max_degree,
-            int(self.cycle_features), _lib.ptr(x), _lib.ptr(y), _lib.ptr(e_dst), ld, e_off,
-            _lib.ptr(e_dst) if want_onehot else None, _lib.ptr(lap), _lib.stream_ptr()), "adjacency_features")
-        return x, y, e_dst, lap
+            int(self.cycle_features), _lib.ptr(x_dst), x_dst.shape[-1], x_off, _lib.ptr(y_dst), y_dst.shape[-1], y_off,
+            _lib.ptr(e_dst), e_dst.shape[-1], e_off, _lib.ptr(e_dst) if want_onehot else None, _lib.ptr(lap),
+            _lib.stream_ptr()), "adjacency_features")
+        return x_dst, y_dst, e_dst, lap
 
-    def eigen_features(self, lap, node_mask):
-        """EigenFeatures.compute_features after the Laplacian (reference :96-112, :138-195)."""
+    def eigen_features(self, lap, node_mask, evl_dst=None, evl_off=0, evc_dst=None, evc_off=0, want_raw=False):
+        """EigenFeatures.compute_features after the Laplacian (reference :96-112, :138-195) on the device: batched
+        Jacobi eigensolver + feature extraction in one kernel.  -> (evalue_feat, evector_feat[, w, V])."""
         B, n = node_mask.shape
-        m = node_mask.float()
-        ev, vec = torch.linalg.eigh(lap)
-        ev = ev / m.sum(dim=1, keepdim=True)
-        vec = vec * m[:, :, None] * m[:, None, :]
-        ncc = (ev < 1e-5).sum(dim=-1)
-        k = self.num_eigenvalues
-        evp = torch.cat([ev, 2 * torch.ones(B, k, device=ev.device)], dim=1)
-        first_ev = torch.gather(evp, 1, torch.arange(k, device=ev.device)[None] + ncc[:, None])
-        evalue_feat = torch.cat([ncc[:, None].to(ev.dtype), first_ev], dim=1)
-        # LCC indicator: nodes whose (rounded) first-eigenvector entry differs from the most common value.  Padded
-        # entries get distinct large values so they can only win a tie among all-distinct valid entries, where the
-        # smallest valid value wins (the reference randomises them with randn, :171-173).
-        v0 = torch.round(vec[:, :, 0], decimals=3)
-        v0 = torch.where(node_mask, v0, 1e6 + torch.arange(n, device=ev.device, dtype=v0.dtype)[None])
-        mode = torch.mode(v0, dim=1).values
-        not_lcc = ((v0 != mode[:, None]) & node_mask).float()
-        k = self.num_eigenvectors
-        vp = torch.cat([vec, torch.zeros(B, n, k, device=ev.device)], dim=2)
-        idx = (torch.arange(k, device=ev.device)[None, None] + ncc[:, None, None]).expand(-1, n, -1)
-        first_vec = torch.gather(vp, 2, idx) * m[:, :, None]
-        return evalue_feat, torch.cat([not_lcc[..., None], first_vec], dim=-1)
+        dev = node_mask.device
+        if evl_dst is None:
+            evl_dst = torch.empty(B, 1 + self.num_eigenvalues, device=dev)
+        if evc_dst is None:
+            evc_dst = torch.empty(B, n, 1 + self.num_eigenvectors, device=dev)
+        w = torch.empty(B, n, device=dev) if want_raw else None
+        V = torch.empty(B, n, n, device=dev) if want_raw else None
+        _lib.check(_lib.lib().scgg_eigen_features(
+            _lib.ptr(lap), _lib.ptr(node_mask.view(torch.uint8)), B, n, self.num_eigenvalues, self.num_eigenvectors,
+            _lib.ptr(evl_dst), evl_dst.shape[-1], evl_off, _lib.ptr(evc_dst), evc_dst.shape[-1], evc_off, _lib.ptr(w),
+            _lib.ptr(V), _lib.stream_ptr()), "eigen_features")
+        return (evl_dst, evc_dst, w, V) if want_raw else (evl_dst, evc_dst)
 
     def __call__(self, noisy_data):
         """reference :60-77."""
         node_mask = noisy_data.node_mask.contiguous()
-        C_e = noisy_data.E.shape[-1] if noisy_data.E is not None else noisy_data._labels_classes
+        B, n = node_mask.shape
+        C_e = noisy_data.E.shape[-1]
         labels = NoiseModel._labels_of(noisy_data, C_e)
-        x, y, e, lap = self.adjacency_features(labels, node_mask, C_e)
-        nfrac = node_mask.sum(dim=1, keepdim=True) / self.max_n_nodes
-        evl, evc = self.eigen_features(lap, node_mask)
-        return PlaceHolder(X=torch.cat([x, evc], dim=-1), E=e, y=torch.cat([nfrac, y, evl], dim=1))
+        ky = 4 + self.num_degree + 2 + 1 + C_e
+        X = torch.empty(B, n, 3 + 1 + self.num_eigenvectors, device=node_mask.device)
+        y = torch.empty(B, 1 + ky + 1 + self.num_eigenvalues, device=node_mask.device)
+        _, _, e, lap = self.adjacency_features(labels, node_mask, C_e, x_dst=X, x_off=0, y_dst=y, y_off=1)
+        self.eigen_features(lap, node_mask, evl_dst=y, evl_off=1 + ky, evc_dst=X, evc_off=3)
+        y[:, 0:1] = node_mask.sum(dim=1, keepdim=True) / self.max_n_nodes
+        return PlaceHolder(X=X, E=e, y=y)

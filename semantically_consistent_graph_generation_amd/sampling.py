@@ -60,6 +60,8 @@ class DiscreteSampler:
             "t_all": torch.arange(self.T + 1, dtype=torch.int32, device=dev)[:, None].expand(-1, B).contiguous(),
         }
         st["X_in"][..., 0] = node_mask.float()            # single node class: masked one-hot
+        if isinstance(self.extra_features, ExtraFeatures):
+            st["y_in"][:, 0:1] = node_mask.sum(dim=1, keepdim=True) / self.extra_features.max_n_nodes
         return st
 
     def _build_inputs(self, st, labels, node_mask, t):
@@ -69,16 +71,13 @@ class DiscreteSampler:
         C_e = nm.E_classes
         ef = self.extra_features
         if isinstance(ef, ExtraFeatures):
-            x, y, _, lap = ef.adjacency_features(labels, node_mask, C_e, e_dst=st["E_in"], e_off=C_e, want_onehot=True)
-            evl, evc = ef.eigen_features(lap, node_mask)
-            st["X_in"][..., 1:4] = x
-            st["X_in"][..., 4:] = evc
-            yi = st["y_in"]
-            yi[:, 0:1] = node_mask.sum(dim=1, keepdim=True) / ef.max_n_nodes
-            k = y.shape[1]
-            yi[:, 1:1 + k] = y
-            yi[:, 1 + k:1 + k + evl.shape[1]] = evl
-            yi[:, -1] = t / self.T
+            # X_in = [node one-hot | 3 cycle feats | LCC flag + eigenvectors], y_in = [n/n_max | graph feats |
+            # eigenvalue feats | t], E_in = [edge one-hot | reachability + Adamic-Adar]: two kernels, no copies
+            ky = 4 + ef.num_degree + 2 + 1 + C_e
+            _, _, _, lap = ef.adjacency_features(labels, node_mask, C_e, e_dst=st["E_in"], e_off=C_e, want_onehot=True,
+                                                 x_dst=st["X_in"], x_off=1, y_dst=st["y_in"], y_off=1)
+            ef.eigen_features(lap, node_mask, evl_dst=st["y_in"], evl_off=1 + ky, evc_dst=st["X_in"], evc_off=4)
+            st["y_in"][:, -1] = t / self.T
         else:
             _lib.check(_lib.lib().scgg_labels_to_onehot(_lib.ptr(labels), None, B * n * n, C_e, 0, _lib.ptr(st["E_in"]), None,
                                                         _lib.stream_ptr()), "labels_to_onehot")
