@@ -204,6 +204,7 @@ int build(scgg_denoiser* h, bool fill, hipStream_t st) {
 
 struct Workspace {
   float *Xh, *qkv, *newX, *t1, *t2, *E0, *E1, *y, *ycat, *yt1, *yt2, *film, *hidX, *hidy, *xo;
+  int *rows, *row_count;
   size_t bytes;
 };
 
@@ -228,6 +229,8 @@ Workspace carve(const scgg_denoiser_config& c, int B, int n, char* base) {
   w.hidX = ar.take<float>(M * c.hid_X);
   w.hidy = ar.take<float>((size_t)B * c.hid_y);
   w.xo = ar.take<float>(M * (size_t)(c.out_X > 0 ? c.out_X : 1));
+  w.rows = ar.take<int>(M);
+  w.row_count = ar.take<int>(64);
   w.bytes = align_up(ar.off, 256);
   return w;
 }
@@ -289,6 +292,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   }
   float* Ecur = w.E0;
   float* Enext = w.E1;
+  launch_build_row_list(mask, M, w.rows, w.row_count, st);
   const bool prof_now = !tap && h->prof_every > 0 && (h->prof_forwards++ % h->prof_every) == 0;
 
   // ---- layers (transformer_model.py:76-112, :165-248)
@@ -315,11 +319,12 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       a.W_mul = L.e_mul.W; a.W_add = L.e_add.W; a.W_out = L.e_out.W; a.W_ff1 = L.ff1.W; a.W_ff2 = L.ff2.W;
       a.b_mul1 = L.e_mul.b; a.b_add = L.e_add.b; a.b_out = L.e_out.b; a.b_ff1 = L.ff1.b; a.b_ff2 = L.ff2.b;
       a.ln1_g = L.ln1_g; a.ln1_b = L.ln1_b; a.ln2_g = L.ln2_g; a.ln2_b = L.ln2_b;
+      a.rows = w.rows; a.row_count = w.row_count;
       a.inv_sqrt_df = 1.0f / sqrtf((float)(dx / c.n_head));
       a.B = B; a.n = n;
       const bool timed = prof_now && h->prof_used + 2 <= h->prof_ev.size();
       if (timed) (void)hipEventRecord(h->prof_ev[h->prof_used], st);
-      if (launch_edge_layer(a, dx, de, c.dim_ffE, st)) return fail("edge_layer: unsupported dims dx=%d de=%d ffE=%d", dx, de, c.dim_ffE);
+      if (launch_edge_layer(a, dx, de, c.dim_ffE, st)) return fail("edge_layer: unsupported dims dx=%d de=%d ffE=%d (or launch setup failed)", dx, de, c.dim_ffE);
       if (timed) { (void)hipEventRecord(h->prof_ev[h->prof_used + 1], st); h->prof_used += 2; }
     }
     // X path (transformer_model.py:234-235, :88-92)

@@ -1,8 +1,7 @@
 // Edge-path kernels of the GraphTransformer denoiser for gfx950 (MI355X), fp32 on v_mfma_f32_32x32x2_f32.
 //
 //   edge_mlp_in_kernel   mlp_in_E                        transformer_model.py:290-297, :358
-//   edge_layer_kernel    NodeEdgeBlock (E part + attention) + XEyTransformerLayer E path
-//                                                        transformer_model.py:165-227, :94-99
+//   (the fused layer kernel itself lives in edge_layer.hip)
 //   edge_mlp_out_kernel  mlp_out_E + residual + diagonal mask + symmetrise + mask
 //                                                        transformer_model.py:372-376, :387-389
 //   edge_stats_kernel    Etoy pooling (mean|min|max|var) layers.py:34-41
@@ -66,145 +65,6 @@ __global__ __launch_bounds__(256, 2) void edge_mlp_in_kernel(EdgeMlpInArgs a) {
       float* dst = a.E_out + pair * (32 * NEB);
 #pragma unroll
       for (int rb = 0; rb < NEB; ++rb) store_vec_block(dst + 32 * rb, h, out[rb]);
-    }
-  }
-}
-
-// =====================================================================================================
-// fused XEy layer, edge part
-// =====================================================================================================
-template <int NXB, int NEB, int NFB>   // dx/32, de/32, ffE/32
-__global__ __launch_bounds__(256, 2) void edge_layer_kernel(EdgeLayerArgs a) {
-  constexpr int DX = 32 * NXB, DE = 32 * NEB;
-  __shared__ float run[4][3][DX];   // per-wave running (max, sum, weighted sum) for rows with > 32 keys
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= a.B * a.n) return;
-  const int b = row / a.n, i = row - b * a.n;
-  if (a.mask[row] == 0) return;      // padded query row: nothing downstream ever reads it (consumers select by mask)
-  const int n = a.n;
-  const int nchunks = (n + 31) >> 5;
-  const float* Qi = a.Q + (long long)row * a.ldqkv;
-  const float* film = a.film + (long long)b * (4 * DX);   // [ye_add | ye_mul+1 | yx_add | yx_mul+1]
-  float* mrun = run[wave][0];
-  float* srun = run[wave][1];
-  float* arun = run[wave][2];
-
-  for (int jc = 0; jc < nchunks; ++jc) {
-    const int j = jc * 32 + p;
-    const bool inb = j < n;
-    const int jj = inb ? j : 0;
-    const bool vj = inb && a.mask[b * n + jj] != 0;
-    const bool live = vj && j != i;
-    const long long off_ij = ((long long)row * n + jj) * DE;
-    const long long off_ji = (((long long)b * n + jj) * n + i) * DE;
-    const float* Kj = a.K + ((long long)b * n + jj) * a.ldqkv;
-    const float* Vj = a.V + ((long long)b * n + jj) * a.ldqkv;
-
-    f32x16 e[NEB];
-    load_sym_tile<NEB>(e, a.E_in, off_ij, off_ji, live, h);
-
-    f32x16 accO[NEB];
-#pragma unroll
-    for (int rb = 0; rb < NEB; ++rb) accO[rb] = load_vec_block(a.b_out + 32 * rb, h);
-
-#pragma unroll 1
-    for (int cb = 0; cb < NXB; ++cb) {
-      f32x16 a1 = load_vec_block(a.b_mul1 + 32 * cb, h);   // bias + 1
-      f32x16 a2 = load_vec_block(a.b_add + 32 * cb, h);
-      linear_rb<NEB>(a1, a.W_mul, cb, e, lane);
-      linear_rb<NEB>(a2, a.W_add, cb, e, lane);
-      const f32x16 q = load_vec_block(Qi + 32 * cb, h);
-      f32x16 k = load_vec_block(Kj + 32 * cb, h);
-      f32x16 v = load_vec_block(Vj + 32 * cb, h);
-      const f32x16 yea = load_vec_block(film + 32 * cb, h);
-      const f32x16 yem = load_vec_block(film + DX + 32 * cb, h);
-      f32x16 z;
-      float wv[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float kk = vj ? k[r] : 0.f;
-        const float y = (q[r] * kk) * a.inv_sqrt_df * a1[r] + a2[r];      // Y = QK/sqrt(df) * (E1+1) + E2
-        z[r] = yea[r] + yem[r] * y;                                      // FiLM by y before e_out
-        // per-channel softmax over the keys of this chunk
-        const float ym = vj ? y : -INFINITY;
-        const float mx = half_max(ym);
-        const float pexp = vj ? __expf(y - mx) : 0.f;
-        const float s = half_sum(pexp);
-        const float av = half_sum(pexp * (vj ? v[r] : 0.f));
-        if (nchunks == 1) {
-          wv[r] = av / s;
-        } else {
-          const int c = 32 * cb + ch_of(r, h);
-          if (p == 0) {
-            if (jc == 0) {
-              mrun[c] = mx; srun[c] = s; arun[c] = av;
-            } else {
-              const float mo = mrun[c], mn = fmaxf(mo, mx);
-              const float fo = mo == -INFINITY ? 0.f : __expf(mo - mn);
-              const float fn = mx == -INFINITY ? 0.f : __expf(mx - mn);
-              mrun[c] = mn;
-              srun[c] = srun[c] * fo + s * fn;
-              arun[c] = arun[c] * fo + av * fn;
-            }
-          }
-          wv[r] = 0.f;
-        }
-      }
-      if (nchunks == 1 && p == 0) {
-        // newX_pre = yx_add + (yx_mul + 1) * weighted_V   (transformer_model.py:230-232)
-        const f32x16 yxa = load_vec_block(film + 2 * DX + 32 * cb, h);
-        const f32x16 yxm = load_vec_block(film + 3 * DX + 32 * cb, h);
-        f32x16 o;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = yxa[r] + yxm[r] * wv[r];
-        store_vec_block(a.newX_pre + (long long)row * DX + 32 * cb, h, o);
-      }
-      // newE += W_out[:, block cb] . z
-#pragma unroll
-      for (int rb = 0; rb < NEB; ++rb) mfma_block<NXB>(accO[rb], a.W_out, rb, cb, z, lane);
-    }
-
-    // E <- LN1(E + newE)   (newE is masked by m_i m_j: identical for live pairs; dead pairs are zeroed at the store)
-#pragma unroll
-    for (int rb = 0; rb < NEB; ++rb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) e[rb][r] += accO[rb][r];
-    layernorm_c<NEB>(e, a.ln1_g, a.ln1_b, h);
-    // FFN
-    f32x16 hid[NFB];
-#pragma unroll
-    for (int rb = 0; rb < NFB; ++rb) {
-      hid[rb] = load_vec_block(a.b_ff1 + 32 * rb, h);
-      linear_rb<NEB>(hid[rb], a.W_ff1, rb, e, lane);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hid[rb][r] = fmaxf(hid[rb][r], 0.f);
-    }
-#pragma unroll
-    for (int rb = 0; rb < NEB; ++rb) {
-      f32x16 f = load_vec_block(a.b_ff2 + 32 * rb, h);
-      linear_rb<NFB>(f, a.W_ff2, rb, hid, lane);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) e[rb][r] += f[r];
-    }
-    layernorm_c<NEB>(e, a.ln2_g, a.ln2_b, h);
-    if (inb) {
-      float* dst = a.E_out + off_ij;
-#pragma unroll
-      for (int rb = 0; rb < NEB; ++rb) {
-        if (!live) e[rb] = splat16(0.f);
-        store_vec_block(dst + 32 * rb, h, e[rb]);
-      }
-    }
-  }
-
-  if (nchunks > 1) {
-    // finish the multi-chunk rows: every lane of the wave takes channels lane, lane+64, ...
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int c = lane; c < DX; c += 64) {
-      const float wv = arun[c] / srun[c];
-      a.newX_pre[(long long)row * DX + c] = film[2 * DX + c] + film[3 * DX + c] * wv;
     }
   }
 }
@@ -341,18 +201,6 @@ int launch_edge_mlp_in(const EdgeMlpInArgs& a, int dE_in, int hid, int de, hipSt
     return 0;                                                                    \
   }
   CASE(1, 4, 2) CASE(2, 4, 2) CASE(1, 1, 1)
-#undef CASE
-  return -1;
-}
-
-int launch_edge_layer(const EdgeLayerArgs& a, int dx, int de, int ffe, hipStream_t st) {
-  dim3 g(row_blocks(a.B, a.n)), blk(256);
-#define CASE(NXB, NEB, NFB)                                                      \
-  if (dx == 32 * NXB && de == 32 * NEB && ffe == 32 * NFB) {                     \
-    hipLaunchKernelGGL((edge_layer_kernel<NXB, NEB, NFB>), g, blk, 0, st, a);    \
-    return 0;                                                                    \
-  }
-  CASE(8, 2, 4) CASE(4, 2, 4) CASE(1, 1, 2)
 #undef CASE
   return -1;
 }

@@ -45,6 +45,8 @@ struct EdgeLayerArgs {
   const float* ln1_b;
   const float* ln2_g;
   const float* ln2_b;
+  const int* rows;        // flat indices (b*n+i) of the valid query rows, built by launch_build_row_list
+  const int* row_count;   // device scalar: number of valid rows
   float inv_sqrt_df;
   int B, n;
 };
@@ -70,6 +72,7 @@ struct EdgeStatsArgs {
 
 int launch_edge_mlp_in(const EdgeMlpInArgs& a, int dE_in, int hid, int de, hipStream_t st);
 int launch_edge_layer(const EdgeLayerArgs& a, int dx, int de, int ffe, hipStream_t st);
+int launch_build_row_list(const uint8_t* mask, int M, int* rows, int* count, hipStream_t st);
 int launch_edge_mlp_out(const EdgeMlpOutArgs& a, int de, int hid, hipStream_t st);
 int launch_edge_stats(const EdgeStatsArgs& a, hipStream_t st);
 
