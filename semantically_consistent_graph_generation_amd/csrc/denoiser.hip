@@ -205,6 +205,7 @@ int build(scgg_denoiser* h, bool fill, hipStream_t st) {
 struct Workspace {
   float *Xh, *qkv, *newX, *t1, *t2, *E0, *E1, *y, *ycat, *yt1, *yt2, *film, *hidX, *hidy, *xo;
   int *rows, *row_count;
+  float* stats;
   size_t bytes;
 };
 
@@ -229,6 +230,7 @@ Workspace carve(const scgg_denoiser_config& c, int B, int n, char* base) {
   w.hidX = ar.take<float>(M * c.hid_X);
   w.hidy = ar.take<float>((size_t)B * c.hid_y);
   w.xo = ar.take<float>(M * (size_t)(c.out_X > 0 ? c.out_X : 1));
+  w.stats = ar.take<float>(M * (size_t)((n + 31) / 32) * 4 * c.de);
   w.rows = ar.take<int>(M);
   w.row_count = ar.take<int>(64);
   w.bytes = align_up(ar.off, 256);
@@ -308,8 +310,6 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       launch_copy_cols(w.y, dy, w.ycat, kcat, B, dy, st);
       NodeStatsArgs ns{w.Xh, mask, w.ycat, B, n, dx, kcat, dy};
       launch_node_stats(ns, st);
-      EdgeStatsArgs es{Ecur, mask, w.ycat, B, n, de, kcat, dy + 4 * dx};
-      if (launch_edge_stats(es, st)) return fail("edge_stats: unsupported de=%d", de);
     }
     {
       EdgeLayerArgs a;
@@ -320,6 +320,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       a.b_mul1 = L.e_mul.b; a.b_add = L.e_add.b; a.b_out = L.e_out.b; a.b_ff1 = L.ff1.b; a.b_ff2 = L.ff2.b;
       a.ln1_g = L.ln1_g; a.ln1_b = L.ln1_b; a.ln2_g = L.ln2_g; a.ln2_b = L.ln2_b;
       a.rows = w.rows; a.row_count = w.row_count;
+      a.stats_part = L.predicts_y ? w.stats : nullptr;
       a.inv_sqrt_df = 1.0f / sqrtf((float)(dx / c.n_head));
       a.B = B; a.n = n;
       const bool timed = prof_now && h->prof_used + 2 <= h->prof_ev.size();
@@ -345,6 +346,8 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     }
     // y path (transformer_model.py:239-246, :101-106)
     if (L.predicts_y) {
+      EdgeStatsArgs es{w.stats, mask, w.ycat, B, n, de, kcat, dy + 4 * dx};   // Etoy of the layer input (partials from the
+      if (launch_edge_stats_finish(es, st)) return fail("edge_stats: unsupported de=%d", de);   // layer kernel above)
       if (gemm_raw(w.ycat, kcat, L.Wycat, L.bycat, w.yt1, dy, B, dy, kcat, 0, nullptr, st)) return -1;
       if (gemm(w.yt1, dy, P_(h, sa + "y_out.0.weight", (int64_t)dy * dy), P_(h, sa + "y_out.0.bias", dy), w.yt2, dy, B, dy,
                dy, GEMM_RELU, nullptr, st)) return -1;

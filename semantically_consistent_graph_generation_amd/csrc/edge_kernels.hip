@@ -4,7 +4,6 @@
 //   (the fused layer kernel itself lives in edge_layer.hip)
 //   edge_mlp_out_kernel  mlp_out_E + residual + diagonal mask + symmetrise + mask
 //                                                        transformer_model.py:372-376, :387-389
-//   edge_stats_kernel    Etoy pooling (mean|min|max|var) layers.py:34-41
 //
 // One wave owns one query row (b, i) and walks its keys j in chunks of 32 (pair on the lane, channel in the
 // register: see mfma_chain.h).  Everything between the load of E[b,i,j,:] and the store of the layer's output
@@ -129,65 +128,6 @@ __global__ __launch_bounds__(256, 2) void edge_mlp_out_kernel(EdgeMlpOutArgs a) 
 }
 
 // =====================================================================================================
-// Etoy pooling over the symmetrised, masked hidden E (diagonal included as zeros): z[b] = [mean|min|max|var]
-// one workgroup (256 threads) per graph; thread = (channel c = tid % DE, slice s = tid / DE)
-// =====================================================================================================
-__global__ __launch_bounds__(256) void edge_stats_kernel(EdgeStatsArgs a) {
-  __shared__ float red[3][256];
-  __shared__ float s_mean[256];
-  const int b = blockIdx.x, n = a.n, DE = a.de;
-  const int tid = threadIdx.x;
-  const int c = tid % DE, s = tid / DE, S = 256 / DE;
-  const uint8_t* m = a.mask + b * n;
-  int nv = 0;
-  for (int t = 0; t < n; ++t) nv += m[t] != 0;
-  const float* E = a.E + (long long)b * n * n * DE;
-  float sum = 0.f, mn = INFINITY, mx = -INFINITY;
-  for (int pr = s; pr < n * n; pr += S) {
-    const int i = pr / n, j = pr - i * n;
-    if (!m[i] || !m[j]) continue;
-    float v = 0.f;
-    if (i != j) v = 0.5f * (E[(long long)pr * DE + c] + E[((long long)j * n + i) * DE + c]);
-    sum += v;
-    mn = fminf(mn, v);
-    mx = fmaxf(mx, v);
-  }
-  red[0][tid] = sum; red[1][tid] = mn; red[2][tid] = mx;
-  __syncthreads();
-  const float cnt = (float)nv * (float)nv;
-  if (s == 0) {
-    for (int t = 1; t < S; ++t) {
-      sum += red[0][t * DE + c];
-      mn = fminf(mn, red[1][t * DE + c]);
-      mx = fmaxf(mx, red[2][t * DE + c]);
-    }
-    const float mean = sum / cnt;
-    s_mean[c] = mean;
-    float* z = a.z + (long long)b * a.z_stride + a.z_offset;
-    z[c] = mean; z[DE + c] = mn; z[2 * DE + c] = mx;
-  }
-  __syncthreads();
-  const float mean = s_mean[c];
-  float q = 0.f;
-  for (int pr = s; pr < n * n; pr += S) {
-    const int i = pr / n, j = pr - i * n;
-    if (!m[i] || !m[j]) continue;
-    float v = 0.f;
-    if (i != j) v = 0.5f * (E[(long long)pr * DE + c] + E[((long long)j * n + i) * DE + c]);
-    const float d = v - mean;
-    q += d * d;
-  }
-  __syncthreads();
-  red[0][tid] = q;
-  __syncthreads();
-  if (s == 0) {
-    for (int t = 1; t < S; ++t) q += red[0][t * DE + c];
-    float* z = a.z + (long long)b * a.z_stride + a.z_offset;
-    z[3 * DE + c] = q / cnt;
-  }
-}
-
-// =====================================================================================================
 // launchers
 // =====================================================================================================
 static inline int row_blocks(int B, int n) { return (B * n + 3) / 4; }
@@ -215,12 +155,6 @@ int launch_edge_mlp_out(const EdgeMlpOutArgs& a, int de, int hid, hipStream_t st
   CASE(2, 4) CASE(1, 1)
 #undef CASE
   return -1;
-}
-
-int launch_edge_stats(const EdgeStatsArgs& a, hipStream_t st) {
-  if (a.de > 256 || 256 % a.de != 0) return -1;
-  hipLaunchKernelGGL(edge_stats_kernel, dim3(a.B), dim3(256), 0, st, a);
-  return 0;
 }
 
 }  // namespace scgg

@@ -198,6 +198,56 @@ __global__ __launch_bounds__(512, 2) void edge_layer_kernel(EdgeLayerArgs a) {
 #pragma unroll
       for (int rb = 0; rb < NEB; ++rb) accO[rb] = load_vec_block(a.b_out + 32 * rb, h);
 
+      // ---- Etoy pooling partials of the layer INPUT for this (row, chunk): per channel sum | min | max | M2 about
+      //      the row mean over the valid keys (the zero diagonal included, layers.py:34-40).  Same LDS transpose as the
+      //      attention sums; merged per graph by edge_stats_finish_kernel (Chan's parallel variance).
+      if (a.stats_part != nullptr && active) {
+        const unsigned vmask = (unsigned)__ballot(vj);                  // keys of this chunk, bit j (both halves agree)
+        const float cntf = (float)__popc(vmask);
+        const int c16 = lane & 15, slab = (lane >> 4) & 1, jh = lane >> 5;
+#pragma unroll
+        for (int ps = 0; ps < NEB; ++ps) {
+#pragma unroll
+          for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+              f32x4 w0;
+#pragma unroll
+              for (int t = 0; t < 4; ++t) w0[t] = e[ps][8 * hp + 4 * gg + t];
+              *reinterpret_cast<f32x4*>(scr + hp * G::SCR_KIND + p * 20 + 8 * gg + 4 * h) = w0;
+            }
+          __builtin_amdgcn_wave_barrier();
+          const float* S = scr + slab * G::SCR_KIND + (jh * 16) * 20 + c16;
+          float xs[16];
+          float sm = 0.f, mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            xs[t] = S[t * 20];
+            const bool ok = (vmask >> (jh * 16 + t)) & 1u;
+            sm += ok ? xs[t] : 0.f;
+            mn = fminf(mn, ok ? xs[t] : INFINITY);
+            mx = fmaxf(mx, ok ? xs[t] : -INFINITY);
+          }
+          __builtin_amdgcn_wave_barrier();
+          sm = other_half_sum(sm);
+          mn = -other_half_max(-mn);
+          mx = other_half_max(mx);
+          const float mean = cntf > 0.f ? sm / cntf : 0.f;
+          float m2 = 0.f;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const bool ok = (vmask >> (jh * 16 + t)) & 1u;
+            const float d = xs[t] - mean;
+            m2 += ok ? d * d : 0.f;
+          }
+          m2 = other_half_sum(m2);
+          if (lane < 32) {
+            float* dst = a.stats_part + ((long long)row * nchunks + jc) * (4 * DE) + 32 * ps + 16 * slab + c16;
+            dst[0] = sm; dst[DE] = mn; dst[2 * DE] = mx; dst[3 * DE] = m2;
+          }
+        }
+      }
+
       // ================================================================== channel-block phases
 #pragma unroll 1
       for (int cb = 0; cb < NXB; ++cb) {
@@ -374,6 +424,41 @@ __global__ __launch_bounds__(512, 2) void edge_layer_kernel(EdgeLayerArgs a) {
         a.newX_pre[(long long)row * DX + c] = film[2 * DX + c] + film[3 * DX + c] * (run[2 * DX + c] / run[DX + c]);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// merge the per-(row, chunk) partials of one graph into z[b] = [mean | min | max | biased variance] (layers.py:34-41)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void edge_stats_finish_kernel(EdgeStatsArgs a) {
+  const int b = blockIdx.x, c = threadIdx.x, n = a.n, DE = a.de;
+  if (c >= DE) return;
+  const uint8_t* m = a.mask + b * n;
+  const int nchunks = (n + 31) >> 5;
+  float N = 0.f, mean = 0.f, M2 = 0.f, mn = INFINITY, mx = -INFINITY;
+  for (int i = 0; i < n; ++i) {
+    if (!m[i]) continue;
+    for (int jc = 0; jc < nchunks; ++jc) {
+      int cnt = 0;
+      for (int j = jc * 32; j < min(n, jc * 32 + 32); ++j) cnt += m[j] != 0;
+      if (cnt == 0) continue;
+      const float* p = a.part + (((long long)b * n + i) * nchunks + jc) * (4 * DE) + c;
+      const float nb = (float)cnt, mb = p[0] / nb;
+      const float tot = N + nb, delta = mb - mean;
+      M2 += p[3 * DE] + delta * delta * (N * nb / tot);
+      mean += delta * (nb / tot);
+      N = tot;
+      mn = fminf(mn, p[DE]);
+      mx = fmaxf(mx, p[2 * DE]);
+    }
+  }
+  float* z = a.z + (long long)b * a.z_stride + a.z_offset;
+  z[c] = mean; z[DE + c] = mn; z[2 * DE + c] = mx; z[3 * DE + c] = M2 / N;
+}
+
+int launch_edge_stats_finish(const EdgeStatsArgs& a, hipStream_t st) {
+  if (a.de > 1024) return -1;
+  hipLaunchKernelGGL(edge_stats_finish_kernel, dim3(a.B), dim3((a.de + 63) / 64 * 64), 0, st, a);
+  return 0;
 }
 
 template <int NXB, int NEB, int NFB>

@@ -45,6 +45,7 @@ struct EdgeLayerArgs {
   const float* ln1_b;
   const float* ln2_g;
   const float* ln2_b;
+  float* stats_part;      // [B*n, nchunks, 4, de] Etoy partials of the layer input (or null)
   const int* rows;        // flat indices (b*n+i) of the valid query rows, built by launch_build_row_list
   const int* row_count;   // device scalar: number of valid rows
   float inv_sqrt_df;
@@ -64,7 +65,7 @@ struct EdgeMlpOutArgs {
 };
 
 struct EdgeStatsArgs {
-  const float* E;         // [B,n,n,de] unsymmetrised
+  const float* part;      // [B*n, nchunks, 4, de] per-(row, chunk) partials written by the layer kernel
   const uint8_t* mask;
   float* z;               // row b at z + b*z_stride + z_offset : [mean|min|max|var] (4*de floats)
   int B, n, de, z_stride, z_offset;
@@ -74,7 +75,7 @@ int launch_edge_mlp_in(const EdgeMlpInArgs& a, int dE_in, int hid, int de, hipSt
 int launch_edge_layer(const EdgeLayerArgs& a, int dx, int de, int ffe, hipStream_t st);
 int launch_build_row_list(const uint8_t* mask, int M, int* rows, int* count, hipStream_t st);
 int launch_edge_mlp_out(const EdgeMlpOutArgs& a, int de, int hid, hipStream_t st);
-int launch_edge_stats(const EdgeStatsArgs& a, hipStream_t st);
+int launch_edge_stats_finish(const EdgeStatsArgs& a, hipStream_t st);
 
 // ---- node / global path -------------------------------------------------------------------------
 enum GemmFlags : int { GEMM_RELU = 1, GEMM_ROWMASK = 2, GEMM_ADD_ONE_COLS = 4 };
