@@ -51,6 +51,7 @@ struct PackedLinear {   // chain-kernel operand
 struct LayerPack {
   bool predicts_y = true;
   PackedLinear e_mul, e_add, e_out, ff1, ff2;
+  PackedLinear qkv, x_out, linX1, linX2;     // node path, row-list kernel (W == nullptr: shape not supported, generic GEMM)
   float *ln1_g, *ln1_b, *ln2_g, *ln2_b;      // padded copies
   float *Wqkv, *bqkv;                        // [3dx,dx]
   float *Wfilm, *bfilm;                      // [4dx,dy]
@@ -68,6 +69,7 @@ struct scgg_denoiser {
   char* arena = nullptr;
   size_t arena_bytes = 0;
   PackedLinear in_E1, in_E2, out_E1, out_E2;
+  PackedLinear in_X2, out_X1;
   std::vector<LayerPack> layers;
   // optional live timing of the dominant kernel (edge_layer_kernel): HIP events on the launch stream
   int prof_every = 0;            // 0 = off; k = time the layer launches of every k-th forward
@@ -123,6 +125,37 @@ int pack_linear(scgg_denoiser* h, Arena& ar, bool fill, const std::string& name,
   return check_launch("pack_linear");
 }
 
+static inline bool node_kernel_ok(int K) { return K == 32 || K == 64 || K == 128 || K == 256; }
+
+// packed copy of a raw (engine-owned or borrowed) weight / bias pair for the row-list node kernel
+int pack_raw(Arena& ar, bool fill, const float* W, const float* b, int N, int K, PackedLinear& out, hipStream_t st) {
+  out = PackedLinear();
+  if (!node_kernel_ok(K)) return 0;
+  const int NB = (N + 31) / 32, KB = K / 32;
+  out.N = N;
+  out.K = K;
+  out.W = ar.take<f32x4_t>((size_t)NB * KB * 256);
+  out.b = ar.take<float>((size_t)NB * 32);
+  if (!fill) return 0;
+  PackArgs pa{W, out.W, N, K, NB, KB};
+  launch_pack_linear(pa, st);
+  launch_pad_vec(b, out.b, N, NB * 32, 0.f, st);
+  return check_launch("pack_raw");
+}
+
+int pack_named(scgg_denoiser* h, Arena& ar, bool fill, const std::string& name, int N, int K, PackedLinear& out,
+               hipStream_t st) {
+  const float *W = nullptr, *b = nullptr;
+  if (fill && node_kernel_ok(K)) {
+    const Param* w = find(h, name + ".weight", (int64_t)N * K);
+    const Param* bb = find(h, name + ".bias", N);
+    if (!w || !bb) return -1;
+    W = w->p;
+    b = bb->p;
+  }
+  return pack_raw(ar, fill, W, b, N, K, out, st);
+}
+
 int pad_vec(scgg_denoiser* h, Arena& ar, bool fill, const std::string& name, int n, float*& out, hipStream_t st) {
   out = ar.take<float>((size_t)pad32(n));
   if (!fill) return 0;
@@ -152,6 +185,8 @@ int build(scgg_denoiser* h, bool fill, hipStream_t st) {
   if (pack_linear(h, ar, fill, "mlp_in_E.3", c.de, c.hid_E, 0.f, h->in_E2, st)) return -1;
   if (pack_linear(h, ar, fill, "mlp_out_E.0", c.hid_E, c.de, 0.f, h->out_E1, st)) return -1;
   if (pack_linear(h, ar, fill, "mlp_out_E.3", c.out_E, c.hid_E, 0.f, h->out_E2, st)) return -1;
+  if (pack_named(h, ar, fill, "mlp_in_X.3", c.dx, c.hid_X, h->in_X2, st)) return -1;
+  if (pack_named(h, ar, fill, "mlp_out_X.0", c.hid_X, c.dx, h->out_X1, st)) return -1;
   h->layers.resize(c.n_layers);
   const int dx = c.dx, de = c.de, dy = c.dy;
   const int kcat = dy + 4 * dx + 4 * de;
@@ -175,11 +210,24 @@ int build(scgg_denoiser* h, bool fill, hipStream_t st) {
     L.bfilm = ar.take<float>((size_t)4 * dx);
     L.Wycat = ar.take<float>((size_t)dy * kcat);
     L.bycat = ar.take<float>((size_t)dy);
+    if (pack_named(h, ar, fill, sa + "x_out", dx, dx, L.x_out, st)) return -1;
+    if (pack_named(h, ar, fill, p + "linX1", c.dim_ffX, dx, L.linX1, st)) return -1;
+    if (pack_named(h, ar, fill, p + "linX2", dx, c.dim_ffX, L.linX2, st)) return -1;
+    {   // reserve the packed q|k|v slot in both passes; it is filled after the concatenation below
+      PackedLinear tmp;
+      if (pack_raw(ar, false, nullptr, nullptr, 3 * dx, dx, tmp, st)) return -1;
+      L.qkv = tmp;
+    }
     if (!fill) continue;
     const char* qkv[3] = {"q", "k", "v"};
     for (int t = 0; t < 3; ++t) {
       if (put_cols(h, sa + qkv[t] + ".weight", dx, dx, L.Wqkv + (size_t)t * dx * dx, dx, 0, st)) return -1;
       if (put_cols(h, sa + qkv[t] + ".bias", 1, dx, L.bqkv + (size_t)t * dx, dx, 0, st)) return -1;
+    }
+    if (L.qkv.W != nullptr) {
+      PackArgs pa{L.Wqkv, L.qkv.W, 3 * dx, dx, (3 * dx + 31) / 32, dx / 32};
+      launch_pack_linear(pa, st);
+      launch_pad_vec(L.bqkv, L.qkv.b, 3 * dx, (3 * dx + 31) / 32 * 32, 0.f, st);
     }
     const char* fl[4] = {"y_e_add", "y_e_mul", "y_x_add", "y_x_mul"};
     for (int t = 0; t < 4; ++t) {
@@ -252,6 +300,21 @@ int gemm_raw(const float* A, int lda, const float* W, const float* bias, float* 
 
 const Param* P_(scgg_denoiser* h, const std::string& name, int64_t numel) { return find(h, name, numel); }
 
+// row-list Linear on the valid rows (falls back to the generic GEMM over all rows when the shape is not packed)
+int node_lin(scgg_denoiser* h, const PackedLinear& pk, const std::string& name, const float* A, int lda, float* C, int ldc,
+             int M, int N, int K, bool relu, bool rowmask, const uint8_t* mask, const int* rows, const int* row_count,
+             hipStream_t st) {
+  if (pk.W != nullptr) {
+    const int NB = (N + 31) / 32;
+    const int rbw = NB >= 24 ? 8 : (NB >= 4 ? 2 : 1);
+    NodeLinearArgs a{A, pk.W, pk.b, C, rows, row_count, N, K, NB, lda, ldc, rbw, relu ? 1 : 0};
+    if (launch_node_linear(a, M, st)) return fail("node_linear: unsupported K=%d", K);
+    return 0;
+  }
+  return gemm(A, lda, P_(h, name + ".weight", (int64_t)N * K), P_(h, name + ".bias", N), C, ldc, M, N, K,
+              (relu ? GEMM_RELU : 0) | (rowmask ? GEMM_ROWMASK : 0), mask, st);
+}
+
 // sym + mask copy of an unsymmetrised hidden E into a caller buffer (debug tap only)
 __global__ void sym_copy_kernel(const float* E, const uint8_t* mask, float* out, int B, int n, int de) {
   const long long idx = blockIdx.x * 256ll + threadIdx.x;
@@ -283,7 +346,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   if (gemm(X, c.in_X, P_(h, "mlp_in_X.0.weight", (int64_t)c.hid_X * c.in_X), P_(h, "mlp_in_X.0.bias", c.hid_X), w.hidX,
            c.hid_X, M, c.hid_X, c.in_X, GEMM_RELU, nullptr, st)) return -1;
   if (gemm(w.hidX, c.hid_X, P_(h, "mlp_in_X.3.weight", (int64_t)dx * c.hid_X), P_(h, "mlp_in_X.3.bias", dx), w.Xh, dx, M,
-           dx, c.hid_X, GEMM_RELU | GEMM_ROWMASK, mask, st)) return -1;
+           dx, c.hid_X, GEMM_RELU | GEMM_ROWMASK, mask, st)) return -1;   // all rows: padded rows of Xh become 0 here
   if (gemm(y, c.in_y, P_(h, "mlp_in_y.0.weight", (int64_t)c.hid_y * c.in_y), P_(h, "mlp_in_y.0.bias", c.hid_y), w.hidy,
            c.hid_y, B, c.hid_y, c.in_y, GEMM_RELU, nullptr, st)) return -1;
   if (gemm(w.hidy, c.hid_y, P_(h, "mlp_in_y.3.weight", (int64_t)dy * c.hid_y), P_(h, "mlp_in_y.3.bias", dy), w.y, dy, B,
@@ -303,7 +366,11 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     const std::string p = "tf_layers." + std::to_string(l) + ".";
     const std::string sa = p + "self_attn.";
     // q|k|v masked, y-FiLM vectors (with the +1 folded in)
-    if (gemm_raw(w.Xh, dx, L.Wqkv, L.bqkv, w.qkv, 3 * dx, M, 3 * dx, dx, GEMM_ROWMASK, mask, st)) return -1;
+    if (L.qkv.W != nullptr) {
+      NodeLinearArgs qa{w.Xh, L.qkv.W, L.qkv.b, w.qkv, w.rows, w.row_count, 3 * dx, dx, (3 * dx + 31) / 32, dx, 3 * dx,
+                        dx >= 256 ? 8 : (3 * dx + 31) / 32, 0};
+      if (launch_node_linear(qa, M, st)) return fail("node_linear(qkv) rejected");
+    } else if (gemm_raw(w.Xh, dx, L.Wqkv, L.bqkv, w.qkv, 3 * dx, M, 3 * dx, dx, GEMM_ROWMASK, mask, st)) return -1;
     if (gemm_raw(w.y, dy, L.Wfilm, L.bfilm, w.film, 4 * dx, B, 4 * dx, dy, GEMM_ADD_ONE_COLS, nullptr, st, dx, 2 * dx,
                  3 * dx, 4 * dx)) return -1;
     if (L.predicts_y) {   // pooled statistics of the layer INPUT (transformer_model.py:239-243)
@@ -329,19 +396,19 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       if (timed) { (void)hipEventRecord(h->prof_ev[h->prof_used + 1], st); h->prof_used += 2; }
     }
     // X path (transformer_model.py:234-235, :88-92)
-    if (gemm(w.newX, dx, P_(h, sa + "x_out.weight", (int64_t)dx * dx), P_(h, sa + "x_out.bias", dx), w.t1, dx, M, dx, dx,
-             GEMM_ROWMASK, mask, st)) return -1;
+    if (node_lin(h, L.x_out, sa + "x_out", w.newX, dx, w.t1, dx, M, dx, dx, false, true, mask, w.rows, w.row_count, st))
+      return -1;
     {
       const Param* g1 = P_(h, p + "normX1.weight", dx); const Param* b1 = P_(h, p + "normX1.bias", dx);
       const Param* g2 = P_(h, p + "normX2.weight", dx); const Param* b2 = P_(h, p + "normX2.bias", dx);
       if (!g1 || !b1 || !g2 || !b2) return -1;
-      AddLnArgs ln1{w.Xh, w.t1, g1->p, b1->p, nullptr, w.Xh, M, dx};
+      AddLnArgs ln1{w.Xh, w.t1, g1->p, b1->p, nullptr, w.Xh, M, dx, w.rows, w.row_count};
       if (launch_add_layernorm(ln1, st)) return fail("layernorm width %d unsupported", dx);
-      if (gemm(w.Xh, dx, P_(h, p + "linX1.weight", (int64_t)c.dim_ffX * dx), P_(h, p + "linX1.bias", c.dim_ffX), w.t2,
-               c.dim_ffX, M, c.dim_ffX, dx, GEMM_RELU, nullptr, st)) return -1;
-      if (gemm(w.t2, c.dim_ffX, P_(h, p + "linX2.weight", (int64_t)dx * c.dim_ffX), P_(h, p + "linX2.bias", dx), w.t1, dx,
-               M, dx, c.dim_ffX, 0, nullptr, st)) return -1;
-      AddLnArgs ln2{w.Xh, w.t1, g2->p, b2->p, mask, w.Xh, M, dx};
+      if (node_lin(h, L.linX1, p + "linX1", w.Xh, dx, w.t2, c.dim_ffX, M, c.dim_ffX, dx, true, false, mask, w.rows,
+                   w.row_count, st)) return -1;
+      if (node_lin(h, L.linX2, p + "linX2", w.t2, c.dim_ffX, w.t1, dx, M, dx, c.dim_ffX, false, false, mask, w.rows,
+                   w.row_count, st)) return -1;
+      AddLnArgs ln2{w.Xh, w.t1, g2->p, b2->p, mask, w.Xh, M, dx, w.rows, w.row_count};
       launch_add_layernorm(ln2, st);
     }
     // y path (transformer_model.py:239-246, :101-106)
@@ -356,13 +423,13 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       const Param* g1 = P_(h, p + "norm_y1.weight", dy); const Param* b1 = P_(h, p + "norm_y1.bias", dy);
       const Param* g2 = P_(h, p + "norm_y2.weight", dy); const Param* b2 = P_(h, p + "norm_y2.bias", dy);
       if (!g1 || !b1 || !g2 || !b2) return -1;
-      AddLnArgs ln1{w.y, w.yt1, g1->p, b1->p, nullptr, w.y, B, dy};
+      AddLnArgs ln1{w.y, w.yt1, g1->p, b1->p, nullptr, w.y, B, dy, nullptr, nullptr};
       launch_add_layernorm(ln1, st);
       if (gemm(w.y, dy, P_(h, p + "lin_y1.weight", (int64_t)c.dim_ffy * dy), P_(h, p + "lin_y1.bias", c.dim_ffy), w.yt2,
                c.dim_ffy, B, c.dim_ffy, dy, GEMM_RELU, nullptr, st)) return -1;
       if (gemm(w.yt2, c.dim_ffy, P_(h, p + "lin_y2.weight", (int64_t)dy * c.dim_ffy), P_(h, p + "lin_y2.bias", dy), w.yt1,
                dy, B, dy, c.dim_ffy, 0, nullptr, st)) return -1;
-      AddLnArgs ln2{w.y, w.yt1, g2->p, b2->p, nullptr, w.y, B, dy};
+      AddLnArgs ln2{w.y, w.yt1, g2->p, b2->p, nullptr, w.y, B, dy, nullptr, nullptr};
       launch_add_layernorm(ln2, st);
     }
     float* t = Ecur; Ecur = Enext; Enext = t;

@@ -101,8 +101,21 @@ struct AddLnArgs {        // out = LN(x + r) * rowmask
   const uint8_t* rowmask; // or null
   float* out;
   int M, D;
+  const int* rows;        // optional valid-row list (then only those rows are normalised) + device count
+  const int* row_count;
 };
 int launch_add_layernorm(const AddLnArgs& a, hipStream_t st);
+
+struct NodeLinearArgs {   // row-list Linear on pre-packed weights (node path)
+  const float* A;         // [M,K] lda
+  const f32x4_t* Wp;      // packed [N x K]
+  const float* bias;      // padded to NB*32
+  float* C;               // [M,N] ldc
+  const int* rows;
+  const int* row_count;
+  int N, K, NB, lda, ldc, rbw, relu;
+};
+int launch_node_linear(const NodeLinearArgs& a, int M, hipStream_t st);
 
 struct NodeStatsArgs {    // Xtoy pooling: z[b] = [mean|min|max|var] over valid nodes
   const float* X;         // [B,n,dx]

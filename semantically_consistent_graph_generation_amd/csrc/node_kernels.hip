@@ -91,12 +91,71 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Row-list Linear for the node path: C[row, :] = epi(A[row, :] . W^T + b) for the VALID rows only.
+// One wave = 32 rows (from the valid-row list) x `rbw` 32-wide output blocks.  The 32 x K activation tile is held in
+// registers in C layout (row on the lane), the weights come pre-packed in A-fragment order (mfma_chain.h) as 1 KiB
+// coalesced loads from L2.  Rows that are not in the list are not touched (their buffers keep the zeros written by the
+// input MLP), which removes the padded third of the node work.
+// ------------------------------------------------------------------------------------------------
+template <int KB>
+__global__ __launch_bounds__(256) void node_linear_kernel(NodeLinearArgs a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+  const int count = *a.row_count;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile * 32 >= count) return;
+  const int ridx = tile * 32 + p;
+  const bool ok = ridx < count;
+  const long long row = a.rows[ok ? ridx : count - 1];
+  f32x16 x[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) x[kb] = load_vec_block(a.A + row * a.lda + 32 * kb, h);
+  const int rb0 = blockIdx.y * a.rbw;
+#pragma unroll 1
+  for (int rb = rb0; rb < rb0 + a.rbw && rb < a.NB; ++rb) {
+    f32x16 acc = load_vec_block(a.bias + 32 * rb, h);
+    linear_rb<KB>(acc, a.Wp, rb, x, lane);
+    if (a.relu) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+    }
+    if (ok) {
+      float* dst = a.C + row * a.ldc + 32 * rb;
+      if (32 * rb + 32 <= a.N) {
+        store_vec_block(dst, h, acc);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (32 * rb + ch_of(r, h) < a.N) dst[ch_of(r, h)] = acc[r];
+      }
+    }
+  }
+}
+
+int launch_node_linear(const NodeLinearArgs& a, int M, hipStream_t st) {
+  if (a.K % 32 != 0 || a.lda % 4 != 0 || a.ldc % 4 != 0) return -1;
+  dim3 g((M + 127) / 128, (a.NB + a.rbw - 1) / a.rbw), b(256);
+  switch (a.K / 32) {
+    case 1: hipLaunchKernelGGL(node_linear_kernel<1>, g, b, 0, st, a); return 0;
+    case 2: hipLaunchKernelGGL(node_linear_kernel<2>, g, b, 0, st, a); return 0;
+    case 4: hipLaunchKernelGGL(node_linear_kernel<4>, g, b, 0, st, a); return 0;
+    case 8: hipLaunchKernelGGL(node_linear_kernel<8>, g, b, 0, st, a); return 0;
+    default: return -1;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // out = LayerNorm(x + r) (eps 1e-5), optionally zeroing masked rows.  One wave per row, D <= 1024.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void add_layernorm_kernel(AddLnArgs a) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (row >= a.M) return;
+  if (a.rows != nullptr) {            // valid-row list: rows beyond the count do nothing, the others are remapped
+    if (row >= *a.row_count) return;
+    row = a.rows[row];
+  }
   const int D = a.D;
   float v[16];
   float s = 0.f;
