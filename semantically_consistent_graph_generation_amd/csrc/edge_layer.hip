@@ -429,35 +429,54 @@ __global__ __launch_bounds__(512, 2) void edge_layer_kernel(EdgeLayerArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // merge the per-(row, chunk) partials of one graph into z[b] = [mean | min | max | biased variance] (layers.py:34-41)
 // ---------------------------------------------------------------------------------------------------------
-__global__ void edge_stats_finish_kernel(EdgeStatsArgs a) {
-  const int b = blockIdx.x, c = threadIdx.x, n = a.n, DE = a.de;
-  if (c >= DE) return;
+__global__ __launch_bounds__(256) void edge_stats_finish_kernel(EdgeStatsArgs a) {
+  // thread = (channel c, row slice s); slices merge through LDS in a fixed order (Chan's formula is order dependent
+  // only in round-off, the fixed order keeps it reproducible)
+  __shared__ float sN[256], sMean[256], sM2[256], sMn[256], sMx[256];
+  const int b = blockIdx.x, n = a.n, DE = a.de, tid = threadIdx.x;
+  const int S = 256 / DE, c = tid % DE, s = tid / DE;
   const uint8_t* m = a.mask + b * n;
   const int nchunks = (n + 31) >> 5;
   float N = 0.f, mean = 0.f, M2 = 0.f, mn = INFINITY, mx = -INFINITY;
-  for (int i = 0; i < n; ++i) {
-    if (!m[i]) continue;
+  if (s < S)
     for (int jc = 0; jc < nchunks; ++jc) {
       int cnt = 0;
       for (int j = jc * 32; j < min(n, jc * 32 + 32); ++j) cnt += m[j] != 0;
       if (cnt == 0) continue;
-      const float* p = a.part + (((long long)b * n + i) * nchunks + jc) * (4 * DE) + c;
-      const float nb = (float)cnt, mb = p[0] / nb;
-      const float tot = N + nb, delta = mb - mean;
-      M2 += p[3 * DE] + delta * delta * (N * nb / tot);
+      const float nb = (float)cnt;
+      for (int i = s; i < n; i += S) {
+        if (!m[i]) continue;
+        const float* p = a.part + (((long long)b * n + i) * nchunks + jc) * (4 * DE) + c;
+        const float mb = p[0] / nb, tot = N + nb, delta = mb - mean;
+        M2 += p[3 * DE] + delta * delta * (N * nb / tot);
+        mean += delta * (nb / tot);
+        N = tot;
+        mn = fminf(mn, p[DE]);
+        mx = fmaxf(mx, p[2 * DE]);
+      }
+    }
+  sN[tid] = N; sMean[tid] = mean; sM2[tid] = M2; sMn[tid] = mn; sMx[tid] = mx;
+  __syncthreads();
+  if (s == 0) {
+    for (int t = 1; t < S; ++t) {
+      const int o = t * DE + c;
+      const float nb = sN[o];
+      if (nb == 0.f) continue;
+      const float tot = N + nb, delta = sMean[o] - mean;
+      M2 += sM2[o] + delta * delta * (N * nb / tot);
       mean += delta * (nb / tot);
       N = tot;
-      mn = fminf(mn, p[DE]);
-      mx = fmaxf(mx, p[2 * DE]);
+      mn = fminf(mn, sMn[o]);
+      mx = fmaxf(mx, sMx[o]);
     }
+    float* z = a.z + (long long)b * a.z_stride + a.z_offset;
+    z[c] = mean; z[DE + c] = mn; z[2 * DE + c] = mx; z[3 * DE + c] = M2 / N;
   }
-  float* z = a.z + (long long)b * a.z_stride + a.z_offset;
-  z[c] = mean; z[DE + c] = mn; z[2 * DE + c] = mx; z[3 * DE + c] = M2 / N;
 }
 
 int launch_edge_stats_finish(const EdgeStatsArgs& a, hipStream_t st) {
-  if (a.de > 1024) return -1;
-  hipLaunchKernelGGL(edge_stats_finish_kernel, dim3(a.B), dim3((a.de + 63) / 64 * 64), 0, st, a);
+  if (a.de > 256 || 256 % a.de != 0) return -1;
+  hipLaunchKernelGGL(edge_stats_finish_kernel, dim3(a.B), dim3(256), 0, st, a);
   return 0;
 }
 

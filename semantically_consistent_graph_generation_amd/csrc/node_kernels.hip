@@ -81,8 +81,65 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Small-M GEMM for the global-feature (y) path, M = number of graphs: the K loop is the long axis, so it is split over
+// the 16 waves of a workgroup that owns one 32(m) x 32(n) output tile; partial tiles meet in LDS and are summed in a
+// FIXED wave order (bit-reproducible, no atomics) before the bias / ReLU / +1 epilogue.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void gemm_splitk_kernel(GemmArgs a) {
+  __shared__ float part[16][32 * 33];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+  const int m_base = blockIdx.x * 32, n_base = blockIdx.y * 32;
+  const int mrow = min(m_base + p, a.M - 1), nrow = min(n_base + p, a.N - 1);
+  const int ksteps = (a.K + 7) / 8;                       // steps of 8 k
+  const int per = (ksteps + 15) / 16;
+  const int s0 = wave * per, s1 = min(ksteps, s0 + per);
+  f32x16 acc = splat16(0.f);
+  const float* Ar = a.A + (long long)mrow * a.lda;
+  const float* Wr = a.W + (long long)nrow * a.ldw;
+  for (int sb = s0; sb < s1; sb += 4) {                   // 4 steps (32 k) per trip: 8 independent loads in flight
+    f32x4 av[4], wv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k0 = (sb + u) * 8 + 4 * h;
+      const bool on = sb + u < s1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = on && k0 + e < a.K;
+        av[u][e] = ok ? Ar[k0 + e] : 0.f;
+        wv[u][e] = ok ? Wr[k0 + e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[u][e], av[u][e], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[wave][ch_of(r, h) * 33 + p] = acc[r];     // [n][m]
+  __syncthreads();
+  const int nn_l = threadIdx.x >> 5, m_l = threadIdx.x & 31;                   // 1024 threads = 32 x 32 outputs
+  float v = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) v += part[w][nn_l * 33 + m_l];
+  const int m = m_base + m_l, nn = n_base + nn_l;
+  if (m < a.M && nn < a.N) {
+    if (a.bias) v += a.bias[nn];
+    if (a.flags & GEMM_RELU) v = fmaxf(v, 0.f);
+    if (a.flags & GEMM_ADD_ONE_COLS)
+      if ((nn >= a.one_lo && nn < a.one_hi) || (nn >= a.one_lo2 && nn < a.one_hi2)) v += 1.0f;
+    const bool keep = !(a.flags & GEMM_ROWMASK) || a.rowmask[m] != 0;
+    a.C[(long long)m * a.ldc + nn] = keep ? v : 0.f;
+  }
+}
+
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0) return 0;
+  if (a.M <= 1024) {   // few rows (graphs): split K over the waves of a workgroup
+    hipLaunchKernelGGL(gemm_splitk_kernel, dim3((a.M + 31) / 32, (a.N + 31) / 32), dim3(1024), 0, st, a);
+    return 0;
+  }
   dim3 g((a.M + 127) / 128, (a.N + 127) / 128), b(256);
   const bool fast = (a.K % 8 == 0) && (a.lda % 4 == 0) && (a.ldw % 4 == 0) &&
                     ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.W)) % 16 == 0);
