@@ -68,12 +68,38 @@ __device__ __forceinline__ void mfma_block(f32x16& acc, const f32x4* __restrict_
   }
 }
 
-// ---- acc += Wp[rb][:] . x[:]  over all KB input blocks
+// ---- fragment helpers for software-pipelined MFMA chains.  hipcc otherwise schedules  load -> vmcnt(0) -> 4 MFMAs ->
+// load ...  (one fragment register quad, every MFMA group waits a full L2 / LDS round trip); loading the NEXT block's
+// four fragments before the current block's 16 MFMAs, with sched_barrier(0) pinning that order, keeps one block of
+// weights in flight behind 1024 cycles of matrix work.
+__device__ __forceinline__ void load_frag(f32x4 (&f)[4], const f32x4* __restrict__ w, int lane) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) f[g] = w[g * 64 + lane];
+}
+
+__device__ __forceinline__ void mfma16(f32x16& acc, const f32x4 (&f)[4], const f32x16& x) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f[g][e], x[4 * g + e], acc, 0, 0, 0);
+}
+
+// ---- acc += Wp[rb][:] . x[:]  over all KB input blocks (pipelined: block kb+1 is loaded under block kb's MFMAs)
 template <int KB>
 __device__ __forceinline__ void linear_rb(f32x16& acc, const f32x4* __restrict__ wp, int rb,
                                           const f32x16 (&x)[KB], int lane) {
+  const f32x4* w = wp + (rb * KB * 4) * 64;
+  f32x4 cur[4], nxt[4];
+  load_frag(cur, w, lane);
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb) mfma_block<KB>(acc, wp, rb, kb, x[kb], lane);
+  for (int kb = 0; kb < KB; ++kb) {
+    if (kb + 1 < KB) load_frag(nxt, w + (kb + 1) * 256, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma16(acc, cur, x[kb]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) cur[g] = nxt[g];
+  }
 }
 
 // ---- cross-lane helpers.  All reductions stay inside one 32-lane half (bit 5 of the lane id is never crossed).
