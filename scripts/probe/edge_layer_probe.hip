@@ -1,0 +1,86 @@
+// Development probe for the fused edge-layer kernel (not part of the library, not a test):
+// runs edge_layer_kernel<8,2,4> on synthetic CoW-shaped inputs (B graphs, n_i ~ U[12,32]), times it with HIP events
+// and, when built with -DSCGG_STAMP, prints the cycle stamps workgroup 0 recorded for its second tile.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DSCGG_STAMP] -I../../include \
+//         -I../../semantically_consistent_graph_generation_amd/csrc edge_layer_probe.hip -o edge_probe
+#include "edge_layer.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <random>
+
+namespace scgg {
+int fail(const char* fmt, ...) { fprintf(stderr, "fail: %s\n", fmt); return -1; }
+const char* last_error() { return ""; }
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <class T> T* dev(size_t n) { T* p; CK(hipMalloc(&p, n * sizeof(T))); return p; }
+static float* dev_rand(size_t n, float scale, std::mt19937& g) {
+  std::vector<float> h(n);
+  std::uniform_real_distribution<float> u(-1.f, 1.f);
+  for (auto& v : h) v = scale * u(g);
+  float* p = dev<float>(n);
+  CK(hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice));
+  return p;
+}
+
+int main(int argc, char** argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 512, n = 32, DX = 256, DE = 64, FFE = 128;
+  const int reps = argc > 2 ? atoi(argv[2]) : 10;
+  std::mt19937 g(1234);
+  std::vector<uint8_t> mask((size_t)B * n, 0);
+  long long pairs = 0; int rows_valid = 0;
+  for (int b = 0; b < B; ++b) {
+    int nb = 12 + (int)(g() % 21);
+    if (b == 0) nb = 32;
+    for (int i = 0; i < nb; ++i) mask[(size_t)b * n + i] = 1;
+    pairs += (long long)nb * nb; rows_valid += nb;
+  }
+  uint8_t* d_mask = dev<uint8_t>((size_t)B * n);
+  CK(hipMemcpy(d_mask, mask.data(), mask.size(), hipMemcpyHostToDevice));
+  scgg::EdgeLayerArgs a{};
+  a.E_in = dev_rand((size_t)B * n * n * DE, 1.f, g);
+  a.E_out = dev<float>((size_t)B * n * n * DE);
+  a.mask = d_mask;
+  float* qkv = dev_rand((size_t)B * n * 3 * DX, 1.f, g);
+  a.Q = qkv; a.K = qkv + DX; a.V = qkv + 2 * DX; a.ldqkv = 3 * DX;
+  a.film = dev_rand((size_t)B * 4 * DX, 1.f, g);
+  a.newX_pre = dev<float>((size_t)B * n * DX);
+  a.phase_img = (const scgg::f32x4_t*)dev_rand((size_t)scgg::edge_phase_img_f4(DX, DE, FFE) * 4, 0.1f, g);
+  a.b_out = dev_rand(DE, 1.f, g);
+  a.ln1_g = dev_rand(DE, 1.f, g); a.ln1_b = dev_rand(DE, 1.f, g);
+  a.ln2_g = dev_rand(DE, 1.f, g); a.ln2_b = dev_rand(DE, 1.f, g);
+  a.stats_part = dev<float>((size_t)B * n * 4 * DE);
+  int* rows = dev<int>((size_t)B * n); int* cnt = dev<int>(1);
+  a.rows = rows; a.row_count = cnt;
+  a.inv_sqrt_df = 1.f / sqrtf(32.f);
+  a.B = B; a.n = n;
+  scgg::launch_build_row_list(d_mask, B * n, rows, cnt, 0);
+  CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int w = 0; w < 3; ++w)
+    if (scgg::launch_edge_layer(a, DX, DE, FFE, 0) != 0) { fprintf(stderr, "launch failed\n"); return 1; }
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, 0));
+  for (int r = 0; r < reps; ++r) scgg::launch_edge_layer(a, DX, DE, FFE, 0);
+  CK(hipEventRecord(e1, 0));
+  CK(hipDeviceSynchronize());
+  float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  printf("B=%d rows=%d pairs=%lld  %.1f us/launch  %.1f TFLOP/s (algorithmic, valid pairs)\n", B, rows_valid, pairs,
+         ms * 1e3, pairs * 131072.0 / (ms * 1e-3) / 1e12);
+#ifdef SCGG_STAMP
+  unsigned long long st[8][96];
+  CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(scgg::g_stamps), sizeof(st)));
+  const int NP = 3 + 6 * 8 + 4 + 4;
+  const unsigned long long t0 = st[0][0];
+  for (int k = 0; k < NP; ++k) {
+    printf("%2d:", k);
+    for (int w = 0; w < 8; ++w) printf(" %8lld", (long long)(st[w][k] - t0));
+    printf("\n");
+  }
+#endif
+  return 0;
+}

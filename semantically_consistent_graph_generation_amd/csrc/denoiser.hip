@@ -51,6 +51,7 @@ struct PackedLinear {   // chain-kernel operand
 struct LayerPack {
   bool predicts_y = true;
   PackedLinear e_mul, e_add, e_out, ff1, ff2;
+  f32x4_t* phase_img = nullptr;   // edge_layer_kernel's per-phase weight images (edge_layer.hip)
   PackedLinear qkv, x_out, linX1, linX2;     // node path, row-list kernel (W == nullptr: shape not supported, generic GEMM)
   float *ln1_g, *ln1_b, *ln2_g, *ln2_b;      // padded copies
   float *Wqkv, *bqkv;                        // [3dx,dx]
@@ -200,6 +201,16 @@ int build(scgg_denoiser* h, bool fill, hipStream_t st) {
     if (pack_linear(h, ar, fill, sa + "e_out", de, dx, 0.f, L.e_out, st)) return -1;
     if (pack_linear(h, ar, fill, p + "linE1", c.dim_ffE, de, 0.f, L.ff1, st)) return -1;
     if (pack_linear(h, ar, fill, p + "linE2", de, c.dim_ffE, 0.f, L.ff2, st)) return -1;
+    {
+      const long long nimg = edge_phase_img_f4(dx, de, c.dim_ffE);
+      if (nimg < 0) return fail("edge layer kernel has no build for dx=%d de=%d dim_ffE=%d", dx, de, c.dim_ffE);
+      L.phase_img = ar.take<f32x4_t>((size_t)nimg);
+      if (fill) {
+        EdgePhasePackArgs pa{L.e_mul.W, L.e_add.W, L.e_out.W, L.ff1.W, L.ff2.W,
+                             L.e_mul.b, L.e_add.b, L.ff1.b, L.ff2.b, L.phase_img};
+        if (launch_edge_phase_pack(pa, dx, de, c.dim_ffE, st)) return fail("edge phase pack failed");
+      }
+    }
     if (pad_vec(h, ar, fill, p + "normE1.weight", de, L.ln1_g, st)) return -1;
     if (pad_vec(h, ar, fill, p + "normE1.bias", de, L.ln1_b, st)) return -1;
     if (pad_vec(h, ar, fill, p + "normE2.weight", de, L.ln2_g, st)) return -1;
@@ -383,8 +394,8 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       a.E_in = Ecur; a.E_out = Enext; a.mask = mask;
       a.Q = w.qkv; a.K = w.qkv + dx; a.V = w.qkv + 2 * dx; a.ldqkv = 3 * dx;
       a.film = w.film; a.newX_pre = w.newX;
-      a.W_mul = L.e_mul.W; a.W_add = L.e_add.W; a.W_out = L.e_out.W; a.W_ff1 = L.ff1.W; a.W_ff2 = L.ff2.W;
-      a.b_mul1 = L.e_mul.b; a.b_add = L.e_add.b; a.b_out = L.e_out.b; a.b_ff1 = L.ff1.b; a.b_ff2 = L.ff2.b;
+      a.phase_img = L.phase_img;
+      a.b_out = L.e_out.b;
       a.ln1_g = L.ln1_g; a.ln1_b = L.ln1_b; a.ln2_g = L.ln2_g; a.ln2_b = L.ln2_b;
       a.rows = w.rows; a.row_count = w.row_count;
       a.stats_part = L.predicts_y ? w.stats : nullptr;

@@ -31,16 +31,8 @@ struct EdgeLayerArgs {
   int ldqkv;              // row stride of Q/K/V (they are column slices of one [B*n, 3*dx] buffer)
   const float* film;      // [B,4*dx] = [y_e_add | y_e_mul+1 | y_x_add | y_x_mul+1]
   float* newX_pre;        // [B,n,dx] = y_x_add + (y_x_mul+1)*weighted_V   (valid rows only)
-  const f32x4_t* W_mul;   // packed [dx x de]
-  const f32x4_t* W_add;
-  const f32x4_t* W_out;   // packed [de x dx]
-  const f32x4_t* W_ff1;   // packed [ffE x de]
-  const f32x4_t* W_ff2;   // packed [de x ffE]
-  const float* b_mul1;    // e_mul.bias + 1
-  const float* b_add;
-  const float* b_out;
-  const float* b_ff1;
-  const float* b_ff2;
+  const f32x4_t* phase_img;  // per-phase weight + bias images built by launch_edge_phase_pack
+  const float* b_out;     // e_out.bias (padded)
   const float* ln1_g;
   const float* ln1_b;
   const float* ln2_g;
@@ -50,6 +42,19 @@ struct EdgeLayerArgs {
   const int* row_count;   // device scalar: number of valid rows
   float inv_sqrt_df;
   int B, n;
+};
+
+struct EdgePhasePackArgs {   // packed Linears of one layer's edge path -> phase images for edge_layer_kernel
+  const f32x4_t* W_mul;   // packed [dx x de]
+  const f32x4_t* W_add;
+  const f32x4_t* W_out;   // packed [de x dx]
+  const f32x4_t* W_ff1;   // packed [ffE x de]
+  const f32x4_t* W_ff2;   // packed [de x ffE]
+  const float* b_mul1;    // e_mul.bias + 1
+  const float* b_add;
+  const float* b_ff1;
+  const float* b_ff2;
+  f32x4_t* img;           // [edge_phase_img_f4(dx,de,ffe)]
 };
 
 struct EdgeMlpOutArgs {
@@ -73,6 +78,8 @@ struct EdgeStatsArgs {
 
 int launch_edge_mlp_in(const EdgeMlpInArgs& a, int dE_in, int hid, int de, hipStream_t st);
 int launch_edge_layer(const EdgeLayerArgs& a, int dx, int de, int ffe, hipStream_t st);
+long long edge_phase_img_f4(int dx, int de, int ffe);   // float4 count of one layer's phase images, -1 if unsupported
+int launch_edge_phase_pack(const EdgePhasePackArgs& a, int dx, int de, int ffe, hipStream_t st);
 int launch_build_row_list(const uint8_t* mask, int M, int* rows, int* count, hipStream_t st);
 int launch_edge_mlp_out(const EdgeMlpOutArgs& a, int de, int hid, hipStream_t st);
 int launch_edge_stats_finish(const EdgeStatsArgs& a, hipStream_t st);
