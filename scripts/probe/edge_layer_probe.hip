@@ -1,9 +1,9 @@
 // Development probe for the fused edge-layer kernel (not part of the library, not a test):
-// runs edge_layer_kernel<8,2,4> on synthetic CoW-shaped inputs (B graphs, n_i ~ U[12,32]), times it with HIP events
+// runs edge_unit_layer_kernel<8,2,4> on synthetic CoW-shaped inputs (B graphs, n_i ~ U[12,32]), times it with HIP events
 // and, when built with -DSCGG_STAMP, prints the cycle stamps workgroup 0 recorded for its second tile.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DSCGG_STAMP] -I../../include \
 //         -I../../semantically_consistent_graph_generation_amd/csrc edge_layer_probe.hip -o edge_probe
-#include "edge_layer.hip"
+#include "edge_unit_layer.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -47,18 +47,20 @@ int main(int argc, char** argv) {
   float* qkv = dev_rand((size_t)B * n * 3 * DX, 1.f, g);
   a.Q = qkv; a.K = qkv + DX; a.V = qkv + 2 * DX; a.ldqkv = 3 * DX;
   a.film = dev_rand((size_t)B * 4 * DX, 1.f, g);
-  a.newX_pre = dev<float>((size_t)B * n * DX);
   a.phase_img = (const scgg::f32x4_t*)dev_rand((size_t)scgg::edge_phase_img_f4(DX, DE, FFE) * 4, 0.1f, g);
   a.b_out = dev_rand(DE, 1.f, g);
   a.ln1_g = dev_rand(DE, 1.f, g); a.ln1_b = dev_rand(DE, 1.f, g);
   a.ln2_g = dev_rand(DE, 1.f, g); a.ln2_b = dev_rand(DE, 1.f, g);
-  a.stats_part = dev<float>((size_t)B * n * 4 * DE);
-  int* rows = dev<int>((size_t)B * n); int* cnt = dev<int>(1);
-  a.rows = rows; a.row_count = cnt;
+  const int nch = (n + 15) / 16;
+  a.stats_part = dev<float>((size_t)B * n * nch * 4 * DE);
+  a.attn_part = dev<float>((size_t)B * n * nch * 3 * DX);
+  int* units = dev<int>((size_t)B * n * nch); int* cnt = dev<int>(1);
+  a.units = units; a.unit_count = cnt;
   a.inv_sqrt_df = 1.f / sqrtf(32.f);
   a.B = B; a.n = n;
-  scgg::launch_build_row_list(d_mask, B * n, rows, cnt, 0);
+  scgg::launch_build_unit_list(d_mask, B * n, n, units, cnt, 0);
   CK(hipDeviceSynchronize());
+  int n_units = 0; CK(hipMemcpy(&n_units, cnt, 4, hipMemcpyDeviceToHost));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int w = 0; w < 3; ++w)
     if (scgg::launch_edge_layer(a, DX, DE, FFE, 0) != 0) { fprintf(stderr, "launch failed\n"); return 1; }
@@ -69,7 +71,7 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
   float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
   ms /= reps;
-  printf("B=%d rows=%d pairs=%lld  %.1f us/launch  %.1f TFLOP/s (algorithmic, valid pairs)\n", B, rows_valid, pairs,
+  printf("B=%d rows=%d units=%d pairs=%lld  %.1f us/launch  %.1f TFLOP/s (algorithmic, valid pairs)\n", B, rows_valid, n_units, pairs,
          ms * 1e3, pairs * 131072.0 / (ms * 1e-3) / 1e12);
 #ifdef SCGG_STAMP
   unsigned long long st[8][96];

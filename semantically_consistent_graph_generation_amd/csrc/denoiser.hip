@@ -50,8 +50,8 @@ struct PackedLinear {   // chain-kernel operand
 
 struct LayerPack {
   bool predicts_y = true;
-  PackedLinear e_mul, e_add, e_out, ff1, ff2;
-  f32x4_t* phase_img = nullptr;   // edge_layer_kernel's per-phase weight images (edge_layer.hip)
+  f32x4_t* phase_img = nullptr;   // edge_unit_layer_kernel's per-phase weight images (edge_unit_layer.hip)
+  float* b_out = nullptr;         // e_out.bias (padded copy)
   PackedLinear qkv, x_out, linX1, linX2;     // node path, row-list kernel (W == nullptr: shape not supported, generic GEMM)
   float *ln1_g, *ln1_b, *ln2_g, *ln2_b;      // padded copies
   float *Wqkv, *bqkv;                        // [3dx,dx]
@@ -196,21 +196,22 @@ int build(scgg_denoiser* h, bool fill, hipStream_t st) {
     L.predicts_y = (l != c.n_layers - 1) || c.out_y > 0;
     const std::string p = "tf_layers." + std::to_string(l) + ".";
     const std::string sa = p + "self_attn.";
-    if (pack_linear(h, ar, fill, sa + "e_mul", dx, de, 1.0f, L.e_mul, st)) return -1;   // bias + 1
-    if (pack_linear(h, ar, fill, sa + "e_add", dx, de, 0.f, L.e_add, st)) return -1;
-    if (pack_linear(h, ar, fill, sa + "e_out", de, dx, 0.f, L.e_out, st)) return -1;
-    if (pack_linear(h, ar, fill, p + "linE1", c.dim_ffE, de, 0.f, L.ff1, st)) return -1;
-    if (pack_linear(h, ar, fill, p + "linE2", de, c.dim_ffE, 0.f, L.ff2, st)) return -1;
     {
       const long long nimg = edge_phase_img_f4(dx, de, c.dim_ffE);
       if (nimg < 0) return fail("edge layer kernel has no build for dx=%d de=%d dim_ffE=%d", dx, de, c.dim_ffE);
       L.phase_img = ar.take<f32x4_t>((size_t)nimg);
       if (fill) {
-        EdgePhasePackArgs pa{L.e_mul.W, L.e_add.W, L.e_out.W, L.ff1.W, L.ff2.W,
-                             L.e_mul.b, L.e_add.b, L.ff1.b, L.ff2.b, L.phase_img};
-        if (launch_edge_phase_pack(pa, dx, de, c.dim_ffE, st)) return fail("edge phase pack failed");
+        const Param* wm = find(h, sa + "e_mul.weight", (int64_t)dx * de); const Param* bm = find(h, sa + "e_mul.bias", dx);
+        const Param* wa = find(h, sa + "e_add.weight", (int64_t)dx * de); const Param* ba = find(h, sa + "e_add.bias", dx);
+        const Param* wo = find(h, sa + "e_out.weight", (int64_t)de * dx);
+        const Param* w1 = find(h, p + "linE1.weight", (int64_t)c.dim_ffE * de); const Param* b1 = find(h, p + "linE1.bias", c.dim_ffE);
+        const Param* w2 = find(h, p + "linE2.weight", (int64_t)de * c.dim_ffE); const Param* b2 = find(h, p + "linE2.bias", de);
+        if (!wm || !bm || !wa || !ba || !wo || !w1 || !b1 || !w2 || !b2) return -1;
+        EdgeUnitPackArgs pa{wm->p, bm->p, wa->p, ba->p, wo->p, w1->p, b1->p, w2->p, b2->p, L.phase_img};
+        if (launch_edge_unit_pack(pa, dx, de, c.dim_ffE, st)) return fail("edge phase pack failed");
       }
     }
+    if (pad_vec(h, ar, fill, sa + "e_out.bias", de, L.b_out, st)) return -1;
     if (pad_vec(h, ar, fill, p + "normE1.weight", de, L.ln1_g, st)) return -1;
     if (pad_vec(h, ar, fill, p + "normE1.bias", de, L.ln1_b, st)) return -1;
     if (pad_vec(h, ar, fill, p + "normE2.weight", de, L.ln2_g, st)) return -1;
@@ -263,8 +264,8 @@ int build(scgg_denoiser* h, bool fill, hipStream_t st) {
 
 struct Workspace {
   float *Xh, *qkv, *newX, *t1, *t2, *E0, *E1, *y, *ycat, *yt1, *yt2, *film, *hidX, *hidy, *xo;
-  int *rows, *row_count;
-  float* stats;
+  int *rows, *row_count, *units, *unit_count;
+  float *stats, *attn;
   size_t bytes;
 };
 
@@ -289,9 +290,13 @@ Workspace carve(const scgg_denoiser_config& c, int B, int n, char* base) {
   w.hidX = ar.take<float>(M * c.hid_X);
   w.hidy = ar.take<float>((size_t)B * c.hid_y);
   w.xo = ar.take<float>(M * (size_t)(c.out_X > 0 ? c.out_X : 1));
-  w.stats = ar.take<float>(M * (size_t)((n + 31) / 32) * 4 * c.de);
+  const size_t nch = (size_t)(n + 15) / 16;                 // 16-key chunks per row (edge_unit_layer.hip)
+  w.stats = ar.take<float>(M * nch * 4 * c.de);
+  w.attn = ar.take<float>(M * nch * 3 * c.dx);
   w.rows = ar.take<int>(M);
   w.row_count = ar.take<int>(64);
+  w.units = ar.take<int>(M * nch);
+  w.unit_count = ar.take<int>(64);
   w.bytes = align_up(ar.off, 256);
   return w;
 }
@@ -369,6 +374,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   float* Ecur = w.E0;
   float* Enext = w.E1;
   launch_build_row_list(mask, M, w.rows, w.row_count, st);
+  if (launch_build_unit_list(mask, M, n, w.units, w.unit_count, st)) return fail("n=%d too large for the unit list (max 512)", n);
   const bool prof_now = !tap && h->prof_every > 0 && (h->prof_forwards++ % h->prof_every) == 0;
 
   // ---- layers (transformer_model.py:76-112, :165-248)
@@ -393,11 +399,11 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       EdgeLayerArgs a;
       a.E_in = Ecur; a.E_out = Enext; a.mask = mask;
       a.Q = w.qkv; a.K = w.qkv + dx; a.V = w.qkv + 2 * dx; a.ldqkv = 3 * dx;
-      a.film = w.film; a.newX_pre = w.newX;
+      a.film = w.film;
       a.phase_img = L.phase_img;
-      a.b_out = L.e_out.b;
+      a.b_out = L.b_out;
+      a.attn_part = w.attn; a.units = w.units; a.unit_count = w.unit_count;
       a.ln1_g = L.ln1_g; a.ln1_b = L.ln1_b; a.ln2_g = L.ln2_g; a.ln2_b = L.ln2_b;
-      a.rows = w.rows; a.row_count = w.row_count;
       a.stats_part = L.predicts_y ? w.stats : nullptr;
       a.inv_sqrt_df = 1.0f / sqrtf((float)(dx / c.n_head));
       a.B = B; a.n = n;
@@ -405,6 +411,8 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       if (timed) (void)hipEventRecord(h->prof_ev[h->prof_used], st);
       if (launch_edge_layer(a, dx, de, c.dim_ffE, st)) return fail("edge_layer: unsupported dims dx=%d de=%d ffE=%d (or launch setup failed)", dx, de, c.dim_ffE);
       if (timed) { (void)hipEventRecord(h->prof_ev[h->prof_used + 1], st); h->prof_used += 2; }
+      AttnFinishArgs af{w.attn, mask, w.film, w.newX, w.rows, w.row_count, n, dx};
+      launch_attn_finish(af, M, st);
     }
     // X path (transformer_model.py:234-235, :88-92)
     if (node_lin(h, L.x_out, sa + "x_out", w.newX, dx, w.t1, dx, M, dx, dx, false, true, mask, w.rows, w.row_count, st))

@@ -1,0 +1,686 @@
+// Fused XEy layer, edge part (gfx950, fp32 on v_mfma_f32_16x16x4_f32) -- persistent workgroups over 16-key units.
+//
+//   NodeEdgeBlock (E part + attention)  transformer_model.py:165-227
+//   XEyTransformerLayer E path          transformer_model.py:94-99, masks :110-112 (utils.py:154)
+//
+// Work unit = (valid query row (b,i), chunk of 16 keys holding at least one valid key).  One wave owns one unit at a
+// time: key j on lane & 15, channel group g = lane >> 4, a 16-channel block of activations is one f32x4 whose register
+// r holds channel 4g + r ("C16 layout": exactly how v_mfma_f32_16x16x4_f32 leaves its 16x16 result).  A Linear is
+// evaluated transposed, out^T = W . in^T, with W as the A operand, so register r of an input block is the B operand of
+// K-step r (channels {r, 4+r, 8+r, 12+r}) and a whole Linear -> FiLM -> Linear -> LN -> FFN chain stays in registers.
+//
+// Why 16-key units and not 32-key rows (the previous edge_layer_kernel): per-wave state halves (about 110 VGPRs), so
+// 4 waves fit a SIMD instead of 2 and the scheduler overlaps one wave's VALU / LDS / memory latency with another's
+// MFMAs; the key reductions of the attention softmax and of the Etoy pooling are 4 DPP steps inside a 16-lane row (no
+// LDS transpose, no cross-row shuffles); graphs are padded to multiples of 16 keys instead of 32.
+//
+// The layer's 256 KB of weights are cut into NPH phase images (edge_unit_pack_kernel, once per weight refresh):
+//   cb = 0..dx/32-1 : e_mul / e_add rows of channel block cb, the matching K-slice of e_out   (96 MFMAs per wave)
+//   FFN1 x ffE/64   : four row blocks of linE1                                                (64)
+//   FFN2 x de/32    : two row blocks of linE2                                                 (64)
+// copied global -> LDS by LDS-DMA into a double buffer while the previous phase computes; one __syncthreads per phase.
+//
+// Attention: per (row, channel) softmax over the keys with one wave-uniform shift M per (unit, channel block); a unit
+// writes per channel [max | sum p | sum p V] and attn_finish_kernel merges the units of a row (exact rescaling) into
+// newX_pre.  If a channel underflows against M the unit falls back to exact per-channel maxima.
+#include "mfma_chain.h"
+#include "kernels.h"
+
+namespace scgg {
+
+// ---- 16-lane row reductions (DPP only; a DPP row is exactly one channel group)
+__device__ __forceinline__ float row_sum16(float v) {
+  v += SCGG_DPP(v, 0xB1);    // quad_perm [1,0,3,2]
+  v += SCGG_DPP(v, 0x4E);    // quad_perm [2,3,0,1]
+  v += SCGG_DPP(v, 0x141);   // row_half_mirror
+  v += SCGG_DPP(v, 0x140);   // row_mirror
+  return v;
+}
+__device__ __forceinline__ float row_max16(float v) {
+  v = fmaxf(v, SCGG_DPP(v, 0xB1));
+  v = fmaxf(v, SCGG_DPP(v, 0x4E));
+  v = fmaxf(v, SCGG_DPP(v, 0x141));
+  v = fmaxf(v, SCGG_DPP(v, 0x140));
+  return v;
+}
+__device__ __forceinline__ float row_min16(float v) { return -row_max16(-v); }
+// across the four channel groups (same key): lane ^ 16 then lane ^ 32
+__device__ __forceinline__ float groups_sum(float v) {
+  v = swap_rows16_sum(v);
+  return other_half_sum(v);
+}
+__device__ __forceinline__ float groups_max(float v) {
+  v = swap_rows16_max(v);
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 splat4(float v) { f32x4 x = {v, v, v, v}; return x; }
+
+// acc += F . x : 16 output channels x 16 input channels (4 K-steps of v_mfma_f32_16x16x4_f32)
+__device__ __forceinline__ void mfma4(f32x4& acc, const f32x4& f, const f32x4& x) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f[r], x[r], acc, 0, 0, 0);
+}
+
+template <int NXB, int NEB, int NFB>
+struct UnitGeom {
+  static constexpr int DX = 32 * NXB, DE = 32 * NEB, FFE = 32 * NFB;
+  static constexpr int IBE = DE / 16, IBF = FFE / 16;      // 16-channel blocks of the E width / FFN width
+  static constexpr int W_CB = 6 * IBE * 64;                // float4s of a channel-block phase (e_mul, e_add, e_out slices)
+  static constexpr int W_F1 = 4 * IBE * 64;
+  static constexpr int W_F2 = 2 * IBF * 64;
+  static constexpr int WMAX = W_CB > W_F1 ? (W_CB > W_F2 ? W_CB : W_F2) : (W_F1 > W_F2 ? W_F1 : W_F2);
+  static constexpr int PH_F4 = WMAX + 64;                  // + bias area (16 float4 used), whole wave instructions
+  static constexpr int NPH = NXB + NFB / 2 + NEB;
+  static constexpr size_t lds_bytes(int nw) { return (size_t)2 * PH_F4 * 16 + (size_t)nw * 3 * DX * 4; }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// valid-row list: rows[k] = flat (b*n+i) of the k-th valid node, *count = number of valid rows.  One block.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void build_row_list_kernel(const uint8_t* mask, int M, int* rows, int* count) {
+  __shared__ int wsum[16];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int start = 0; start < M; start += 1024) {
+    const int idx = start + tid;
+    const bool v = idx < M && mask[idx] != 0;
+    const unsigned long long bal = __ballot(v);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (v) rows[off + before] = idx;
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; ++w) t += wsum[w];
+      base += t;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *count = base;
+}
+
+int launch_build_row_list(const uint8_t* mask, int M, int* rows, int* count, hipStream_t st) {
+  hipLaunchKernelGGL(build_row_list_kernel, dim3(1), dim3(1024), 0, st, mask, M, rows, count);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// unit list: units[k] = row * nch + jc for every valid row and every 16-key chunk of its graph with a valid key.
+// One block; rows in order, so the units of a row (and of a graph) are contiguous.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void build_unit_list_kernel(const uint8_t* mask, int M, int n, int nch, int* units,
+                                                               int* count) {
+  __shared__ int wsum[16];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int start = 0; start < M; start += 1024) {
+    const int row = start + tid;
+    unsigned bits = 0;
+    if (row < M && mask[row] != 0) {
+      const uint8_t* mb = mask + (row / n) * n;
+      for (int jc = 0; jc < nch; ++jc) {
+        bool any = false;
+        for (int j = jc * 16; j < min(n, jc * 16 + 16); ++j) any |= mb[j] != 0;
+        bits |= any ? (1u << jc) : 0u;
+      }
+    }
+    const int c = __popc(bits);
+    int incl = c;   // inclusive scan inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int off = base + incl - c;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    for (int jc = 0; jc < nch; ++jc)
+      if ((bits >> jc) & 1u) units[off++] = row * nch + jc;
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; ++w) t += wsum[w];
+      base += t;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *count = base;
+}
+
+int launch_build_unit_list(const uint8_t* mask, int M, int n, int* units, int* count, hipStream_t st) {
+  const int nch = (n + 15) / 16;
+  if (nch > 32) return -1;
+  hipLaunchKernelGGL(build_unit_list_kernel, dim3(1), dim3(1024), 0, st, mask, M, n, nch, units, count);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Phase images from the raw (torch layout) weights.  Fragment t of a phase is 64 float4: lane l holds
+// W[row0 + (l & 15)][col0 + 4 (l >> 4) + 0..3]; fragments are stored in the order the kernel consumes them:
+//   cb phase : e_mul rows 32cb+16ob (ob 0,1) x in blocks ib | same for e_add | e_out rows 16ob x cols 32cb+16ib (ib 0,1)
+//   FFN1 f   : linE1 rows 64f+16ob (ob 0..3) x ib
+//   FFN2 rb  : linE2 rows 32rb+16ob (ob 0,1) x ib
+// bias area (floats, at float4 slot WMAX): cb: (e_mul.bias+1)[32cb..] | e_add.bias[32cb..]; FFN1: linE1.bias[64f..];
+// FFN2: linE2.bias[32rb..].
+// ---------------------------------------------------------------------------------------------------------
+template <int NXB, int NEB, int NFB>
+__global__ __launch_bounds__(512) void edge_unit_pack_kernel(EdgeUnitPackArgs a) {
+  using G = UnitGeom<NXB, NEB, NFB>;
+  constexpr int DX = G::DX, DE = G::DE, FFE = G::FFE, IBE = G::IBE, IBF = G::IBF;
+  const int ph = blockIdx.x;
+  for (int idx = threadIdx.x; idx < G::PH_F4; idx += blockDim.x) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const int t = idx >> 6, l = idx & 63;
+    const float* W = nullptr;
+    int row0 = 0, col0 = 0, K = 0;
+    if (ph < NXB) {
+      const int cb = ph;
+      if (t < 4 * IBE) {
+        W = t < 2 * IBE ? a.W_mul : a.W_add;
+        row0 = 32 * cb + 16 * ((t / IBE) & 1); col0 = 16 * (t % IBE); K = DE;
+      } else if (t < 6 * IBE) {
+        const int u = t - 4 * IBE;
+        W = a.W_out; row0 = 16 * (u >> 1); col0 = 32 * cb + 16 * (u & 1); K = DX;
+      } else if (idx >= G::WMAX && idx < G::WMAX + 16) {
+        const int f = (idx - G::WMAX) * 4;   // float offset in the bias area
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = f < 32 ? a.b_mul[32 * cb + f + e] + 1.0f : a.b_add[32 * cb + f - 32 + e];
+      }
+    } else if (ph < NXB + NFB / 2) {
+      const int f = ph - NXB;
+      if (t < 4 * IBE) {
+        W = a.W_ff1; row0 = 64 * f + 16 * (t / IBE); col0 = 16 * (t % IBE); K = DE;
+      } else if (idx >= G::WMAX && idx < G::WMAX + 16) {
+        const int o = (idx - G::WMAX) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = a.b_ff1[64 * f + o + e];
+      }
+    } else {
+      const int rb = ph - NXB - NFB / 2;
+      if (t < 2 * IBF) {
+        W = a.W_ff2; row0 = 32 * rb + 16 * (t / IBF); col0 = 16 * (t % IBF); K = FFE;
+      } else if (idx >= G::WMAX && idx < G::WMAX + 8) {
+        const int o = (idx - G::WMAX) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = a.b_ff2[32 * rb + o + e];
+      }
+    }
+    if (W != nullptr) v = ld4(W + (size_t)(row0 + (l & 15)) * K + col0 + 4 * (l >> 4));
+    a.img[(size_t)ph * G::PH_F4 + idx] = v;
+  }
+}
+
+// LDS-DMA copy of one phase image into buf: wave w issues the 64-float4 pieces w, w+NW, ... (each 1 KiB, lane-linear)
+template <int PH_F4, int NW>
+__device__ __forceinline__ void stage_phase_unit(const f32x4* __restrict__ src, f32x4* buf, int wave, int lane) {
+  static_assert(PH_F4 % 64 == 0, "phase image must be whole wave instructions");
+#pragma unroll
+  for (int s = 0; s < (PH_F4 / 64 + NW - 1) / NW; ++s) {
+    const int piece = wave + NW * s;                                  // wave-uniform
+    if (piece < PH_F4 / 64)
+      __builtin_amdgcn_global_load_lds(
+          reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(src + piece * 64 + lane)),
+          (__attribute__((address_space(3))) void*)(buf + piece * 64), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void load_frags2(f32x4 (&f)[2], const f32x4* w, int lane) {
+  f[0] = w[lane];
+  f[1] = w[64 + lane];
+}
+
+// NG (even) groups of two fragments starting at W; on entry fa holds group 0, on exit fa holds the group at `after`
+// (when not null).  body(t, frag) issues the four MFMAs of fragment t.  The next group's two ds_read_b128 are issued
+// before the current group's 8 MFMAs; sched_barrier pins that order (see edge_layer history: left alone hipcc either
+// serialises read -> wait -> MFMA or hoists a phase worth of fragments and spills).
+template <int NG, class Body>
+__device__ __forceinline__ void frag_pipeline(const f32x4* W, const f32x4* after, f32x4 (&fa)[2], f32x4 (&fb)[2],
+                                              int lane, Body body) {
+  static_assert(NG % 2 == 0, "even number of fragment groups");
+#pragma unroll
+  for (int gq = 0; gq < NG; gq += 2) {
+    load_frags2(fb, W + (gq + 1) * 128, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    body(2 * gq, fa[0]);
+    body(2 * gq + 1, fa[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (gq + 2 < NG) load_frags2(fa, W + (gq + 2) * 128, lane);
+    else if (after != nullptr) load_frags2(fa, after, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    body(2 * gq + 2, fb[0]);
+    body(2 * gq + 3, fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// LayerNorm over IBE*16 channels in C16 layout (eps = 1e-5, biased variance, two-pass)
+template <int IBE>
+__device__ __forceinline__ void layernorm_c16(f32x4 (&x)[IBE], const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, int g) {
+  float s = 0.f;
+#pragma unroll
+  for (int b = 0; b < IBE; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s += x[b][r];
+  const float mean = groups_sum(s) * (1.0f / (16 * IBE));
+  float q = 0.f;
+#pragma unroll
+  for (int b = 0; b < IBE; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float d = x[b][r] - mean;
+      q += d * d;
+    }
+  const float var = groups_sum(q) * (1.0f / (16 * IBE));
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+  for (int b = 0; b < IBE; ++b) {
+    const f32x4 gm = ld4(gamma + 16 * b + 4 * g);
+    const f32x4 bt = ld4(beta + 16 * b + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[b][r] = (x[b][r] - mean) * rstd * gm[r] + bt[r];
+  }
+}
+
+template <int NXB, int NEB, int NFB, int NW>
+__global__ __launch_bounds__(NW * 64) void edge_unit_layer_kernel(EdgeLayerArgs a) {
+  using G = UnitGeom<NXB, NEB, NFB>;
+  constexpr int DX = G::DX, DE = G::DE, IBE = G::IBE, IBF = G::IBF, NPH = G::NPH;
+  static_assert(NFB % 2 == 0, "dim_ffE must be a multiple of 64");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* wbuf = reinterpret_cast<f32x4*>(smem);                        // [2][PH_F4]
+  float* fl = reinterpret_cast<float*>(wbuf + 2 * G::PH_F4);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  float* vecw = fl + wave * (3 * DX);                                  // Q row / sqrt(df) | y_e_add | y_e_mul+1
+  const int n = a.n;
+  const int nch = (n + 15) >> 4;
+  const int count = *a.unit_count;
+  const int per_iter = NW * gridDim.x;
+  const int iters = (count + per_iter - 1) / per_iter;
+  constexpr float LOG2E = 1.4426950408889634f;
+
+  stage_phase_unit<G::PH_F4, NW>(a.phase_img, wbuf, wave, lane);
+  int cur = 0;   // buffer holding the phase about to run
+
+  for (int it = 0; it < iters; ++it) {
+    const int uidx = (it * gridDim.x + blockIdx.x) * NW + wave;
+    const bool active = uidx < count;                                  // wave-uniform
+    const int u = active ? a.units[uidx] : 0;
+    const int row = u / nch, jc = u - row * nch;
+    const int b = row / n, i = row - b * n;
+    const float* film = a.film + (long long)b * (4 * DX);
+    if (active) {   // per-row vectors into this wave's LDS slice
+      for (int c = lane * 4; c < 3 * DX; c += 256) {
+        const float* src = c < DX ? a.Q + (long long)row * a.ldqkv + c : film + (c - DX);
+        f32x4 val = ld4(src);
+        if (c < DX) val = val * a.inv_sqrt_df;                         // fold 1/sqrt(df) into the query row
+        *reinterpret_cast<f32x4*>(vecw + c) = val;
+      }
+    }
+    const int j = jc * 16 + p;
+    const bool inb = j < n;
+    const int jj = inb ? j : 0;
+    const bool vj = active && inb && a.mask[b * n + jj] != 0;
+    const bool live = vj && j != i;
+    const long long off_ij = ((long long)row * n + jj) * DE;
+    const long long off_ji = (((long long)b * n + jj) * n + i) * DE;
+    const float* Kj = a.K + ((long long)b * n + jj) * a.ldqkv + 4 * g;
+    const float* Vj = a.V + ((long long)b * n + jj) * a.ldqkv + 4 * g;
+
+    // ---- symmetrised input tile (transformer_model.py:99 of the previous layer, applied on load), e_out accumulators
+    f32x4 e[IBE], accO[IBE];
+#pragma unroll
+    for (int eb = 0; eb < IBE; ++eb) {
+      if (live) {
+        const f32x4 x0 = ld4(a.E_in + off_ij + 16 * eb + 4 * g);
+        const f32x4 x1 = ld4(a.E_in + off_ji + 16 * eb + 4 * g);
+        e[eb] = 0.5f * (x0 + x1);
+      } else {
+        e[eb] = splat4(0.f);
+      }
+      accO[eb] = ld4(a.b_out + 16 * eb + 4 * g);
+    }
+
+    // ---- Etoy pooling partials of the layer INPUT for this unit: per channel sum | min | max | M2 about the unit mean
+    //      over the valid keys (the zero diagonal included, layers.py:34-40); merged by edge_stats_finish_kernel.
+    if (a.stats_part != nullptr && active) {
+      const float cntf = (float)__popc((unsigned)__ballot(vj) & 0xFFFFu);
+      const float rc = 1.0f / cntf;                                     // a unit has at least one valid key
+      float* dst = a.stats_part + ((long long)u * 4) * DE + 4 * g;
+#pragma unroll
+      for (int eb = 0; eb < IBE; ++eb) {
+        f32x4 sm, mn, mx, m2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x = e[eb][r];
+          sm[r] = row_sum16(vj ? x : 0.f);
+          mn[r] = row_min16(vj ? x : INFINITY);
+          mx[r] = row_max16(vj ? x : -INFINITY);
+          const float d = x - sm[r] * rc;
+          m2[r] = row_sum16(vj ? d * d : 0.f);
+        }
+        if (p == 0) {
+          *reinterpret_cast<f32x4*>(dst + 16 * eb) = sm;
+          *reinterpret_cast<f32x4*>(dst + DE + 16 * eb) = mn;
+          *reinterpret_cast<f32x4*>(dst + 2 * DE + 16 * eb) = mx;
+          *reinterpret_cast<f32x4*>(dst + 3 * DE + 16 * eb) = m2;
+        }
+      }
+    }
+
+    f32x4 fa[2], fb[2];                                                 // A fragments: group in use / group in flight
+    // ================================================================== channel-block phases
+#pragma unroll 1
+    for (int cb = 0; cb < NXB; ++cb) {
+      __syncthreads();
+      stage_phase_unit<G::PH_F4, NW>(a.phase_img + (size_t)(cb + 1) * G::PH_F4, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
+      const f32x4* W = wbuf + cur * G::PH_F4;
+      if (active) {
+        f32x4 k[2], vn[2], a1[2], a2[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          k[blk] = ld4(Kj + 32 * cb + 16 * blk);
+          vn[blk] = ld4(Vj + 32 * cb + 16 * blk);
+        }
+        load_frags2(fa, W, lane);
+        const float* bias = reinterpret_cast<const float*>(W + G::WMAX);
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+          a1[ob] = ld4(bias + 16 * ob + 4 * g);                         // e_mul bias + 1
+          a2[ob] = ld4(bias + 32 + 16 * ob + 4 * g);                    // e_add bias
+        }
+        frag_pipeline<2 * IBE>(W, W + 4 * IBE * 64, fa, fb, lane, [&](int t, const f32x4& f) {
+          const int ob = (t / IBE) & 1, ib = t % IBE;
+          if (t < 2 * IBE) mfma4(a1[ob], f, e[ib]);
+          else mfma4(a2[ob], f, e[ib]);
+        });
+        f32x4 y[2], v[2], z[2];
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          const int co = 32 * cb + 16 * blk + 4 * g;
+          const f32x4 q = ld4(vecw + co);                               // Q_i / sqrt(df)
+          const f32x4 yea = ld4(vecw + DX + co);
+          const f32x4 yem = ld4(vecw + 2 * DX + co);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float kk = vj ? k[blk][r] : 0.f;
+            const float yy = (q[r] * kk) * a1[blk][r] + a2[blk][r];     // Y = QK/sqrt(df) * (E1+1) + E2
+            z[blk][r] = yea[r] + yem[r] * yy;                           // FiLM by y before e_out
+            y[blk][r] = vj ? yy : -INFINITY;
+            v[blk][r] = vj ? vn[blk][r] : 0.f;
+            mloc = fmaxf(mloc, y[blk][r]);
+          }
+        }
+        // newE += W_out[:, block cb] . z
+        frag_pipeline<IBE>(W + 4 * IBE * 64, nullptr, fa, fb, lane,
+                           [&](int t, const f32x4& f) { mfma4(accO[t >> 1], f, z[t & 1]); });
+
+        // ---- attention statistics of this (unit, channel block)
+        const float M = groups_max(row_max16(mloc));                    // wave-uniform shift
+        const float nM = M == -INFINITY ? 0.f : -M * LOG2E;
+        f32x4 cm[2], cs[2], ca[2];
+        bool under = false;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pe = __builtin_amdgcn_exp2f(fmaf(y[blk][r], LOG2E, nM));   // exp(y - M); 0 on invalid keys
+            cs[blk][r] = row_sum16(pe);
+            ca[blk][r] = row_sum16(pe * v[blk][r]);
+            cm[blk][r] = M;
+            under |= cs[blk][r] == 0.f;
+          }
+        if (M > -INFINITY && __any(under)) {
+          // a channel underflowed against the block-wide shift: exact per-channel maxima
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float yy = y[blk][r];
+              const float mx = row_max16(yy);
+              const float ex = yy == -INFINITY ? 0.f : __expf(yy - mx);
+              cm[blk][r] = mx;
+              cs[blk][r] = row_sum16(ex);
+              ca[blk][r] = row_sum16(ex * v[blk][r]);
+            }
+        }
+        if (p == 0) {
+          float* dst = a.attn_part + (long long)u * (3 * DX) + 32 * cb + 4 * g;
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk) {
+            *reinterpret_cast<f32x4*>(dst + 16 * blk) = cm[blk];
+            *reinterpret_cast<f32x4*>(dst + DX + 16 * blk) = cs[blk];
+            *reinterpret_cast<f32x4*>(dst + 2 * DX + 16 * blk) = ca[blk];
+          }
+        }
+      }
+      cur ^= 1;
+    }
+
+    // ================================================================== E <- LN1(E + newE), FFN phases
+    f32x4 hid[IBF];
+#pragma unroll
+    for (int f = 0; f < NFB / 2; ++f) {
+      __syncthreads();
+      stage_phase_unit<G::PH_F4, NW>(a.phase_img + (size_t)(NXB + f + 1) * G::PH_F4, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
+      const f32x4* W = wbuf + cur * G::PH_F4;
+      if (active) {
+        load_frags2(fa, W, lane);
+        if (f == 0) {
+#pragma unroll
+          for (int eb = 0; eb < IBE; ++eb) e[eb] += accO[eb];
+          layernorm_c16<IBE>(e, a.ln1_g, a.ln1_b, g);
+        }
+        const float* bias = reinterpret_cast<const float*>(W + G::WMAX);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) hid[4 * f + ob] = ld4(bias + 16 * ob + 4 * g);
+        frag_pipeline<2 * IBE>(W, nullptr, fa, fb, lane,
+                               [&](int t, const f32x4& fr) { mfma4(hid[4 * f + t / IBE], fr, e[t % IBE]); });
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hid[4 * f + ob][r] = fmaxf(hid[4 * f + ob][r], 0.f);
+      }
+      cur ^= 1;
+    }
+#pragma unroll
+    for (int rb = 0; rb < NEB; ++rb) {
+      __syncthreads();
+      const int nxt = (NXB + NFB / 2 + rb + 1) % NPH;                   // wraps to the first phase of the next unit
+      stage_phase_unit<G::PH_F4, NW>(a.phase_img + (size_t)nxt * G::PH_F4, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
+      const f32x4* W = wbuf + cur * G::PH_F4;
+      if (active) {
+        load_frags2(fa, W, lane);
+        const float* bias = reinterpret_cast<const float*>(W + G::WMAX);
+        f32x4 f2[2];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) f2[ob] = ld4(bias + 16 * ob + 4 * g);
+        frag_pipeline<IBF>(W, nullptr, fa, fb, lane,
+                           [&](int t, const f32x4& fr) { mfma4(f2[t / IBF], fr, hid[t % IBF]); });
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) e[2 * rb + ob] += f2[ob];
+      }
+      cur ^= 1;
+    }
+    if (active) {
+      layernorm_c16<IBE>(e, a.ln2_g, a.ln2_b, g);
+      if (inb) {
+        float* dst = a.E_out + off_ij + 4 * g;
+#pragma unroll
+        for (int eb = 0; eb < IBE; ++eb) *reinterpret_cast<f32x4*>(dst + 16 * eb) = live ? e[eb] : splat4(0.f);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// newX_pre[row] = y_x_add + (y_x_mul + 1) * softmax-weighted V, merged over the row's units
+// (transformer_model.py:207-214, :230-232).  One block per valid row, one thread per channel.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_finish_kernel(AttnFinishArgs a) {
+  __shared__ unsigned cv;
+  const int ridx = blockIdx.x;
+  if (ridx >= *a.row_count) return;
+  const int row = a.rows[ridx];
+  const int n = a.n, DX = a.dx, nch = (n + 15) >> 4;
+  const int b = row / n;
+  if (threadIdx.x == 0) {
+    unsigned bits = 0;
+    for (int jc = 0; jc < nch; ++jc) {
+      bool any = false;
+      for (int j = jc * 16; j < min(n, jc * 16 + 16); ++j) any |= a.mask[b * n + j] != 0;
+      bits |= any ? (1u << jc) : 0u;
+    }
+    cv = bits;
+  }
+  __syncthreads();
+  const unsigned bits = cv;
+  const float* film = a.film + (long long)b * (4 * DX);
+  for (int c = threadIdx.x; c < DX; c += blockDim.x) {
+    float M = -INFINITY, S = 0.f, A = 0.f;
+    for (int jc = 0; jc < nch; ++jc) {
+      if (!((bits >> jc) & 1u)) continue;
+      const float* pt = a.attn_part + ((long long)row * nch + jc) * (3 * DX) + c;
+      const float m = pt[0], s = pt[DX], ac = pt[2 * DX];
+      const float mn = fmaxf(M, m);
+      const float fo = M == -INFINITY ? 0.f : __expf(M - mn);
+      const float fn = m == -INFINITY ? 0.f : __expf(m - mn);
+      S = S * fo + s * fn;
+      A = A * fo + ac * fn;
+      M = mn;
+    }
+    a.newX_pre[(long long)row * DX + c] = film[2 * DX + c] + film[3 * DX + c] * (A / S);
+  }
+}
+
+int launch_attn_finish(const AttnFinishArgs& a, int M, hipStream_t st) {
+  hipLaunchKernelGGL(attn_finish_kernel, dim3(M), dim3(256), 0, st, a);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// merge the per-unit partials of one graph into z[b] = [mean | min | max | biased variance] (layers.py:34-41)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edge_stats_finish_kernel(EdgeStatsArgs a) {
+  // thread = (channel c, row slice s); slices merge through LDS in a fixed order (Chan's formula is order dependent
+  // only in round-off, the fixed order keeps it reproducible)
+  __shared__ float sN[256], sMean[256], sM2[256], sMn[256], sMx[256];
+  const int b = blockIdx.x, n = a.n, DE = a.de, tid = threadIdx.x;
+  const int S = 256 / DE, c = tid % DE, s = tid / DE;
+  const uint8_t* m = a.mask + b * n;
+  const int nch = (n + 15) >> 4;
+  float N = 0.f, mean = 0.f, M2 = 0.f, mn = INFINITY, mx = -INFINITY;
+  if (s < S)
+    for (int jc = 0; jc < nch; ++jc) {
+      int cnt = 0;
+      for (int j = jc * 16; j < min(n, jc * 16 + 16); ++j) cnt += m[j] != 0;
+      if (cnt == 0) continue;
+      const float nb = (float)cnt;
+      for (int i = s; i < n; i += S) {
+        if (!m[i]) continue;
+        const float* p = a.part + (((long long)b * n + i) * nch + jc) * (4 * DE) + c;
+        const float mb = p[0] / nb, tot = N + nb, delta = mb - mean;
+        M2 += p[3 * DE] + delta * delta * (N * nb / tot);
+        mean += delta * (nb / tot);
+        N = tot;
+        mn = fminf(mn, p[DE]);
+        mx = fmaxf(mx, p[2 * DE]);
+      }
+    }
+  sN[tid] = N; sMean[tid] = mean; sM2[tid] = M2; sMn[tid] = mn; sMx[tid] = mx;
+  __syncthreads();
+  if (s == 0) {
+    for (int t = 1; t < S; ++t) {
+      const int o = t * DE + c;
+      const float nb = sN[o];
+      if (nb == 0.f) continue;
+      const float tot = N + nb, delta = sMean[o] - mean;
+      M2 += sM2[o] + delta * delta * (N * nb / tot);
+      mean += delta * (nb / tot);
+      N = tot;
+      mn = fminf(mn, sMn[o]);
+      mx = fmaxf(mx, sMx[o]);
+    }
+    float* z = a.z + (long long)b * a.z_stride + a.z_offset;
+    z[c] = mean; z[DE + c] = mn; z[2 * DE + c] = mx; z[3 * DE + c] = M2 / N;
+  }
+}
+
+int launch_edge_stats_finish(const EdgeStatsArgs& a, hipStream_t st) {
+  if (a.de > 256 || 256 % a.de != 0) return -1;
+  hipLaunchKernelGGL(edge_stats_finish_kernel, dim3(a.B), dim3(256), 0, st, a);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+#define SCGG_UNIT_CASES CASE(8, 2, 4) CASE(4, 2, 4) CASE(1, 1, 2)
+
+long long edge_phase_img_f4(int dx, int de, int ffe) {
+#define CASE(NXB, NEB, NFB)                                \
+  if (dx == 32 * NXB && de == 32 * NEB && ffe == 32 * NFB) \
+    return (long long)UnitGeom<NXB, NEB, NFB>::NPH * UnitGeom<NXB, NEB, NFB>::PH_F4;
+  SCGG_UNIT_CASES
+#undef CASE
+  return -1;
+}
+
+int launch_edge_unit_pack(const EdgeUnitPackArgs& a, int dx, int de, int ffe, hipStream_t st) {
+#define CASE(NXB, NEB, NFB)                                                                                        \
+  if (dx == 32 * NXB && de == 32 * NEB && ffe == 32 * NFB) {                                                       \
+    hipLaunchKernelGGL((edge_unit_pack_kernel<NXB, NEB, NFB>), dim3(UnitGeom<NXB, NEB, NFB>::NPH), dim3(512), 0, st, a); \
+    return 0;                                                                                                      \
+  }
+  SCGG_UNIT_CASES
+#undef CASE
+  return -1;
+}
+
+#ifndef SCGG_UNIT_WAVES
+#define SCGG_UNIT_WAVES 16
+#endif
+
+template <int NXB, int NEB, int NFB>
+static int launch_one(const EdgeLayerArgs& a, int n_cu, hipStream_t st) {
+  using G = UnitGeom<NXB, NEB, NFB>;
+  constexpr int NW = SCGG_UNIT_WAVES;
+  static bool attr_set = false;
+  auto kern = edge_unit_layer_kernel<NXB, NEB, NFB, NW>;
+  const size_t lds = G::lds_bytes(NW);
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
+      return -2;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(n_cu), dim3(NW * 64), lds, st, a);
+  return 0;
+}
+
+int launch_edge_layer(const EdgeLayerArgs& a, int dx, int de, int ffe, hipStream_t st) {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -2;
+    n_cu = prop.multiProcessorCount;
+  }
+#define CASE(NXB, NEB, NFB) \
+  if (dx == 32 * NXB && de == 32 * NEB && ffe == 32 * NFB) return launch_one<NXB, NEB, NFB>(a, n_cu, st);
+  SCGG_UNIT_CASES
+#undef CASE
+  return -1;
+}
+
+}  // namespace scgg

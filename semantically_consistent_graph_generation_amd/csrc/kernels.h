@@ -30,31 +30,41 @@ struct EdgeLayerArgs {
   const float* V;
   int ldqkv;              // row stride of Q/K/V (they are column slices of one [B*n, 3*dx] buffer)
   const float* film;      // [B,4*dx] = [y_e_add | y_e_mul+1 | y_x_add | y_x_mul+1]
-  float* newX_pre;        // [B,n,dx] = y_x_add + (y_x_mul+1)*weighted_V   (valid rows only)
-  const f32x4_t* phase_img;  // per-phase weight + bias images built by launch_edge_phase_pack
-  const float* b_out;     // e_out.bias (padded)
+  const f32x4_t* phase_img;  // per-phase weight + bias images built by launch_edge_unit_pack
+  const float* b_out;     // e_out.bias
   const float* ln1_g;
   const float* ln1_b;
   const float* ln2_g;
   const float* ln2_b;
-  float* stats_part;      // [B*n, nchunks, 4, de] Etoy partials of the layer input (or null)
-  const int* rows;        // flat indices (b*n+i) of the valid query rows, built by launch_build_row_list
-  const int* row_count;   // device scalar: number of valid rows
+  float* stats_part;      // [B*n*nch, 4, de] Etoy partials of the layer input per unit (or null)
+  float* attn_part;       // [B*n*nch, 3, dx] per unit and channel: softmax max | sum p | sum p V
+  const int* units;       // row * nch + jc of every unit, built by launch_build_unit_list (nch = ceil(n/16))
+  const int* unit_count;  // device scalar
   float inv_sqrt_df;
   int B, n;
 };
 
-struct EdgePhasePackArgs {   // packed Linears of one layer's edge path -> phase images for edge_layer_kernel
-  const f32x4_t* W_mul;   // packed [dx x de]
-  const f32x4_t* W_add;
-  const f32x4_t* W_out;   // packed [de x dx]
-  const f32x4_t* W_ff1;   // packed [ffE x de]
-  const f32x4_t* W_ff2;   // packed [de x ffE]
-  const float* b_mul1;    // e_mul.bias + 1
+struct EdgeUnitPackArgs {   // raw (torch layout) weights of one layer's edge path -> phase images for edge_unit_layer_kernel
+  const float* W_mul;     // [dx, de]
+  const float* b_mul;
+  const float* W_add;     // [dx, de]
   const float* b_add;
+  const float* W_out;     // [de, dx]
+  const float* W_ff1;     // [ffE, de]
   const float* b_ff1;
+  const float* W_ff2;     // [de, ffE]
   const float* b_ff2;
   f32x4_t* img;           // [edge_phase_img_f4(dx,de,ffe)]
+};
+
+struct AttnFinishArgs {   // merge the units of every valid row: newX_pre = y_x_add + (y_x_mul+1) * weighted_V
+  const float* attn_part;
+  const uint8_t* mask;
+  const float* film;      // [B, 4*dx]
+  float* newX_pre;        // [B,n,dx]
+  const int* rows;        // valid-row list + device count
+  const int* row_count;
+  int n, dx;
 };
 
 struct EdgeMlpOutArgs {
@@ -70,7 +80,7 @@ struct EdgeMlpOutArgs {
 };
 
 struct EdgeStatsArgs {
-  const float* part;      // [B*n, nchunks, 4, de] per-(row, chunk) partials written by the layer kernel
+  const float* part;      // [B*n, nch, 4, de] per-unit partials written by the layer kernel (nch = ceil(n/16))
   const uint8_t* mask;
   float* z;               // row b at z + b*z_stride + z_offset : [mean|min|max|var] (4*de floats)
   int B, n, de, z_stride, z_offset;
@@ -79,7 +89,9 @@ struct EdgeStatsArgs {
 int launch_edge_mlp_in(const EdgeMlpInArgs& a, int dE_in, int hid, int de, hipStream_t st);
 int launch_edge_layer(const EdgeLayerArgs& a, int dx, int de, int ffe, hipStream_t st);
 long long edge_phase_img_f4(int dx, int de, int ffe);   // float4 count of one layer's phase images, -1 if unsupported
-int launch_edge_phase_pack(const EdgePhasePackArgs& a, int dx, int de, int ffe, hipStream_t st);
+int launch_edge_unit_pack(const EdgeUnitPackArgs& a, int dx, int de, int ffe, hipStream_t st);
+int launch_build_unit_list(const uint8_t* mask, int M, int n, int* units, int* count, hipStream_t st);
+int launch_attn_finish(const AttnFinishArgs& a, int M, hipStream_t st);
 int launch_build_row_list(const uint8_t* mask, int M, int* rows, int* count, hipStream_t st);
 int launch_edge_mlp_out(const EdgeMlpOutArgs& a, int de, int hid, hipStream_t st);
 int launch_edge_stats_finish(const EdgeStatsArgs& a, hipStream_t st);
