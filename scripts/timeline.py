@@ -1,6 +1,6 @@
 """Print the kernel timeline of the last denoiser forward found in a rocprofv3 kernel_trace csv (development aid)."""
 import csv, glob, sys, collections
-f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
+f = (glob.glob(sys.argv[1] + '/*/*kernel_trace.csv') + glob.glob(sys.argv[1] + '/*kernel_trace.csv'))[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'edge_mlp_in' in r['Kernel_Name']]
 s, e = idx[-2] - 4, idx[-1] - 4

@@ -664,7 +664,7 @@ static int launch_one(const EdgeLayerArgs& a, int n_cu, hipStream_t st) {
       return -2;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(n_cu), dim3(NW * 64), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(n_cu * (16 / NW)), dim3(NW * 64), lds, st, a);
   return 0;
 }
 

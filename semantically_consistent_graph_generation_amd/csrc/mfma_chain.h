@@ -103,8 +103,9 @@ __device__ __forceinline__ void linear_rb(f32x16& acc, const f32x4* __restrict__
 }
 
 // ---- cross-lane helpers.  All reductions stay inside one 32-lane half (bit 5 of the lane id is never crossed).
-#define SCGG_DPP(v, ctrl) \
-  __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, false))
+// (mov_dpp: "old" operand undefined and bound_ctrl set, so no zero-initialising v_mov is emitted and the DPP combiner can
+// fold the move into its consumer; every control used here reads a valid lane, the old value is never observed)
+#define SCGG_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), (ctrl), 0xF, 0xF, true))
 
 __device__ __forceinline__ float swap_rows16_sum(float v) {
   // v_permlane16_swap: odd rows of vdst <-> even rows of src.  With vdst = src = v the two results are
