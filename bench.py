@@ -104,9 +104,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
+    from semantically_consistent_graph_generation_amd import sharding
+    rank, local_rank, world = sharding.env_rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -117,13 +116,15 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     sampler, model = build_sampler(a.T, dev)
+    # weak scaling: the job samples world * batch graphs; rank r owns the global graph ids [r*batch, (r+1)*batch)
+    shard = sharding.shard_range(world * a.batch, rank, world)
     n_nodes = node_counts(a.batch, rank)
     valid_pairs = int((n_nodes.long() ** 2).sum())
     hd = DIMS["hidden_dims"]
     flops_per_launch = valid_pairs * (6 * hd["de"] * hd["dx"] + 4 * hd["de"] * hd["dim_ffE"])
 
     def chain(k):
-        return sampler.sample_batch(n_nodes, seed=1000 + k, graph_id_base=rank * a.batch, n_max=N_MAX, return_state=True)
+        return sampler.sample_batch(n_nodes, seed=1000 + k, graph_id_base=shard.start, n_max=N_MAX, return_state=True)
 
     for k in range(a.warmup):
         chain(k)
@@ -140,11 +141,7 @@ def main():
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt)
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, device=dev)
     n_launch, ms = model.read_edge_layer_profile()
     edges = int((labels > 0).sum()) // 2
 
@@ -163,7 +160,7 @@ def main():
                        "sampled_edges_last_chain": edges},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "scgg::edge_layer_kernel<8,2,4> (fused XEy layer, edge path, fp32 MFMA)",
+                         "kernel": "scgg::edge_unit_layer_kernel<8,2,4,16> (fused XEy layer, edge path, fp32 MFMA 16x16x4)",
                          "avg_launch_ms": kernel_ms, "launches_timed": n_launch,
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "edge_stream_GBps": 2 * valid_pairs * hd["de"] * 4 / (kernel_ms * 1e-3) / 1e9 if n_launch else 0.0},

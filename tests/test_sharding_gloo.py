@@ -1,0 +1,77 @@
+"""N > 1 path on CPU: two gloo ranks shard a list of graphs, draw their Philox streams with GLOBAL graph ids, and the
+final gather reproduces the single-process result (independent graph batches, no data-path collective)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import noise as N
+from semantically_consistent_graph_generation_amd import sharding as S
+
+
+def test_shard_range_covers_every_graph_once():
+    for n_graphs in (0, 1, 7, 512, 1000):
+        for world in (1, 2, 3, 8):
+            shards = [S.shard_range(n_graphs, r, world) for r in range(world)]
+            assert shards[0].start == 0 and shards[-1].stop == n_graphs
+            for a, b in zip(shards, shards[1:]):
+                assert a.stop == b.start
+            counts = [s.count for s in shards]
+            assert max(counts) - min(counts) <= 1 and sum(counts) == n_graphs
+    with pytest.raises(ValueError):
+        S.shard_range(4, 2, 2)
+
+
+def test_single_process_helpers_are_identity():
+    assert S.max_over_ranks(1.25) == 1.25
+    x = torch.arange(6).reshape(1, 2, 3)
+    assert S.gather_labels(x, S.shard_range(1, 0, 1), 1) is x
+    assert S.env_rank_world()[2] >= 1
+
+
+def _fake_chain(graph_ids, n, seed):
+    """Stand-in for a sampled state that depends only on (seed, global graph id): the slot-0 Philox uniforms of the
+    reverse step, quantised to int8 labels."""
+    u0, _ = N.philox_edge_uniforms(seed, 3, np.asarray(graph_ids), n, 2)
+    return torch.from_numpy((u0 * 14).astype(np.int8))
+
+
+def _worker(rank, world, port, n_graphs, n, seed, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        r, _, w = S.env_rank_world()
+        n_nodes_all = torch.arange(n_graphs) % 5 + 3
+        mine, sh = S.shard_node_counts(n_nodes_all, r, w)
+        assert mine.shape[0] == sh.count
+        labels = _fake_chain(range(sh.start, sh.stop), n, seed)
+        wall = S.max_over_ranks(1.5 + rank)
+        full = S.gather_labels(labels, sh, n_graphs, dst=0)
+        if rank == 0:
+            torch.save({"full": full, "wall": wall}, out_path)
+        else:
+            assert full is None and wall == 1.5 + (world - 1)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("n_graphs", [7, 8])
+def test_two_gloo_ranks_reproduce_the_single_process_result(tmp_path, n_graphs):
+    world, n, seed = 2, 6, 99
+    out = str(tmp_path / "rank0.pt")
+    mp.spawn(_worker, args=(world, _free_port(), n_graphs, n, seed, out), nprocs=world, join=True)
+    got = torch.load(out, weights_only=True)
+    want = _fake_chain(range(n_graphs), n, seed)
+    assert got["wall"] == 1.5 + (world - 1)
+    assert got["full"].dtype == torch.int8 and torch.equal(got["full"], want)
