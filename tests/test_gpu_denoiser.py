@@ -99,3 +99,69 @@ def test_rejects_cpu_tensors_and_bad_widths():
         model(model_input(inp.X.cpu(), inp.E.cpu(), inp.y.cpu(), inp.node_mask.cpu()))
     with pytest.raises(_lib.ScggError):
         model(model_input(inp.X[..., :-1].contiguous(), inp.E, inp.y, inp.node_mask))
+
+
+def _synthetic_case(dims, n_layers, ind, od, B, n, mask, seed, tweak=None):
+    """Random weights / inputs of a given shape; returns (oracle outputs incl. hidden, model, model input)."""
+    from semantically_consistent_graph_generation_amd.transformer_model import GraphTransformer, model_input
+    torch.manual_seed(seed)
+    model = GraphTransformer(n_layers, fx.dims_ns(*ind), dims["hidden_mlp_dims"], dims["hidden_dims"], fx.dims_ns(*od)).eval()
+    if tweak is not None:
+        with torch.no_grad():
+            tweak(model)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    X = torch.randn(B, n, ind[0])
+    E = torch.randn(B, n, n, ind[1])
+    E = 0.5 * (E + E.transpose(1, 2))
+    y = torch.randn(B, ind[2])
+    dd = D.DenoiserDims(n_layers, dims["hidden_dims"]["n_head"], od[0], od[1], od[2])
+    with torch.no_grad():
+        ref, hidden = D.graph_transformer_forward(sd, dd, X, E, y, mask, return_hidden=True)
+    model = model.cuda()
+    inp = model_input(X.cuda(), E.cuda(), y.cuda(), mask.cuda())
+    return ref, hidden, model, inp
+
+
+def test_attention_underflow_takes_the_exact_per_channel_path():
+    """One attention channel sits ~300 above the others of its 32-channel block, so every other channel underflows
+    against the block-wide softmax shift and the kernel must redo the block with per-channel maxima
+    (edge_unit_layer.hip, "underflowed against the block-wide shift")."""
+    def tweak(model):
+        model.tf_layers[0].self_attn.e_add.bias[5] += 300.0
+        model.tf_layers[1].self_attn.e_add.bias[17] -= 300.0       # and one channel far BELOW the rest
+    n = 24
+    mask = fx.ragged_mask(torch.tensor([24, 9, 17, 3]), n)
+    ref, hidden, model, inp = _synthetic_case(fx.TINY_DIMS, 2, (5, 7, 4), (2, 7, 0), 4, n, mask, 11, tweak)
+    for l, (oX, oE, oy) in enumerate(hidden):
+        hX, hE, hy = model.forward_hidden(inp, l)
+        torch.cuda.synchronize()
+        assert rel_err(hX, oX) < REL, f"X after layer {l}"
+        assert rel_err(hE, oE) < REL, f"E after layer {l}"
+    out = model(inp)
+    assert rel_err(out.E, ref[2]) < REL and rel_err(out.X, ref[0]) < REL
+
+
+@pytest.mark.parametrize("dims_name,n", [("tiny", 40), ("construct", 32)])
+def test_scattered_masks_and_empty_key_chunks(dims_name, n):
+    """Masks that are not prefixes: holes, a graph whose valid nodes all sit in the last 16-key chunk (its other chunks
+    are skipped units) and a single-node graph.  (An empty graph is not a case: the reference's pooled statistics
+    divide by its zero node count and turn the whole graph NaN.)"""
+    dims = fx.TINY_DIMS if dims_name == "tiny" else fx.CONSTRUCT_DIMS
+    g = torch.Generator().manual_seed(5)
+    B = 6
+    mask = torch.rand(B, n, generator=g) < 0.6
+    mask[1] = False
+    mask[1, n - 7:] = True                       # only the last chunk holds keys
+    mask[2] = False
+    mask[2, 3] = True                            # single node: no live pair at all
+    mask[3, :2] = True
+    mask[4] = True                               # full graph
+    ref, hidden, model, inp = _synthetic_case(dims, 2, (6, 9, 5), (3, 9, 2), B, n, mask, 21)
+    for l, (oX, oE, oy) in enumerate(hidden):
+        hX, hE, hy = model.forward_hidden(inp, l)
+        torch.cuda.synchronize()
+        assert rel_err(hX, oX) < REL, f"X after layer {l}"
+        assert rel_err(hE, oE) < REL, f"E after layer {l}"
+        assert rel_err(hy, oy) < REL, f"y after layer {l}"
+    out = model(inp)
+    assert rel_err(out.E, ref[2]) < REL and rel_err(out.X, ref[0]) < REL
