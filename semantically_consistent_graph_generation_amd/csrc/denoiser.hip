@@ -77,6 +77,10 @@ struct scgg_denoiser {
   long long prof_forwards = 0;
   std::vector<hipEvent_t> prof_ev;   // pairs (start, stop), created by scgg_denoiser_profile
   size_t prof_used = 0;
+  // second stream for the global-feature (y) path, which only meets the node / edge paths at the FiLM vectors and at
+  // the pooled statistics: it runs beside the X path instead of after it (fork / join by events, capture-safe)
+  hipStream_t aux = nullptr;
+  std::vector<hipEvent_t> sync_ev;
 };
 
 namespace {
@@ -286,7 +290,8 @@ Workspace carve(const scgg_denoiser_config& c, int B, int n, char* base) {
   w.yt1 = ar.take<float>((size_t)B * c.dy);
   const int ywide = c.dim_ffy > c.hid_y ? c.dim_ffy : c.hid_y;
   w.yt2 = ar.take<float>((size_t)B * (ywide > c.dy ? ywide : c.dy));
-  w.film = ar.take<float>((size_t)B * 4 * c.dx);
+  w.film = ar.take<float>((size_t)2 * B * 4 * c.dx);        // double-buffered: layer l+1's FiLM vectors are produced
+                                                            // on the aux stream while layer l's are still read
   w.hidX = ar.take<float>(M * c.hid_X);
   w.hidy = ar.take<float>((size_t)B * c.hid_y);
   w.xo = ar.take<float>(M * (size_t)(c.out_X > 0 ? c.out_X : 1));
@@ -351,6 +356,12 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   if (!h || !h->finalized) return fail("denoiser not finalized");
   if (B <= 0 || n <= 0) return fail("bad batch shape B=%d n=%d", B, n);
   const scgg_denoiser_config& c = h->c;
+  if (h->aux == nullptr) {   // created on first use, on the device the caller has made current
+    if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess) return fail("aux stream creation failed");
+    h->sync_ev.resize((size_t)(c.n_layers + 1) * 4);
+    for (hipEvent_t& e : h->sync_ev)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail("event creation failed");
+  }
   if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) return fail("workspace must be 256-byte aligned");
   Workspace w = carve(c, B, n, static_cast<char*>(workspace));
   if (ws_bytes < w.bytes) return fail("workspace too small: %zu < %zu", ws_bytes, w.bytes);
@@ -378,28 +389,44 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   const bool prof_now = !tap && h->prof_every > 0 && (h->prof_forwards++ % h->prof_every) == 0;
 
   // ---- layers (transformer_model.py:76-112, :165-248)
+  // Streams: `st` carries q|k|v, the fused edge kernel and the X path; `ax` carries the y path (FiLM vectors, pooled
+  // statistics, y update).  Events per layer: FILM (film(l) ready), EDGE (edge kernel l done: Etoy partials ready),
+  // NS (Xtoy of the layer input read: X may be overwritten), X (X(l+1) ready).
+  hipStream_t ax = h->aux;
+  enum { EV_FILM = 0, EV_EDGE = 1, EV_NS = 2, EV_X = 3, EV_PER_LAYER = 4 };
+  auto ev = [&](int l, int k) { return h->sync_ev[(size_t)(l + 1) * EV_PER_LAYER + k]; };
+  auto signal = [&](hipEvent_t e, hipStream_t s) { return hipEventRecord(e, s) != hipSuccess; };
+  auto await = [&](hipStream_t s, hipEvent_t e) { return hipStreamWaitEvent(s, e, 0) != hipSuccess; };
+  if (signal(ev(-1, EV_X), st) || await(ax, ev(-1, EV_X))) return fail("stream fork failed");   // inputs embedded
+
   for (int l = 0; l < n_run_layers; ++l) {
     LayerPack& L = h->layers[l];
     const std::string p = "tf_layers." + std::to_string(l) + ".";
     const std::string sa = p + "self_attn.";
-    // q|k|v masked, y-FiLM vectors (with the +1 folded in)
+    float* film = w.film + (size_t)(l & 1) * B * 4 * dx;
+    // ---- aux: y-FiLM vectors (with the +1 folded in), Xtoy pooled statistics of the layer INPUT (:239-243)
+    if (gemm_raw(w.y, dy, L.Wfilm, L.bfilm, film, 4 * dx, B, 4 * dx, dy, GEMM_ADD_ONE_COLS, nullptr, ax, dx, 2 * dx,
+                 3 * dx, 4 * dx)) return -1;
+    if (signal(ev(l, EV_FILM), ax)) return fail("event record failed");
+    if (L.predicts_y) {
+      launch_copy_cols(w.y, dy, w.ycat, kcat, B, dy, ax);
+      if (l > 0 && await(ax, ev(l - 1, EV_X))) return fail("stream wait failed");
+      NodeStatsArgs ns{w.Xh, mask, w.ycat, B, n, dx, kcat, dy};
+      launch_node_stats(ns, ax);
+    }
+    if (signal(ev(l, EV_NS), ax)) return fail("event record failed");
+    // ---- main: q|k|v masked, fused edge kernel, attention finish
     if (L.qkv.W != nullptr) {
       NodeLinearArgs qa{w.Xh, L.qkv.W, L.qkv.b, w.qkv, w.rows, w.row_count, 3 * dx, dx, (3 * dx + 31) / 32, dx, 3 * dx,
                         dx >= 256 ? 8 : (3 * dx + 31) / 32, 0};
       if (launch_node_linear(qa, M, st)) return fail("node_linear(qkv) rejected");
     } else if (gemm_raw(w.Xh, dx, L.Wqkv, L.bqkv, w.qkv, 3 * dx, M, 3 * dx, dx, GEMM_ROWMASK, mask, st)) return -1;
-    if (gemm_raw(w.y, dy, L.Wfilm, L.bfilm, w.film, 4 * dx, B, 4 * dx, dy, GEMM_ADD_ONE_COLS, nullptr, st, dx, 2 * dx,
-                 3 * dx, 4 * dx)) return -1;
-    if (L.predicts_y) {   // pooled statistics of the layer INPUT (transformer_model.py:239-243)
-      launch_copy_cols(w.y, dy, w.ycat, kcat, B, dy, st);
-      NodeStatsArgs ns{w.Xh, mask, w.ycat, B, n, dx, kcat, dy};
-      launch_node_stats(ns, st);
-    }
+    if (await(st, ev(l, EV_FILM))) return fail("stream wait failed");
     {
       EdgeLayerArgs a;
       a.E_in = Ecur; a.E_out = Enext; a.mask = mask;
       a.Q = w.qkv; a.K = w.qkv + dx; a.V = w.qkv + 2 * dx; a.ldqkv = 3 * dx;
-      a.film = w.film;
+      a.film = film;
       a.phase_img = L.phase_img;
       a.b_out = L.b_out;
       a.attn_part = w.attn; a.units = w.units; a.unit_count = w.unit_count;
@@ -411,16 +438,18 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       if (timed) (void)hipEventRecord(h->prof_ev[h->prof_used], st);
       if (launch_edge_layer(a, dx, de, c.dim_ffE, st)) return fail("edge_layer: unsupported dims dx=%d de=%d ffE=%d (or launch setup failed)", dx, de, c.dim_ffE);
       if (timed) { (void)hipEventRecord(h->prof_ev[h->prof_used + 1], st); h->prof_used += 2; }
-      AttnFinishArgs af{w.attn, mask, w.film, w.newX, w.rows, w.row_count, n, dx};
+      if (signal(ev(l, EV_EDGE), st)) return fail("event record failed");
+      AttnFinishArgs af{w.attn, mask, film, w.newX, w.rows, w.row_count, n, dx};
       launch_attn_finish(af, M, st);
     }
-    // X path (transformer_model.py:234-235, :88-92)
+    // ---- main: X path (transformer_model.py:234-235, :88-92)
     if (node_lin(h, L.x_out, sa + "x_out", w.newX, dx, w.t1, dx, M, dx, dx, false, true, mask, w.rows, w.row_count, st))
       return -1;
     {
       const Param* g1 = P_(h, p + "normX1.weight", dx); const Param* b1 = P_(h, p + "normX1.bias", dx);
       const Param* g2 = P_(h, p + "normX2.weight", dx); const Param* b2 = P_(h, p + "normX2.bias", dx);
       if (!g1 || !b1 || !g2 || !b2) return -1;
+      if (await(st, ev(l, EV_NS))) return fail("stream wait failed");     // Xh is updated in place from here on
       AddLnArgs ln1{w.Xh, w.t1, g1->p, b1->p, nullptr, w.Xh, M, dx, w.rows, w.row_count};
       if (launch_add_layernorm(ln1, st)) return fail("layernorm width %d unsupported", dx);
       if (node_lin(h, L.linX1, p + "linX1", w.Xh, dx, w.t2, c.dim_ffX, M, c.dim_ffX, dx, true, false, mask, w.rows,
@@ -429,31 +458,35 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
                    w.row_count, st)) return -1;
       AddLnArgs ln2{w.Xh, w.t1, g2->p, b2->p, mask, w.Xh, M, dx, w.rows, w.row_count};
       launch_add_layernorm(ln2, st);
+      if (signal(ev(l, EV_X), st)) return fail("event record failed");
     }
-    // y path (transformer_model.py:239-246, :101-106)
+    // ---- aux: y update (transformer_model.py:239-246, :101-106)
     if (L.predicts_y) {
+      if (await(ax, ev(l, EV_EDGE))) return fail("stream wait failed");
       EdgeStatsArgs es{w.stats, mask, w.ycat, B, n, de, kcat, dy + 4 * dx};   // Etoy of the layer input (partials from the
-      if (launch_edge_stats_finish(es, st)) return fail("edge_stats: unsupported de=%d", de);   // layer kernel above)
-      if (gemm_raw(w.ycat, kcat, L.Wycat, L.bycat, w.yt1, dy, B, dy, kcat, 0, nullptr, st)) return -1;
+      if (launch_edge_stats_finish(es, ax)) return fail("edge_stats: unsupported de=%d", de);   // layer kernel above)
+      if (gemm_raw(w.ycat, kcat, L.Wycat, L.bycat, w.yt1, dy, B, dy, kcat, 0, nullptr, ax)) return -1;
       if (gemm(w.yt1, dy, P_(h, sa + "y_out.0.weight", (int64_t)dy * dy), P_(h, sa + "y_out.0.bias", dy), w.yt2, dy, B, dy,
-               dy, GEMM_RELU, nullptr, st)) return -1;
+               dy, GEMM_RELU, nullptr, ax)) return -1;
       if (gemm(w.yt2, dy, P_(h, sa + "y_out.2.weight", (int64_t)dy * dy), P_(h, sa + "y_out.2.bias", dy), w.yt1, dy, B, dy,
-               dy, 0, nullptr, st)) return -1;
+               dy, 0, nullptr, ax)) return -1;
       const Param* g1 = P_(h, p + "norm_y1.weight", dy); const Param* b1 = P_(h, p + "norm_y1.bias", dy);
       const Param* g2 = P_(h, p + "norm_y2.weight", dy); const Param* b2 = P_(h, p + "norm_y2.bias", dy);
       if (!g1 || !b1 || !g2 || !b2) return -1;
       AddLnArgs ln1{w.y, w.yt1, g1->p, b1->p, nullptr, w.y, B, dy, nullptr, nullptr};
-      launch_add_layernorm(ln1, st);
+      launch_add_layernorm(ln1, ax);
       if (gemm(w.y, dy, P_(h, p + "lin_y1.weight", (int64_t)c.dim_ffy * dy), P_(h, p + "lin_y1.bias", c.dim_ffy), w.yt2,
-               c.dim_ffy, B, c.dim_ffy, dy, GEMM_RELU, nullptr, st)) return -1;
+               c.dim_ffy, B, c.dim_ffy, dy, GEMM_RELU, nullptr, ax)) return -1;
       if (gemm(w.yt2, c.dim_ffy, P_(h, p + "lin_y2.weight", (int64_t)dy * c.dim_ffy), P_(h, p + "lin_y2.bias", dy), w.yt1,
-               dy, B, dy, c.dim_ffy, 0, nullptr, st)) return -1;
+               dy, B, dy, c.dim_ffy, 0, nullptr, ax)) return -1;
       AddLnArgs ln2{w.y, w.yt1, g2->p, b2->p, nullptr, w.y, B, dy, nullptr, nullptr};
-      launch_add_layernorm(ln2, st);
+      launch_add_layernorm(ln2, ax);
     }
     float* t = Ecur; Ecur = Enext; Enext = t;
     if (check_launch("layer")) return -1;
   }
+  // join: everything the aux stream did is ordered before what follows on the caller's stream
+  if (signal(h->sync_ev[0], ax) || await(st, h->sync_ev[0])) return fail("stream join failed");
 
   if (tap) {
     if (o1) launch_copy_cols(w.Xh, dx, o1, dx, M, dx, st);
@@ -512,6 +545,8 @@ scgg_denoiser* scgg_denoiser_create(const scgg_denoiser_config* cfg) {
 void scgg_denoiser_destroy(scgg_denoiser* h) {
   if (!h) return;
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->sync_ev) (void)hipEventDestroy(e);
+  if (h->aux) (void)hipStreamDestroy(h->aux);
   if (h->arena) (void)hipFree(h->arena);
   delete h;
 }
