@@ -1,6 +1,7 @@
 // Batched symmetric eigendecomposition of the padded graph Laplacians (n <= 32) and the spectral features built
-// from it, for gfx950.  One wave (one 64-thread workgroup) per graph; the matrix and the eigenvector matrix live
-// in LDS (2 x 32 x 33 floats); parallel-order cyclic Jacobi (16 disjoint rotations per round, 31 rounds per sweep).
+// from it, for gfx950.  One 256-thread workgroup per graph; the matrix and the eigenvector matrix live in LDS
+// (2 x 32 x 33 floats); parallel-order cyclic Jacobi over the nv valid nodes only (nv/2 disjoint rotations per round,
+// nv-1 rounds per sweep; masked and padding nodes are diagonal from the start).
 //
 // Reference: EigenFeatures.compute_features  src/ConStruct/diffusion/extra_features.py:87-112
 //   (torch.linalg.eigh :96, eigenvalues_features :138-157, eigenvector_features :159-195).
@@ -32,20 +33,35 @@ struct EigArgs {
   int B, n, num_ev, num_vec, ld_ev, off_ev, ld_vec, off_vec;
 };
 
-__global__ __launch_bounds__(64) void eigen_features_kernel(EigArgs a) {
+constexpr int ETHREADS = 256;
+
+// (p, q), p < q: the k-th pair of round r of the round-robin tournament over the nve active nodes (act[] maps to nodes)
+__device__ __forceinline__ void jacobi_pair(int r, int k, int nve, const int* act, int& p, int& q) {
+  int x, y;
+  if (k == 0) { x = r; y = nve - 1; }
+  else { x = (r + k) % (nve - 1); y = (r - k + (nve - 1)) % (nve - 1); }
+  x = act[x]; y = act[y];
+  p = x < y ? x : y;
+  q = x < y ? y : x;
+}
+
+__global__ __launch_bounds__(ETHREADS) void eigen_features_kernel(EigArgs a) {
   __shared__ float A[EN * ELD];
   __shared__ float V[EN * ELD];
   __shared__ float cs[16][2];
+  __shared__ int pq[16][2];
   __shared__ float w[EN];
   __shared__ int order[EN];      // order[r] = index of the r-th smallest eigenvalue
+  __shared__ int act[EN];        // the nodes that take part in rotations: the valid ones (+ one idle node if odd)
   __shared__ float v0[EN];
-  __shared__ int flag;
+  __shared__ float red[ETHREADS / 64];
+  __shared__ int flag, s_nve;
   const int b = blockIdx.x, n = a.n, lane = threadIdx.x;
   const uint8_t* m = a.mask + b * n;
   const float* L = a.lap + (long long)b * n * n;
 
   float fro = 0.f;
-  for (int idx = lane; idx < EN * EN; idx += 64) {
+  for (int idx = lane; idx < EN * EN; idx += ETHREADS) {
     const int i = idx >> 5, j = idx & 31;
     float v = 0.f;
     if (i < n && j < n) v = L[i * n + j];
@@ -56,19 +72,32 @@ __global__ __launch_bounds__(64) void eigen_features_kernel(EigArgs a) {
   }
 #pragma unroll
   for (int mm = 1; mm < 64; mm <<= 1) fro += __shfl_xor(fro, mm);
-  const float thresh = 2e-7f * sqrtf(fro);
+  if ((lane & 63) == 0) red[lane >> 6] = fro;
+  if (lane < 64) {
+    // masked and padding nodes are already diagonal (their rows and columns are zero off the diagonal): only the
+    // valid nodes are rotated, which cuts a sweep from 31 x 16 rotations to (nv-1) x nv/2
+    const bool valid = lane < n && m[lane] != 0;
+    const unsigned bal = (unsigned)__ballot(valid);                   // lanes 32..63 contribute 0
+    const int nv = __popc(bal);
+    if (valid) act[__popc(bal & ((1u << lane) - 1u))] = lane;
+    if (lane == 0) {
+      if (nv & 1) act[nv] = __ffs((int)~bal) - 1;                      // an idle node: its rotations are identities
+      s_nve = nv < 2 ? 0 : (nv + 1) & ~1;
+    }
+  }
   __syncthreads();
+  fro = red[0] + red[1] + red[2] + red[3];
+  const float thresh = 2e-7f * sqrtf(fro);
+  const int nve = s_nve, npairs = nve >> 1;
 
-  for (int sweep = 0; sweep < MAX_SWEEPS; ++sweep) {
+  for (int sweep = 0; sweep < MAX_SWEEPS && nve > 0; ++sweep) {
     if (lane == 0) flag = 0;
     __syncthreads();
-    for (int r = 0; r < EN - 1; ++r) {
-      // ---- rotation angles of the 16 disjoint pairs of this round
-      if (lane < 16) {
+    for (int r = 0; r < nve - 1; ++r) {
+      // ---- the disjoint pairs of this round and their rotation angles
+      if (lane < npairs) {
         int p, q;
-        if (lane == 0) { p = r; q = EN - 1; }
-        else { p = (r + lane) % (EN - 1); q = (r - lane + (EN - 1)) % (EN - 1); }
-        if (p > q) { const int t = p; p = q; q = t; }
+        jacobi_pair(r, lane, nve, act, p, q);
         const float apq = A[p * ELD + q];
         float c = 1.f, s = 0.f;
         if (fabsf(apq) > thresh) {
@@ -80,42 +109,36 @@ __global__ __launch_bounds__(64) void eigen_features_kernel(EigArgs a) {
         }
         cs[lane][0] = c;
         cs[lane][1] = s;
+        pq[lane][0] = p;
+        pq[lane][1] = q;
       }
       __syncthreads();
-      // ---- A <- A J and V <- V J : items (pair k, row i)
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int item = it * 64 + lane, k = item >> 5, i = item & 31;
-        int p, q;
-        if (k == 0) { p = r; q = EN - 1; }
-        else { p = (r + k) % (EN - 1); q = (r - k + (EN - 1)) % (EN - 1); }
-        if (p > q) { const int t = p; p = q; q = t; }
-        const float c = cs[k][0], s = cs[k][1];
-        const float aip = A[i * ELD + p], aiq = A[i * ELD + q];
-        A[i * ELD + p] = c * aip - s * aiq;
-        A[i * ELD + q] = s * aip + c * aiq;
-        const float vip = V[i * ELD + p], viq = V[i * ELD + q];
-        V[i * ELD + p] = c * vip - s * viq;
-        V[i * ELD + q] = s * vip + c * viq;
-      }
-      __syncthreads();
-      // ---- A <- J^T A : items (pair k, column j)
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int item = it * 64 + lane, k = item >> 5, j = item & 31;
-        int p, q;
-        if (k == 0) { p = r; q = EN - 1; }
-        else { p = (r + k) % (EN - 1); q = (r - k + (EN - 1)) % (EN - 1); }
-        if (p > q) { const int t = p; p = q; q = t; }
-        const float c = cs[k][0], s = cs[k][1];
-        const float apj = A[p * ELD + j], aqj = A[q * ELD + j];
-        float np_ = c * apj - s * aqj, nq_ = s * apj + c * aqj;
-        if (s != 0.f) {               // the rotated pair is annihilated exactly
-          if (j == q) np_ = 0.f;
-          if (j == p) nq_ = 0.f;
+      // ---- A <- J^T A J in one pass: item (k, l) owns the 2x2 block rows {p_k, q_k} x columns {p_l, q_l};
+      //      V <- V J: item (k, active row i).  Blocks are disjoint, so there is no barrier between the two sides.
+      const int nblk = npairs * npairs;
+      for (int item = lane; item < nblk + npairs * nve; item += ETHREADS) {
+        if (item < nblk) {
+          const int k = item / npairs, l = item - k * npairs;
+          const int pk = pq[k][0], qk = pq[k][1], pl = pq[l][0], ql = pq[l][1];
+          const float ck = cs[k][0], sk = cs[k][1], cl = cs[l][0], sl = cs[l][1];
+          const float a00 = A[pk * ELD + pl], a01 = A[pk * ELD + ql], a10 = A[qk * ELD + pl], a11 = A[qk * ELD + ql];
+          // columns first (A J), then rows (J^T .): same operation order as two separate passes
+          const float b00 = cl * a00 - sl * a01, b01 = sl * a00 + cl * a01;
+          const float b10 = cl * a10 - sl * a11, b11 = sl * a10 + cl * a11;
+          float r00 = ck * b00 - sk * b10, r01 = ck * b01 - sk * b11;
+          float r10 = sk * b00 + ck * b10, r11 = sk * b01 + ck * b11;
+          if (k == l && sk != 0.f) { r01 = 0.f; r10 = 0.f; }          // the rotated pair is annihilated exactly
+          A[pk * ELD + pl] = r00; A[pk * ELD + ql] = r01;
+          A[qk * ELD + pl] = r10; A[qk * ELD + ql] = r11;
+        } else {
+          const int it2 = item - nblk;
+          const int k = it2 / nve, i = act[it2 - k * nve];
+          const int p = pq[k][0], q = pq[k][1];
+          const float c = cs[k][0], s = cs[k][1];
+          const float vip = V[i * ELD + p], viq = V[i * ELD + q];
+          V[i * ELD + p] = c * vip - s * viq;
+          V[i * ELD + q] = s * vip + c * viq;
         }
-        A[p * ELD + j] = np_;
-        A[q * ELD + j] = nq_;
       }
       __syncthreads();
     }
@@ -123,21 +146,21 @@ __global__ __launch_bounds__(64) void eigen_features_kernel(EigArgs a) {
     __syncthreads();
   }
 
-  // ---- sort ascending (stable rank), scale, features
-  int nv = 0;
-  for (int t = 0; t < n; ++t) nv += m[t] != 0;
-  const float nvf = (float)nv;
+  // ---- sort ascending (stable rank), scale, features.  Wave 0 only from here (the mask as a bit set, no global reads
+  //      inside the loops).
+  if (lane >= 64) return;
+  const unsigned vbits = (unsigned)__ballot(lane < n && m[lane < n ? lane : 0] != 0);
+  const float nvf = (float)__popc(vbits);
   if (lane < EN) w[lane] = A[lane * ELD + lane];
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   if (lane < EN) {
     const float wi = w[lane];
     int rank = 0;
     for (int j = 0; j < EN; ++j) rank += (w[j] < wi || (w[j] == wi && j < lane)) ? 1 : 0;
     order[rank] = lane;
   }
-  __syncthreads();
-  int ncc = 0;
-  for (int r = 0; r < n; ++r) ncc += (w[order[r]] / nvf < 1e-5f) ? 1 : 0;
+  __builtin_amdgcn_wave_barrier();
+  const int ncc = __popc((unsigned)__ballot(lane < n && w[order[lane < n ? lane : 0]] / nvf < 1e-5f));
 
   if (a.w_out != nullptr && lane < n) a.w_out[b * n + lane] = w[order[lane]];
   if (a.v_out != nullptr)
@@ -155,29 +178,36 @@ __global__ __launch_bounds__(64) void eigen_features_kernel(EigArgs a) {
   }
   if (a.evec_feat != nullptr) {
     // eigvectors * mask(row) * mask(column index) (:98), first column rounded to 3 decimals (:169)
+    const bool mi = lane < n && ((vbits >> lane) & 1u);
+    float mine = 0.f;
     if (lane < EN) {
-      float v = 0.f;
-      if (lane < n && m[lane] && m[0]) v = V[lane * ELD + order[0]];
-      v0[lane] = nearbyintf(v * 1000.f) / 1000.f;
+      if (mi && (vbits & 1u)) mine = V[lane * ELD + order[0]];
+      mine = nearbyintf(mine * 1000.f) / 1000.f;
+      v0[lane] = mine;
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+    // mode over the valid nodes, ties -> smallest value: lane i counts the valid nodes that share its value, then the
+    // (count, -value) maximum is taken across the wave
+    int cnt = -1;
+    if (mi) {
+      cnt = 0;
+      for (int j = 0; j < n; ++j) cnt += (((vbits >> j) & 1u) && v0[j] == mine) ? 1 : 0;
+    }
+    int bestc = cnt;
+    float best = mi ? mine : 0.f;
+#pragma unroll
+    for (int mm = 1; mm < 64; mm <<= 1) {
+      const int oc = __shfl_xor(bestc, mm);
+      const float ov = __shfl_xor(best, mm);
+      if (oc > bestc || (oc == bestc && oc >= 0 && ov < best)) { bestc = oc; best = ov; }
+    }
     if (lane < n) {
-      // mode over the valid nodes, ties -> smallest value
-      float best = 0.f;
-      int bestc = -1;
-      for (int i = 0; i < n; ++i) {
-        if (!m[i]) continue;
-        int cnt = 0;
-        for (int j = 0; j < n; ++j) cnt += (m[j] && v0[j] == v0[i]) ? 1 : 0;
-        if (cnt > bestc || (cnt == bestc && v0[i] < best)) { bestc = cnt; best = v0[i]; }
-      }
       float* o = a.evec_feat + ((long long)b * n + lane) * a.ld_vec + a.off_vec;
-      const bool mi = m[lane] != 0;
-      o[0] = (mi && v0[lane] != best) ? 1.f : 0.f;
+      o[0] = (mi && mine != best) ? 1.f : 0.f;
       for (int k = 0; k < a.num_vec; ++k) {
         const int r = ncc + k;
         float v = 0.f;
-        if (r < n && mi && m[r]) v = V[lane * ELD + order[r]];
+        if (r < n && mi && ((vbits >> r) & 1u)) v = V[lane * ELD + order[r]];
         o[1 + k] = v;
       }
     }
@@ -201,7 +231,7 @@ extern "C" int scgg_eigen_features(const float* laplacian, const uint8_t* node_m
     return fail("eigen_features: bad destination stride");
   EigArgs a{laplacian, node_mask, eval_feat, evec_feat, w_out, v_out, B, n, num_eigenvalues, num_eigenvectors,
             ld_ev, off_ev, ld_vec, off_vec};
-  hipLaunchKernelGGL(eigen_features_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(eigen_features_kernel, dim3(B), dim3(ETHREADS), 0, static_cast<hipStream_t>(stream), a);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail("eigen_features: %s", hipGetErrorString(e));
   return 0;
