@@ -57,6 +57,7 @@ struct LayerPack {
   float *Wqkv, *bqkv;                        // [3dx,dx]
   float *Wfilm, *bfilm;                      // [4dx,dy]
   float *Wycat, *bycat;                      // [dy, dy+4dx+4de]
+  float *Wt_cat, *Wt_o0, *Wt_o2, *Wt_l1, *Wt_l2, *Wt_film;   // transposed copies for y_layer_kernel ([K][N])
 };
 
 }  // namespace scgg
@@ -226,6 +227,12 @@ int build(scgg_denoiser* h, bool fill, hipStream_t st) {
     L.bfilm = ar.take<float>((size_t)4 * dx);
     L.Wycat = ar.take<float>((size_t)dy * kcat);
     L.bycat = ar.take<float>((size_t)dy);
+    L.Wt_cat = ar.take<float>((size_t)dy * kcat);
+    L.Wt_o0 = ar.take<float>((size_t)dy * dy);
+    L.Wt_o2 = ar.take<float>((size_t)dy * dy);
+    L.Wt_l1 = ar.take<float>((size_t)dy * c.dim_ffy);
+    L.Wt_l2 = ar.take<float>((size_t)dy * c.dim_ffy);
+    L.Wt_film = ar.take<float>((size_t)4 * dx * dy);
     if (pack_named(h, ar, fill, sa + "x_out", dx, dx, L.x_out, st)) return -1;
     if (pack_named(h, ar, fill, p + "linX1", c.dim_ffX, dx, L.linX1, st)) return -1;
     if (pack_named(h, ar, fill, p + "linX2", dx, c.dim_ffX, L.linX2, st)) return -1;
@@ -259,6 +266,19 @@ int build(scgg_denoiser* h, bool fill, hipStream_t st) {
       const Param* b2 = find(h, sa + "e_y.lin.bias", dy);
       if (!b0 || !b1 || !b2) return -1;
       hipLaunchKernelGGL(vec_sum3_kernel, dim3((dy + 255) / 256), dim3(256), 0, st, b0->p, b1->p, b2->p, L.bycat, dy);
+    }
+    launch_transpose(L.Wfilm, L.Wt_film, 4 * dx, dy, st);
+    if (L.predicts_y) {
+      const Param* o0 = find(h, sa + "y_out.0.weight", (int64_t)dy * dy);
+      const Param* o2 = find(h, sa + "y_out.2.weight", (int64_t)dy * dy);
+      const Param* l1 = find(h, p + "lin_y1.weight", (int64_t)c.dim_ffy * dy);
+      const Param* l2 = find(h, p + "lin_y2.weight", (int64_t)dy * c.dim_ffy);
+      if (!o0 || !o2 || !l1 || !l2) return -1;
+      launch_transpose(L.Wycat, L.Wt_cat, dy, kcat, st);
+      launch_transpose(o0->p, L.Wt_o0, dy, dy, st);
+      launch_transpose(o2->p, L.Wt_o2, dy, dy, st);
+      launch_transpose(l1->p, L.Wt_l1, c.dim_ffy, dy, st);
+      launch_transpose(l2->p, L.Wt_l2, dy, c.dim_ffy, st);
     }
     if (check_launch("concat weights")) return -1;
   }
@@ -357,7 +377,10 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   if (B <= 0 || n <= 0) return fail("bad batch shape B=%d n=%d", B, n);
   const scgg_denoiser_config& c = h->c;
   if (h->aux == nullptr) {   // created on first use, on the device the caller has made current
-    if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess) return fail("aux stream creation failed");
+    int prio_lo = 0, prio_hi = 0;   // the y kernels are short and feed the next edge launch: let them jump the queue
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, prio_hi) != hipSuccess)
+      return fail("aux stream creation failed");
     h->sync_ev.resize((size_t)(c.n_layers + 1) * 4);
     for (hipEvent_t& e : h->sync_ev)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail("event creation failed");
@@ -390,8 +413,9 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
 
   // ---- layers (transformer_model.py:76-112, :165-248)
   // Streams: `st` carries q|k|v, the fused edge kernel and the X path; `ax` carries the y path (FiLM vectors, pooled
-  // statistics, y update).  Events per layer: FILM (film(l) ready), EDGE (edge kernel l done: Etoy partials ready),
-  // NS (Xtoy of the layer input read: X may be overwritten), X (X(l+1) ready).
+  // statistics, y update, the next layer's FiLM vectors), which runs beside the node kernel.  Events per layer: FILM
+  // (film(l) ready), EDGE (edge kernel l done: Etoy partials ready), NS (Xtoy of X(l) taken: X may be overwritten),
+  // X (X(l+1) ready).
   hipStream_t ax = h->aux;
   enum { EV_FILM = 0, EV_EDGE = 1, EV_NS = 2, EV_X = 3, EV_PER_LAYER = 4 };
   auto ev = [&](int l, int k) { return h->sync_ev[(size_t)(l + 1) * EV_PER_LAYER + k]; };
@@ -405,18 +429,30 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     const std::string sa = p + "self_attn.";
     float* film = w.film + (size_t)(l & 1) * B * 4 * dx;
     // ---- aux: y-FiLM vectors (with the +1 folded in), Xtoy pooled statistics of the layer INPUT (:239-243)
-    if (gemm_raw(w.y, dy, L.Wfilm, L.bfilm, film, 4 * dx, B, 4 * dx, dy, GEMM_ADD_ONE_COLS, nullptr, ax, dx, 2 * dx,
-                 3 * dx, 4 * dx)) return -1;
-    if (signal(ev(l, EV_FILM), ax)) return fail("event record failed");
+    const bool fused_y = y_layer_supported(dy, c.dim_ffy, kcat);
+    if (!fused_y || l == 0) {   // (fused: layer l's vectors were produced by layer l-1's y kernel)
+      if (fused_y) {
+        YLayerArgs ya{};
+        ya.y = w.y; ya.Wt_film = L.Wt_film; ya.b_film = L.bfilm; ya.film = film;
+        ya.B = B; ya.dy = dy; ya.ffy = c.dim_ffy; ya.kcat = kcat; ya.dx = dx; ya.update = 0;
+        if (launch_y_layer(ya, ax)) return fail("y_layer launch failed");
+      } else if (gemm_raw(w.y, dy, L.Wfilm, L.bfilm, film, 4 * dx, B, 4 * dx, dy, GEMM_ADD_ONE_COLS, nullptr, ax, dx,
+                          2 * dx, 3 * dx, 4 * dx)) return -1;
+      if (signal(ev(l, EV_FILM), ax)) return fail("event record failed");
+    }
     if (L.predicts_y) {
-      launch_copy_cols(w.y, dy, w.ycat, kcat, B, dy, ax);
+      if (!fused_y) launch_copy_cols(w.y, dy, w.ycat, kcat, B, dy, ax);
       if (l > 0 && await(ax, ev(l - 1, EV_X))) return fail("stream wait failed");
       NodeStatsArgs ns{w.Xh, mask, w.ycat, B, n, dx, kcat, dy};
       launch_node_stats(ns, ax);
     }
     if (signal(ev(l, EV_NS), ax)) return fail("event record failed");
-    // ---- main: q|k|v masked, fused edge kernel, attention finish
-    if (L.qkv.W != nullptr) {
+
+    // ---- main: q|k|v masked (layer 0, or every layer on the unfused path), fused edge kernel
+    const bool fused_node = node_layer_supported(dx, c.dim_ffX) && L.x_out.W && L.linX1.W && L.linX2.W && L.qkv.W;
+    if (fused_node && l > 0) {
+      // q|k|v of this layer were produced by the previous layer's node kernel
+    } else if (L.qkv.W != nullptr) {
       NodeLinearArgs qa{w.Xh, L.qkv.W, L.qkv.b, w.qkv, w.rows, w.row_count, 3 * dx, dx, (3 * dx + 31) / 32, dx, 3 * dx,
                         dx >= 256 ? 8 : (3 * dx + 31) / 32, 0};
       if (launch_node_linear(qa, M, st)) return fail("node_linear(qkv) rejected");
@@ -439,29 +475,64 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       if (launch_edge_layer(a, dx, de, c.dim_ffE, st)) return fail("edge_layer: unsupported dims dx=%d de=%d ffE=%d (or launch setup failed)", dx, de, c.dim_ffE);
       if (timed) { (void)hipEventRecord(h->prof_ev[h->prof_used + 1], st); h->prof_used += 2; }
       if (signal(ev(l, EV_EDGE), st)) return fail("event record failed");
-      AttnFinishArgs af{w.attn, mask, film, w.newX, w.rows, w.row_count, n, dx};
-      launch_attn_finish(af, M, st);
+      if (!fused_node) {
+        AttnFinishArgs af{w.attn, mask, film, w.newX, w.rows, w.row_count, n, dx};
+        launch_attn_finish(af, M, st);
+      }
     }
     // ---- main: X path (transformer_model.py:234-235, :88-92)
-    if (node_lin(h, L.x_out, sa + "x_out", w.newX, dx, w.t1, dx, M, dx, dx, false, true, mask, w.rows, w.row_count, st))
-      return -1;
     {
       const Param* g1 = P_(h, p + "normX1.weight", dx); const Param* b1 = P_(h, p + "normX1.bias", dx);
       const Param* g2 = P_(h, p + "normX2.weight", dx); const Param* b2 = P_(h, p + "normX2.bias", dx);
       if (!g1 || !b1 || !g2 || !b2) return -1;
       if (await(st, ev(l, EV_NS))) return fail("stream wait failed");     // Xh is updated in place from here on
-      AddLnArgs ln1{w.Xh, w.t1, g1->p, b1->p, nullptr, w.Xh, M, dx, w.rows, w.row_count};
-      if (launch_add_layernorm(ln1, st)) return fail("layernorm width %d unsupported", dx);
-      if (node_lin(h, L.linX1, p + "linX1", w.Xh, dx, w.t2, c.dim_ffX, M, c.dim_ffX, dx, true, false, mask, w.rows,
-                   w.row_count, st)) return -1;
-      if (node_lin(h, L.linX2, p + "linX2", w.t2, c.dim_ffX, w.t1, dx, M, dx, c.dim_ffX, false, false, mask, w.rows,
-                   w.row_count, st)) return -1;
-      AddLnArgs ln2{w.Xh, w.t1, g2->p, b2->p, mask, w.Xh, M, dx, w.rows, w.row_count};
-      launch_add_layernorm(ln2, st);
+      if (fused_node) {
+        const bool next = l + 1 < n_run_layers;
+        NodeLayerArgs na{w.attn, mask, film, w.Xh, w.rows, w.row_count, L.x_out.W, L.x_out.b, g1->p, b1->p,
+                         L.linX1.W, L.linX1.b, L.linX2.W, L.linX2.b, g2->p, b2->p,
+                         next ? h->layers[l + 1].qkv.W : nullptr, next ? h->layers[l + 1].qkv.b : nullptr, w.qkv, n};
+        if (launch_node_layer(na, dx, c.dim_ffX, M, st)) return fail("node_layer launch failed");
+      } else {
+        if (node_lin(h, L.x_out, sa + "x_out", w.newX, dx, w.t1, dx, M, dx, dx, false, true, mask, w.rows, w.row_count, st))
+          return -1;
+        AddLnArgs ln1{w.Xh, w.t1, g1->p, b1->p, nullptr, w.Xh, M, dx, w.rows, w.row_count};
+        if (launch_add_layernorm(ln1, st)) return fail("layernorm width %d unsupported", dx);
+        if (node_lin(h, L.linX1, p + "linX1", w.Xh, dx, w.t2, c.dim_ffX, M, c.dim_ffX, dx, true, false, mask, w.rows,
+                     w.row_count, st)) return -1;
+        if (node_lin(h, L.linX2, p + "linX2", w.t2, c.dim_ffX, w.t1, dx, M, dx, c.dim_ffX, false, false, mask, w.rows,
+                     w.row_count, st)) return -1;
+        AddLnArgs ln2{w.Xh, w.t1, g2->p, b2->p, mask, w.Xh, M, dx, w.rows, w.row_count};
+        launch_add_layernorm(ln2, st);
+      }
       if (signal(ev(l, EV_X), st)) return fail("event record failed");
     }
-    // ---- aux: y update (transformer_model.py:239-246, :101-106)
-    if (L.predicts_y) {
+    // ---- aux: y update (transformer_model.py:239-246, :101-106) and the next layer's FiLM vectors
+    const bool next_layer = l + 1 < n_run_layers;
+    float* film_next = w.film + (size_t)((l + 1) & 1) * B * 4 * dx;
+    if (fused_y) {
+      if (L.predicts_y || next_layer) {
+        YLayerArgs ya{};
+        ya.y = w.y; ya.ycat = w.ycat; ya.B = B; ya.dy = dy; ya.ffy = c.dim_ffy; ya.kcat = kcat; ya.dx = dx;
+        ya.update = L.predicts_y ? 1 : 0;
+        if (L.predicts_y) {
+          if (await(ax, ev(l, EV_EDGE))) return fail("stream wait failed");
+          EdgeStatsArgs es{w.stats, mask, w.ycat, B, n, de, kcat, dy + 4 * dx};   // Etoy of the layer input (partials from
+          if (launch_edge_stats_finish(es, ax)) return fail("edge_stats: unsupported de=%d", de);   // the edge kernel above)
+          const Param* o0b = P_(h, sa + "y_out.0.bias", dy); const Param* o2b = P_(h, sa + "y_out.2.bias", dy);
+          const Param* g1 = P_(h, p + "norm_y1.weight", dy); const Param* b1 = P_(h, p + "norm_y1.bias", dy);
+          const Param* g2 = P_(h, p + "norm_y2.weight", dy); const Param* b2 = P_(h, p + "norm_y2.bias", dy);
+          const Param* l1b = P_(h, p + "lin_y1.bias", c.dim_ffy); const Param* l2b = P_(h, p + "lin_y2.bias", dy);
+          if (!o0b || !o2b || !g1 || !b1 || !g2 || !b2 || !l1b || !l2b) return -1;
+          ya.Wt_cat = L.Wt_cat; ya.b_cat = L.bycat;
+          ya.Wt_o0 = L.Wt_o0; ya.b_o0 = o0b->p; ya.Wt_o2 = L.Wt_o2; ya.b_o2 = o2b->p;
+          ya.ln1_g = g1->p; ya.ln1_b = b1->p; ya.ln2_g = g2->p; ya.ln2_b = b2->p;
+          ya.Wt_l1 = L.Wt_l1; ya.b_l1 = l1b->p; ya.Wt_l2 = L.Wt_l2; ya.b_l2 = l2b->p;
+        }
+        if (next_layer) { ya.Wt_film = h->layers[l + 1].Wt_film; ya.b_film = h->layers[l + 1].bfilm; ya.film = film_next; }
+        if (launch_y_layer(ya, ax)) return fail("y_layer launch failed");
+        if (next_layer && signal(ev(l + 1, EV_FILM), ax)) return fail("event record failed");
+      }
+    } else if (L.predicts_y) {
       if (await(ax, ev(l, EV_EDGE))) return fail("stream wait failed");
       EdgeStatsArgs es{w.stats, mask, w.ycat, B, n, de, kcat, dy + 4 * dx};   // Etoy of the layer input (partials from the
       if (launch_edge_stats_finish(es, ax)) return fail("edge_stats: unsupported de=%d", de);   // layer kernel above)

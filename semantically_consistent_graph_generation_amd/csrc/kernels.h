@@ -86,6 +86,8 @@ struct EdgeStatsArgs {
   int B, n, de, z_stride, z_offset;
 };
 
+
+
 int launch_edge_mlp_in(const EdgeMlpInArgs& a, int dE_in, int hid, int de, hipStream_t st);
 int launch_edge_layer(const EdgeLayerArgs& a, int dx, int de, int ffe, hipStream_t st);
 long long edge_phase_img_f4(int dx, int de, int ffe);   // float4 count of one layer's phase images, -1 if unsupported
@@ -136,6 +138,44 @@ struct NodeLinearArgs {   // row-list Linear on pre-packed weights (node path)
 };
 int launch_node_linear(const NodeLinearArgs& a, int M, hipStream_t st);
 
+struct NodeLayerArgs {    // fused node part of one layer (node_layer.hip); packed weights as for NodeLinearArgs
+  const float* attn_part; // [B*n*nch, 3, dx] per-unit attention partials of this layer's edge kernel
+  const uint8_t* mask;
+  const float* film;      // [B, 4*dx]
+  float* X;               // [B,n,dx] residual stream, updated in place on the valid rows
+  const int* rows;
+  const int* row_count;
+  const f32x4_t* W_xout;  const float* b_xout;
+  const float* ln1_g;     const float* ln1_b;
+  const f32x4_t* W_lin1;  const float* b_lin1;
+  const f32x4_t* W_lin2;  const float* b_lin2;
+  const float* ln2_g;     const float* ln2_b;
+  const f32x4_t* W_qkv;   const float* b_qkv;   // next layer's q|k|v (null: not computed)
+  float* qkv;             // [B,n,3*dx]
+  int n;
+};
+bool node_layer_supported(int dx, int ffx);
+int launch_node_layer(const NodeLayerArgs& a, int dx, int ffx, int M, hipStream_t st);
+
+struct YLayerArgs {       // fused global-feature part of one layer (y_layer.hip); weights TRANSPOSED to [K][N]
+  float* y;               // [B,dy] in / out
+  const float* ycat;      // [B,kcat]: columns [dy, dy+4dx) = Xtoy stats, [dy+4dx, kcat) = Etoy stats (columns < dy unused)
+  const float* Wt_cat;  const float* b_cat;   // [kcat,dy] = [y_y | x_y.lin | e_y.lin]^T, summed biases
+  const float* Wt_o0;   const float* b_o0;    // y_out.0
+  const float* Wt_o2;   const float* b_o2;    // y_out.2
+  const float* ln1_g;   const float* ln1_b;
+  const float* Wt_l1;   const float* b_l1;    // lin_y1^T [dy,ffy]
+  const float* Wt_l2;   const float* b_l2;    // lin_y2^T [ffy,dy]
+  const float* ln2_g;   const float* ln2_b;
+  const float* Wt_film; const float* b_film;  // next layer's FiLM weights^T [dy,4dx] (null: none)
+  float* film;            // [B,4dx] destination of the FiLM vectors
+  int B, dy, ffy, kcat, dx;
+  int update;             // 0: only the FiLM vectors of the current y
+};
+
+bool y_layer_supported(int dy, int ffy, int kcat);
+int launch_y_layer(const YLayerArgs& a, hipStream_t st);
+
 struct NodeStatsArgs {    // Xtoy pooling: z[b] = [mean|min|max|var] over valid nodes
   const float* X;         // [B,n,dx]
   const uint8_t* mask;
@@ -152,6 +192,7 @@ struct PackArgs {
 int launch_pack_linear(const PackArgs& a, hipStream_t st);
 int launch_pad_vec(const float* src, float* dst, int n, int n_pad, float add, hipStream_t st);
 int launch_copy_cols(const float* src, int lds, float* dst, int ldd, int M, int ncols, hipStream_t st);
+int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t st);   // dst[c][r] = src[r][c]
 int launch_x_out_residual(const float* mlp, const float* X_in, int dX_in, const uint8_t* mask, float* out,
                           int M, int nout, hipStream_t st);
 

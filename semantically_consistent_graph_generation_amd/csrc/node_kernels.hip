@@ -331,6 +331,19 @@ __global__ void copy_cols_kernel(const float* src, int lds, float* dst, int ldd,
   dst[(long long)m * ldd + c] = src[(long long)m * lds + c];
 }
 
+__global__ void transpose_kernel(const float* src, float* dst, int rows, int cols) {
+  const long long idx = blockIdx.x * 256ll + threadIdx.x;
+  if (idx >= (long long)rows * cols) return;
+  const int r = (int)(idx / cols), c = (int)(idx - (long long)r * cols);
+  dst[(size_t)c * rows + r] = src[idx];
+}
+
+int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)(((long long)rows * cols + 255) / 256)), dim3(256), 0, st, src, dst,
+                     rows, cols);
+  return 0;
+}
+
 int launch_copy_cols(const float* src, int lds, float* dst, int ldd, int M, int ncols, hipStream_t st) {
   const long long total = (long long)M * ncols;
   if (total == 0) return 0;

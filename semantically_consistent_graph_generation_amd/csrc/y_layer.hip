@@ -1,0 +1,201 @@
+// Fused XEy layer, global-feature (y) part (gfx950): one launch instead of nine small GEMM / LayerNorm launches.
+//
+//   new_y = y_y(y) + x_y(Xtoy(X)) + e_y(Etoy(E)); y_out MLP          transformer_model.py:239-246
+//   y = norm_y1(y + new_y); y = norm_y2(y + lin_y2(relu(lin_y1(y))))  transformer_model.py:101-106
+//   FiLM vectors of the NEXT layer: [y_e_add | y_e_mul+1 | y_x_add | y_x_mul+1](y)   transformer_model.py:186-190, :230
+//
+// The work is tiny (B rows of width <= 2048) and sits on the path between two edge-layer launches (the next edge
+// kernel needs the FiLM vectors), so the goal is latency: one workgroup owns G = 2 graphs (256 workgroups at B = 512),
+// keeps their vectors in LDS and walks the chain of dense layers with plain fp32 FMAs.  Weights are TRANSPOSED copies
+// ([K][N], made once per weight refresh): a thread owns 4 adjacent outputs, so every weight read is a coalesced
+// float4, there is no cross-lane reduction, and the input element is an LDS broadcast.  Narrow layers (N/4 < 256
+// threads) split K over the spare threads and combine through LDS.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace scgg {
+
+constexpr int YG = 2;          // graphs per workgroup
+constexpr int YT = 256;        // threads per workgroup
+constexpr int YW = 256;        // max width of the y vectors (dy); the FFN hidden width dim_ffy has its own buffer
+
+typedef float yf4 __attribute__((ext_vector_type(4)));
+
+// out[g][o] = act(bias[o] + sum_k Wt[k][o] in[g][k]) for o < N, g < YG.  in / out: LDS [YG][ld]; red: LDS scratch of
+// YT * YG float4.  Contains barriers: call from uniform control flow.  On return `out` is complete and synchronised.
+__device__ __forceinline__ void y_dense(const float* __restrict__ Wt, const float* __restrict__ bias, int N, int K,
+                                        const float* in, int ldin, float* out, int ldout, bool relu, yf4* red, int tid) {
+  const int N4 = N >> 2;
+  const yf4* w4 = reinterpret_cast<const yf4*>(Wt);
+  if (N4 >= YT || YT % N4 != 0) {
+    for (int o4 = tid; o4 < N4; o4 += YT) {
+      yf4 acc[YG];
+      const yf4 bv = *reinterpret_cast<const yf4*>(bias + 4 * o4);
+#pragma unroll
+      for (int g = 0; g < YG; ++g) acc[g] = bv;
+#pragma unroll 4
+      for (int k = 0; k < K; ++k) {
+        const yf4 w = w4[(size_t)k * N4 + o4];
+#pragma unroll
+        for (int g = 0; g < YG; ++g) acc[g] += w * in[g * ldin + k];
+      }
+#pragma unroll
+      for (int g = 0; g < YG; ++g) {
+        yf4 v = acc[g];
+        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        *reinterpret_cast<yf4*>(out + g * ldout + 4 * o4) = v;
+      }
+    }
+    __syncthreads();
+  } else {
+    const int S = YT / N4, o4 = tid % N4, sl = tid / N4;
+    const int k0 = (int)((long long)K * sl / S), k1 = (int)((long long)K * (sl + 1) / S);
+    yf4 acc[YG];
+#pragma unroll
+    for (int g = 0; g < YG; ++g) acc[g] = yf4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k) {
+      const yf4 w = w4[(size_t)k * N4 + o4];
+#pragma unroll
+      for (int g = 0; g < YG; ++g) acc[g] += w * in[g * ldin + k];
+    }
+#pragma unroll
+    for (int g = 0; g < YG; ++g) red[g * YT + tid] = acc[g];
+    __syncthreads();
+    if (sl == 0) {
+      const yf4 bv = *reinterpret_cast<const yf4*>(bias + 4 * o4);
+#pragma unroll
+      for (int g = 0; g < YG; ++g) {
+        yf4 v = bv;
+        for (int t = 0; t < S; ++t) v += red[g * YT + t * N4 + o4];
+        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        *reinterpret_cast<yf4*>(out + g * ldout + 4 * o4) = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// y[g][:] <- LN(y[g][:] + t[g][:]) * gamma + beta, D <= 256; wave w handles graphs w, w+4
+__device__ __forceinline__ void y_add_layernorm(float* y, const float* t, int ld, int D, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int g = wave; g < YG; g += YT / 64) {
+    float v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = c < D ? y[g * ld + c] + t[g * ld + c] : 0.f;
+      s += v[i];
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m);
+    const float mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      const float d = c < D ? v[i] - mean : 0.f;
+      q += d * d;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) q += __shfl_xor(q, m);
+    const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D) y[g * ld + c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+    }
+  }
+}
+
+__global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float ysm[];
+  const int tid = threadIdx.x;
+  const int dy = a.dy, kcat = a.kcat;
+  const int ldf = a.ffy > YW ? a.ffy : YW;
+  yf4* red = reinterpret_cast<yf4*>(ysm);                       // [YG][YT] float4
+  float* cat = ysm + YG * YT * 4;                                // [YG][kcat]  (y | Xtoy | Etoy)
+  float* yv = cat + YG * kcat;                                   // [YG][YW]    the y stream
+  float* t1 = yv + YG * YW;                                      // [YG][YW]
+  float* t2 = t1 + YG * YW;                                      // [YG][ldf]   (y_out hidden, then the lin_y1 hidden)
+  const int b0 = blockIdx.x * YG;
+
+  if (a.update) {
+    for (int idx = tid; idx < YG * kcat; idx += YT) {
+      const int g = idx / kcat, c = idx - g * kcat;
+      const int b = min(b0 + g, a.B - 1);
+      cat[idx] = c < dy ? a.y[(size_t)b * dy + c] : a.ycat[(size_t)b * kcat + c];
+    }
+  }
+  for (int idx = tid; idx < YG * dy; idx += YT) {
+    const int g = idx / dy, c = idx - g * dy;
+    yv[g * YW + c] = a.y[(size_t)min(b0 + g, a.B - 1) * dy + c];
+  }
+  __syncthreads();
+  if (a.update) {
+    y_dense(a.Wt_cat, a.b_cat, dy, kcat, cat, kcat, t1, YW, false, red, tid);        // y_y + x_y + e_y
+    y_dense(a.Wt_o0, a.b_o0, dy, dy, t1, YW, t2, ldf, true, red, tid);               // y_out.0 + relu
+    y_dense(a.Wt_o2, a.b_o2, dy, dy, t2, ldf, t1, YW, false, red, tid);              // y_out.2
+    y_add_layernorm(yv, t1, YW, dy, a.ln1_g, a.ln1_b, tid);
+    __syncthreads();
+    y_dense(a.Wt_l1, a.b_l1, a.ffy, dy, yv, YW, t2, ldf, true, red, tid);            // lin_y1 + relu
+    y_dense(a.Wt_l2, a.b_l2, dy, a.ffy, t2, ldf, t1, YW, false, red, tid);           // lin_y2
+    y_add_layernorm(yv, t1, YW, dy, a.ln2_g, a.ln2_b, tid);
+    __syncthreads();
+    for (int idx = tid; idx < YG * dy; idx += YT) {
+      const int g = idx / dy, c = idx - g * dy;
+      if (b0 + g < a.B) a.y[(size_t)(b0 + g) * dy + c] = yv[g * YW + c];
+    }
+  }
+  if (a.Wt_film != nullptr) {
+    // FiLM vectors for the next edge / node kernels, +1 folded into the two "mul" quarters
+    const int N4 = a.dx;                                         // 4 dx outputs = dx float4
+    const yf4* w4 = reinterpret_cast<const yf4*>(a.Wt_film);
+    for (int o4 = tid; o4 < N4; o4 += YT) {
+      yf4 acc[YG];
+      yf4 bv = *reinterpret_cast<const yf4*>(a.b_film + 4 * o4);
+      const int quarter = (4 * o4) / a.dx;
+      if (quarter == 1 || quarter == 3) bv += 1.0f;
+#pragma unroll
+      for (int g = 0; g < YG; ++g) acc[g] = bv;
+#pragma unroll 4
+      for (int k = 0; k < dy; ++k) {
+        const yf4 w = w4[(size_t)k * N4 + o4];
+#pragma unroll
+        for (int g = 0; g < YG; ++g) acc[g] += w * yv[g * YW + k];
+      }
+#pragma unroll
+      for (int g = 0; g < YG; ++g)
+        if (b0 + g < a.B) *reinterpret_cast<yf4*>(a.film + (size_t)(b0 + g) * 4 * a.dx + 4 * o4) = acc[g];
+    }
+  }
+}
+
+static size_t y_layer_lds(int ffy, int kcat) {
+  return (size_t)(YG * YT * 4 + YG * kcat + 2 * YG * YW + YG * (ffy > YW ? ffy : YW)) * 4;
+}
+
+bool y_layer_supported(int dy, int ffy, int kcat) {
+  return dy % 4 == 0 && ffy % 4 == 0 && kcat % 4 == 0 && dy <= YW && y_layer_lds(ffy, kcat) <= 64 * 1024;
+}
+
+int launch_y_layer(const YLayerArgs& a, hipStream_t st) {
+  if (!y_layer_supported(a.dy, a.ffy, a.kcat)) return -1;
+  const size_t lds = y_layer_lds(a.ffy, a.kcat);
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(y_layer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return -2;
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL(y_layer_kernel, dim3((a.B + YG - 1) / YG), dim3(YT), lds, st, a);
+  return 0;
+}
+
+}  // namespace scgg
