@@ -58,7 +58,8 @@ int main(int argc, char** argv) {
   a.units = units; a.unit_count = cnt;
   a.inv_sqrt_df = 1.f / sqrtf(32.f);
   a.B = B; a.n = n;
-  scgg::launch_build_unit_list(d_mask, B * n, n, units, cnt, 0);
+  int* rows = dev<int>((size_t)B * n); int* rcnt = dev<int>(1); int* goff = dev<int>((size_t)2 * B);
+  scgg::launch_build_lists(d_mask, B, n, goff, rows, rcnt, units, cnt, 0);
   CK(hipDeviceSynchronize());
   int n_units = 0; CK(hipMemcpy(&n_units, cnt, 4, hipMemcpyDeviceToHost));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

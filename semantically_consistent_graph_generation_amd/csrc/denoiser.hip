@@ -288,7 +288,7 @@ int build(scgg_denoiser* h, bool fill, hipStream_t st) {
 
 struct Workspace {
   float *Xh, *qkv, *newX, *t1, *t2, *E0, *E1, *y, *ycat, *yt1, *yt2, *film, *hidX, *hidy, *xo;
-  int *rows, *row_count, *units, *unit_count;
+  int *rows, *row_count, *units, *unit_count, *goff;
   float *stats, *attn;
   size_t bytes;
 };
@@ -322,6 +322,7 @@ Workspace carve(const scgg_denoiser_config& c, int B, int n, char* base) {
   w.row_count = ar.take<int>(64);
   w.units = ar.take<int>(M * nch);
   w.unit_count = ar.take<int>(64);
+  w.goff = ar.take<int>((size_t)2 * B);
   w.bytes = align_up(ar.off, 256);
   return w;
 }
@@ -392,42 +393,70 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   const int dx = c.dx, de = c.de, dy = c.dy;
   const int kcat = dy + 4 * dx + 4 * de;
 
-  // ---- input MLPs (transformer_model.py:358-366)
-  if (gemm(X, c.in_X, P_(h, "mlp_in_X.0.weight", (int64_t)c.hid_X * c.in_X), P_(h, "mlp_in_X.0.bias", c.hid_X), w.hidX,
-           c.hid_X, M, c.hid_X, c.in_X, GEMM_RELU, nullptr, st)) return -1;
-  if (gemm(w.hidX, c.hid_X, P_(h, "mlp_in_X.3.weight", (int64_t)dx * c.hid_X), P_(h, "mlp_in_X.3.bias", dx), w.Xh, dx, M,
-           dx, c.hid_X, GEMM_RELU | GEMM_ROWMASK, mask, st)) return -1;   // all rows: padded rows of Xh become 0 here
+  // ---- streams.  `st` (the caller's) carries the edge path and the fused node kernel; `ax` carries the node / global
+  //      input MLPs, the first q|k|v, the y path (pooled statistics, y update, FiLM vectors) and the X / y output MLPs.
+  //      Events per layer: FILM (film(l) -- and for l = 0 everything the aux prologue produced -- ready), EDGE (edge
+  //      kernel l done: Etoy partials ready), NS (Xtoy of X(l) taken: X may be overwritten), X (X(l+1) ready).
+  hipStream_t ax = h->aux;
+  enum { EV_FILM = 0, EV_EDGE = 1, EV_NS = 2, EV_X = 3, EV_PER_LAYER = 4 };
+  auto ev = [&](int l, int k) { return h->sync_ev[(size_t)(l + 1) * EV_PER_LAYER + k]; };
+  auto signal = [&](hipEvent_t e, hipStream_t s) { return hipEventRecord(e, s) != hipSuccess; };
+  auto await = [&](hipStream_t s, hipEvent_t e) { return hipStreamWaitEvent(s, e, 0) != hipSuccess; };
+  hipEvent_t ev_join = h->sync_ev[0], ev_fork = h->sync_ev[1];
+
+  // ---- work lists (valid rows, 16-key units), then fork
+  if (launch_build_lists(mask, B, n, w.goff, w.rows, w.row_count, w.units, w.unit_count, st))
+    return fail("n=%d too large for the unit list (max 512)", n);
+  if (signal(ev_fork, st) || await(ax, ev_fork)) return fail("stream fork failed");
+
+  // ---- input MLPs (transformer_model.py:358-366): E on the main stream, X and y beside it on the aux stream
+  {
+    const Param* w0 = P_(h, "mlp_in_X.0.weight", (int64_t)c.hid_X * c.in_X); const Param* b0 = P_(h, "mlp_in_X.0.bias", c.hid_X);
+    const Param* w3 = P_(h, "mlp_in_X.3.weight", (int64_t)dx * c.hid_X); const Param* b3 = P_(h, "mlp_in_X.3.bias", dx);
+    if (!w0 || !b0 || !w3 || !b3) return -1;
+    if (h->in_X2.W != nullptr && c.in_X <= 64 && c.hid_X % 4 == 0) {
+      // valid rows only: the padded rows of the residual stream are zeroed once, nothing writes them afterwards
+      if (hipMemsetAsync(w.Xh, 0, (size_t)M * dx * sizeof(float), ax) != hipSuccess) return fail("memset failed");
+      NarrowLinearArgs na{X, w0->p, b0->p, w.hidX, w.rows, w.row_count, c.hid_X, c.in_X, c.in_X, c.hid_X, 1};
+      if (launch_narrow_linear(na, M, ax)) return fail("narrow_linear rejected");
+      NodeLinearArgs la{w.hidX, h->in_X2.W, h->in_X2.b, w.Xh, w.rows, w.row_count, dx, c.hid_X, (dx + 31) / 32, c.hid_X, dx,
+                        (dx + 31) / 32 >= 4 ? 2 : 1, 1};
+      if (launch_node_linear(la, M, ax)) return fail("node_linear(mlp_in_X.3) rejected");
+    } else {
+      if (gemm(X, c.in_X, w0, b0, w.hidX, c.hid_X, M, c.hid_X, c.in_X, GEMM_RELU, nullptr, ax)) return -1;
+      if (gemm(w.hidX, c.hid_X, w3, b3, w.Xh, dx, M, dx, c.hid_X, GEMM_RELU | GEMM_ROWMASK, mask, ax)) return -1;
+    }
+  }
   if (gemm(y, c.in_y, P_(h, "mlp_in_y.0.weight", (int64_t)c.hid_y * c.in_y), P_(h, "mlp_in_y.0.bias", c.hid_y), w.hidy,
-           c.hid_y, B, c.hid_y, c.in_y, GEMM_RELU, nullptr, st)) return -1;
+           c.hid_y, B, c.hid_y, c.in_y, GEMM_RELU, nullptr, ax)) return -1;
   if (gemm(w.hidy, c.hid_y, P_(h, "mlp_in_y.3.weight", (int64_t)dy * c.hid_y), P_(h, "mlp_in_y.3.bias", dy), w.y, dy, B,
-           dy, c.hid_y, GEMM_RELU, nullptr, st)) return -1;
+           dy, c.hid_y, GEMM_RELU, nullptr, ax)) return -1;
   {
     EdgeMlpInArgs a{E, mask, h->in_E1.W, h->in_E1.b, h->in_E2.W, h->in_E2.b, w.E0, B, n, c.in_E};
     if (launch_edge_mlp_in(a, c.in_E, c.hid_E, de, st)) return fail("edge_mlp_in: unsupported dims");
   }
   float* Ecur = w.E0;
   float* Enext = w.E1;
-  launch_build_row_list(mask, M, w.rows, w.row_count, st);
-  if (launch_build_unit_list(mask, M, n, w.units, w.unit_count, st)) return fail("n=%d too large for the unit list (max 512)", n);
   const bool prof_now = !tap && h->prof_every > 0 && (h->prof_forwards++ % h->prof_every) == 0;
 
   // ---- layers (transformer_model.py:76-112, :165-248)
-  // Streams: `st` carries q|k|v, the fused edge kernel and the X path; `ax` carries the y path (FiLM vectors, pooled
-  // statistics, y update, the next layer's FiLM vectors), which runs beside the node kernel.  Events per layer: FILM
-  // (film(l) ready), EDGE (edge kernel l done: Etoy partials ready), NS (Xtoy of X(l) taken: X may be overwritten),
-  // X (X(l+1) ready).
-  hipStream_t ax = h->aux;
-  enum { EV_FILM = 0, EV_EDGE = 1, EV_NS = 2, EV_X = 3, EV_PER_LAYER = 4 };
-  auto ev = [&](int l, int k) { return h->sync_ev[(size_t)(l + 1) * EV_PER_LAYER + k]; };
-  auto signal = [&](hipEvent_t e, hipStream_t s) { return hipEventRecord(e, s) != hipSuccess; };
-  auto await = [&](hipStream_t s, hipEvent_t e) { return hipStreamWaitEvent(s, e, 0) != hipSuccess; };
-  if (signal(ev(-1, EV_X), st) || await(ax, ev(-1, EV_X))) return fail("stream fork failed");   // inputs embedded
-
   for (int l = 0; l < n_run_layers; ++l) {
     LayerPack& L = h->layers[l];
     const std::string p = "tf_layers." + std::to_string(l) + ".";
     const std::string sa = p + "self_attn.";
     float* film = w.film + (size_t)(l & 1) * B * 4 * dx;
+    // ---- q|k|v masked: layer 0 on the aux stream (beside the edge input MLP), later layers come out of the previous
+    //      layer's fused node kernel; on the unfused path every layer computes them on the main stream
+    const bool fused_node = node_layer_supported(dx, c.dim_ffX) && L.x_out.W && L.linX1.W && L.linX2.W && L.qkv.W;
+    {
+      hipStream_t qs = l == 0 ? ax : st;
+      if (fused_node && l > 0) {
+      } else if (L.qkv.W != nullptr) {
+        NodeLinearArgs qa{w.Xh, L.qkv.W, L.qkv.b, w.qkv, w.rows, w.row_count, 3 * dx, dx, (3 * dx + 31) / 32, dx, 3 * dx,
+                          dx >= 256 ? 8 : (3 * dx + 31) / 32, 0};
+        if (launch_node_linear(qa, M, qs)) return fail("node_linear(qkv) rejected");
+      } else if (gemm_raw(w.Xh, dx, L.Wqkv, L.bqkv, w.qkv, 3 * dx, M, 3 * dx, dx, GEMM_ROWMASK, mask, qs)) return -1;
+    }
     // ---- aux: y-FiLM vectors (with the +1 folded in), Xtoy pooled statistics of the layer INPUT (:239-243)
     const bool fused_y = y_layer_supported(dy, c.dim_ffy, kcat);
     if (!fused_y || l == 0) {   // (fused: layer l's vectors were produced by layer l-1's y kernel)
@@ -448,15 +477,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     }
     if (signal(ev(l, EV_NS), ax)) return fail("event record failed");
 
-    // ---- main: q|k|v masked (layer 0, or every layer on the unfused path), fused edge kernel
-    const bool fused_node = node_layer_supported(dx, c.dim_ffX) && L.x_out.W && L.linX1.W && L.linX2.W && L.qkv.W;
-    if (fused_node && l > 0) {
-      // q|k|v of this layer were produced by the previous layer's node kernel
-    } else if (L.qkv.W != nullptr) {
-      NodeLinearArgs qa{w.Xh, L.qkv.W, L.qkv.b, w.qkv, w.rows, w.row_count, 3 * dx, dx, (3 * dx + 31) / 32, dx, 3 * dx,
-                        dx >= 256 ? 8 : (3 * dx + 31) / 32, 0};
-      if (launch_node_linear(qa, M, st)) return fail("node_linear(qkv) rejected");
-    } else if (gemm_raw(w.Xh, dx, L.Wqkv, L.bqkv, w.qkv, 3 * dx, M, 3 * dx, dx, GEMM_ROWMASK, mask, st)) return -1;
+    // ---- main: fused edge kernel
     if (await(st, ev(l, EV_FILM))) return fail("stream wait failed");
     {
       EdgeLayerArgs a;
@@ -556,10 +577,11 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     float* t = Ecur; Ecur = Enext; Enext = t;
     if (check_launch("layer")) return -1;
   }
-  // join: everything the aux stream did is ordered before what follows on the caller's stream
-  if (signal(h->sync_ev[0], ax) || await(st, h->sync_ev[0])) return fail("stream join failed");
+  // the aux stream needs the final X (the main stream's last node kernel)
+  if (await(ax, ev(n_run_layers - 1, EV_X))) return fail("stream wait failed");
 
   if (tap) {
+    if (signal(ev_join, ax) || await(st, ev_join)) return fail("stream join failed");
     if (o1) launch_copy_cols(w.Xh, dx, o1, dx, M, dx, st);
     if (o2) {
       const long long total = (long long)M * n * de;
@@ -569,26 +591,28 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     return check_launch("tap");
   }
 
-  // ---- output MLPs (transformer_model.py:371-389)
+  // ---- output MLPs (transformer_model.py:371-389): E on the main stream, X and y beside it on the aux stream
   if (c.out_X > 0) {
     if (gemm(w.Xh, dx, P_(h, "mlp_out_X.0.weight", (int64_t)c.hid_X * dx), P_(h, "mlp_out_X.0.bias", c.hid_X), w.hidX,
-             c.hid_X, M, c.hid_X, dx, GEMM_RELU, nullptr, st)) return -1;
+             c.hid_X, M, c.hid_X, dx, GEMM_RELU, nullptr, ax)) return -1;
     if (gemm(w.hidX, c.hid_X, P_(h, "mlp_out_X.3.weight", (int64_t)c.out_X * c.hid_X), P_(h, "mlp_out_X.3.bias", c.out_X),
-             w.xo, c.out_X, M, c.out_X, c.hid_X, 0, nullptr, st)) return -1;
-    launch_x_out_residual(w.xo, X, c.in_X, mask, o1, M, c.out_X, st);
+             w.xo, c.out_X, M, c.out_X, c.hid_X, 0, nullptr, ax)) return -1;
+    launch_x_out_residual(w.xo, X, c.in_X, mask, o1, M, c.out_X, ax);
+  }
+  if (c.out_y > 0) {
+    if (!o3) return fail("out_y requested by the config but out_y pointer is NULL");
+    if (gemm(w.y, dy, P_(h, "mlp_out_y.0.weight", (int64_t)c.hid_y * dy), P_(h, "mlp_out_y.0.bias", c.hid_y), w.hidy,
+             c.hid_y, B, c.hid_y, dy, GEMM_RELU, nullptr, ax)) return -1;
+    if (gemm(w.hidy, c.hid_y, P_(h, "mlp_out_y.3.weight", (int64_t)c.out_y * c.hid_y), P_(h, "mlp_out_y.3.bias", c.out_y),
+             w.yt1, c.out_y, B, c.out_y, c.hid_y, 0, nullptr, ax)) return -1;
+    launch_x_out_residual(w.yt1, y, c.in_y, nullptr, o3, B, c.out_y, ax);
   }
   {
     EdgeMlpOutArgs a{Ecur, E, mask, h->out_E1.W, h->out_E1.b, h->out_E2.W, h->out_E2.b, o2, B, n, c.in_E, c.out_E};
     if (launch_edge_mlp_out(a, de, c.hid_E, st)) return fail("edge_mlp_out: unsupported dims");
   }
-  if (c.out_y > 0) {
-    if (!o3) return fail("out_y requested by the config but out_y pointer is NULL");
-    if (gemm(w.y, dy, P_(h, "mlp_out_y.0.weight", (int64_t)c.hid_y * dy), P_(h, "mlp_out_y.0.bias", c.hid_y), w.hidy,
-             c.hid_y, B, c.hid_y, dy, GEMM_RELU, nullptr, st)) return -1;
-    if (gemm(w.hidy, c.hid_y, P_(h, "mlp_out_y.3.weight", (int64_t)c.out_y * c.hid_y), P_(h, "mlp_out_y.3.bias", c.out_y),
-             w.yt1, c.out_y, B, c.out_y, c.hid_y, 0, nullptr, st)) return -1;
-    launch_x_out_residual(w.yt1, y, c.in_y, nullptr, o3, B, c.out_y, st);
-  }
+  // join: everything the aux stream did is ordered before what follows on the caller's stream
+  if (signal(ev_join, ax) || await(st, ev_join)) return fail("stream join failed");
   return check_launch("forward");
 }
 

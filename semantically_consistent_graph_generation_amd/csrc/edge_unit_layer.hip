@@ -78,90 +78,95 @@ struct UnitGeom {
 };
 
 // ---------------------------------------------------------------------------------------------------------
-// valid-row list: rows[k] = flat (b*n+i) of the k-th valid node, *count = number of valid rows.  One block.
+// Work lists, rebuilt per forward from the node mask (two short launches):
+//   rows[k]  = flat (b*n+i) of the k-th valid node                      (*row_count of them)
+//   units[k] = row * nch + jc for every valid row and every 16-key chunk jc of its graph that holds a valid key
+//              (*unit_count of them; rows in order, so the units of a row and of a graph are contiguous)
+// graph_scan_kernel (one block) counts per graph and scans; graph_fill_kernel (one wave per graph) writes the slices.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void build_row_list_kernel(const uint8_t* mask, int M, int* rows, int* count) {
-  __shared__ int wsum[16];
-  __shared__ int base;
+__global__ __launch_bounds__(1024) void graph_scan_kernel(const uint8_t* mask, int B, int n, int nch, int* goff,
+                                                          int* row_count, int* unit_count) {
+  __shared__ int wr[16], wu[16];
+  __shared__ int base_r, base_u;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) base = 0;
+  if (tid == 0) { base_r = 0; base_u = 0; }
   __syncthreads();
-  for (int start = 0; start < M; start += 1024) {
-    const int idx = start + tid;
-    const bool v = idx < M && mask[idx] != 0;
-    const unsigned long long bal = __ballot(v);
-    const int before = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wsum[wave] = __popcll(bal);
-    __syncthreads();
-    int off = base;
-    for (int w = 0; w < wave; ++w) off += wsum[w];
-    if (v) rows[off + before] = idx;
-    __syncthreads();
-    if (tid == 0) {
-      int t = 0;
-      for (int w = 0; w < 16; ++w) t += wsum[w];
-      base += t;
-    }
-    __syncthreads();
-  }
-  if (tid == 0) *count = base;
-}
-
-int launch_build_row_list(const uint8_t* mask, int M, int* rows, int* count, hipStream_t st) {
-  hipLaunchKernelGGL(build_row_list_kernel, dim3(1), dim3(1024), 0, st, mask, M, rows, count);
-  return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// unit list: units[k] = row * nch + jc for every valid row and every 16-key chunk of its graph with a valid key.
-// One block; rows in order, so the units of a row (and of a graph) are contiguous.
-// ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void build_unit_list_kernel(const uint8_t* mask, int M, int n, int nch, int* units,
-                                                               int* count) {
-  __shared__ int wsum[16];
-  __shared__ int base;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) base = 0;
-  __syncthreads();
-  for (int start = 0; start < M; start += 1024) {
-    const int row = start + tid;
-    unsigned bits = 0;
-    if (row < M && mask[row] != 0) {
-      const uint8_t* mb = mask + (row / n) * n;
+  for (int start = 0; start < B; start += 1024) {
+    const int b = start + tid;
+    int nv = 0, nu = 0;
+    if (b < B) {
+      const uint8_t* mb = mask + (size_t)b * n;
+      int chunks = 0;
       for (int jc = 0; jc < nch; ++jc) {
-        bool any = false;
-        for (int j = jc * 16; j < min(n, jc * 16 + 16); ++j) any |= mb[j] != 0;
-        bits |= any ? (1u << jc) : 0u;
+        int cnt = 0;
+        for (int j = jc * 16; j < min(n, jc * 16 + 16); ++j) cnt += mb[j] != 0;
+        nv += cnt;
+        chunks += cnt > 0;
       }
+      nu = nv * chunks;
     }
-    const int c = __popc(bits);
-    int incl = c;   // inclusive scan inside the wave
+    int ir = nv, iu = nu;   // inclusive scans inside the wave
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_up(incl, d);
-      if (lane >= d) incl += t;
+      const int tr = __shfl_up(ir, d), tu = __shfl_up(iu, d);
+      if (lane >= d) { ir += tr; iu += tu; }
     }
-    if (lane == 63) wsum[wave] = incl;
+    if (lane == 63) { wr[wave] = ir; wu[wave] = iu; }
     __syncthreads();
-    int off = base + incl - c;
-    for (int w = 0; w < wave; ++w) off += wsum[w];
-    for (int jc = 0; jc < nch; ++jc)
-      if ((bits >> jc) & 1u) units[off++] = row * nch + jc;
+    int orow = base_r + ir - nv, ounit = base_u + iu - nu;
+    for (int w = 0; w < wave; ++w) { orow += wr[w]; ounit += wu[w]; }
+    if (b < B) { goff[2 * b] = orow; goff[2 * b + 1] = ounit; }
     __syncthreads();
     if (tid == 0) {
-      int t = 0;
-      for (int w = 0; w < 16; ++w) t += wsum[w];
-      base += t;
+      int tr = 0, tu = 0;
+      for (int w = 0; w < 16; ++w) { tr += wr[w]; tu += wu[w]; }
+      base_r += tr; base_u += tu;
     }
     __syncthreads();
   }
-  if (tid == 0) *count = base;
+  if (tid == 0) { *row_count = base_r; *unit_count = base_u; }
 }
 
-int launch_build_unit_list(const uint8_t* mask, int M, int n, int* units, int* count, hipStream_t st) {
+__global__ __launch_bounds__(64) void graph_fill_kernel(const uint8_t* mask, int n, int nch, const int* goff, int* rows,
+                                                        int* units) {
+  __shared__ int chunk_rank[32];
+  __shared__ int s_nvc;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const uint8_t* mb = mask + (size_t)b * n;
+  if (lane == 0) {
+    int k = 0;
+    for (int jc = 0; jc < nch; ++jc) {
+      bool any = false;
+      for (int j = jc * 16; j < min(n, jc * 16 + 16); ++j) any |= mb[j] != 0;
+      chunk_rank[jc] = any ? k++ : -1;
+    }
+    s_nvc = k;
+  }
+  __syncthreads();
+  const int nvc = s_nvc;
+  int done = 0;   // valid nodes before this 64-node slab
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const int i = i0 + lane;
+    const bool v = i < n && mb[i] != 0;
+    const unsigned long long bal = __ballot(v);
+    if (v) {
+      const int rank = done + __popcll(bal & ((1ull << lane) - 1ull));
+      const int row = b * n + i;
+      rows[goff[2 * b] + rank] = row;
+      int* u = units + goff[2 * b + 1] + rank * nvc;
+      for (int jc = 0; jc < nch; ++jc)
+        if (chunk_rank[jc] >= 0) u[chunk_rank[jc]] = row * nch + jc;
+    }
+    done += __popcll(bal);
+  }
+}
+
+int launch_build_lists(const uint8_t* mask, int B, int n, int* goff, int* rows, int* row_count, int* units,
+                       int* unit_count, hipStream_t st) {
   const int nch = (n + 15) / 16;
   if (nch > 32) return -1;
-  hipLaunchKernelGGL(build_unit_list_kernel, dim3(1), dim3(1024), 0, st, mask, M, n, nch, units, count);
+  hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(1024), 0, st, mask, B, n, nch, goff, row_count, unit_count);
+  hipLaunchKernelGGL(graph_fill_kernel, dim3(B), dim3(64), 0, st, mask, n, nch, goff, rows, units);
   return 0;
 }
 

@@ -92,9 +92,10 @@ int launch_edge_mlp_in(const EdgeMlpInArgs& a, int dE_in, int hid, int de, hipSt
 int launch_edge_layer(const EdgeLayerArgs& a, int dx, int de, int ffe, hipStream_t st);
 long long edge_phase_img_f4(int dx, int de, int ffe);   // float4 count of one layer's phase images, -1 if unsupported
 int launch_edge_unit_pack(const EdgeUnitPackArgs& a, int dx, int de, int ffe, hipStream_t st);
-int launch_build_unit_list(const uint8_t* mask, int M, int n, int* units, int* count, hipStream_t st);
+// valid-row list and 16-key unit list of a node mask; goff: 2*B ints of scratch (per-graph offsets)
+int launch_build_lists(const uint8_t* mask, int B, int n, int* goff, int* rows, int* row_count, int* units,
+                       int* unit_count, hipStream_t st);
 int launch_attn_finish(const AttnFinishArgs& a, int M, hipStream_t st);
-int launch_build_row_list(const uint8_t* mask, int M, int* rows, int* count, hipStream_t st);
 int launch_edge_mlp_out(const EdgeMlpOutArgs& a, int de, int hid, hipStream_t st);
 int launch_edge_stats_finish(const EdgeStatsArgs& a, hipStream_t st);
 
@@ -175,6 +176,17 @@ struct YLayerArgs {       // fused global-feature part of one layer (y_layer.hip
 
 bool y_layer_supported(int dy, int ffy, int kcat);
 int launch_y_layer(const YLayerArgs& a, hipStream_t st);
+
+struct NarrowLinearArgs { // row-list Linear with a narrow input (K <= 64), torch-layout weights
+  const float* A;         // [M,K] lda
+  const float* W;         // [N,K]
+  const float* bias;      // [N]
+  float* C;               // [M,N] ldc
+  const int* rows;
+  const int* row_count;
+  int N, K, lda, ldc, relu;
+};
+int launch_narrow_linear(const NarrowLinearArgs& a, int M, hipStream_t st);
 
 struct NodeStatsArgs {    // Xtoy pooling: z[b] = [mean|min|max|var] over valid nodes
   const float* X;         // [B,n,dx]

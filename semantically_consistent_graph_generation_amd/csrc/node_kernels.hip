@@ -331,6 +331,33 @@ __global__ void copy_cols_kernel(const float* src, int lds, float* dst, int ldd,
   dst[(long long)m * ldd + c] = src[(long long)m * lds + c];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row-list Linear for a very narrow input (K <= 64: the raw node features): thread = (valid row, 4 outputs).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void narrow_linear_kernel(NarrowLinearArgs a) {
+  const int N4 = a.N >> 2;
+  const long long item = blockIdx.x * 256ll + threadIdx.x;
+  const int ridx = (int)(item / N4), o4 = (int)(item - (long long)ridx * N4);
+  if (ridx >= *a.row_count) return;
+  const long long row = a.rows[ridx];
+  const float* x = a.A + row * a.lda;
+  f32x4 acc = *reinterpret_cast<const f32x4*>(a.bias + 4 * o4);
+  const float* w = a.W + (size_t)(4 * o4) * a.K;
+  for (int k = 0; k < a.K; ++k) {
+    const float xv = x[k];
+    acc[0] += w[k] * xv; acc[1] += w[a.K + k] * xv; acc[2] += w[2 * a.K + k] * xv; acc[3] += w[3 * a.K + k] * xv;
+  }
+  if (a.relu) { acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f); acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f); }
+  *reinterpret_cast<f32x4*>(a.C + row * a.ldc + 4 * o4) = acc;
+}
+
+int launch_narrow_linear(const NarrowLinearArgs& a, int M, hipStream_t st) {
+  if (a.N % 4 != 0 || a.ldc % 4 != 0 || a.K > 64) return -1;
+  const long long items = (long long)M * (a.N >> 2);
+  hipLaunchKernelGGL(narrow_linear_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, a);
+  return 0;
+}
+
 __global__ void transpose_kernel(const float* src, float* dst, int rows, int cols) {
   const long long idx = blockIdx.x * 256ll + threadIdx.x;
   if (idx >= (long long)rows * cols) return;
