@@ -289,7 +289,7 @@ int build(scgg_denoiser* h, bool fill, hipStream_t st) {
 struct Workspace {
   float *Xh, *qkv, *newX, *t1, *t2, *E0, *E1, *y, *ycat, *yt1, *yt2, *film, *hidX, *hidy, *xo;
   int *rows, *row_count, *units, *unit_count, *goff;
-  float *stats, *attn;
+  float *epool, *attn;
   size_t bytes;
 };
 
@@ -316,7 +316,7 @@ Workspace carve(const scgg_denoiser_config& c, int B, int n, char* base) {
   w.hidy = ar.take<float>((size_t)B * c.hid_y);
   w.xo = ar.take<float>(M * (size_t)(c.out_X > 0 ? c.out_X : 1));
   const size_t nch = (size_t)(n + 15) / 16;                 // 16-key chunks per row (edge_unit_layer.hip)
-  w.stats = ar.take<float>(M * nch * 4 * c.de);
+  w.epool = ar.take<float>((size_t)2 * B * 4 * c.de);       // Etoy stats of E(l), E(l+1)
   w.attn = ar.take<float>(M * nch * 3 * c.dx);
   w.rows = ar.take<int>(M);
   w.row_count = ar.take<int>(64);
@@ -402,7 +402,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   auto ev = [&](int l, int k) { return h->sync_ev[(size_t)(l + 1) * EV_PER_LAYER + k]; };
   auto signal = [&](hipEvent_t e, hipStream_t s) { return hipEventRecord(e, s) != hipSuccess; };
   auto await = [&](hipStream_t s, hipEvent_t e) { return hipStreamWaitEvent(s, e, 0) != hipSuccess; };
-  hipEvent_t ev_join = h->sync_ev[0], ev_fork = h->sync_ev[1];
+  hipEvent_t ev_join = h->sync_ev[0], ev_fork = h->sync_ev[1], ev_e0 = h->sync_ev[2];
 
   // ---- work lists (valid rows, 16-key units), then fork
   if (launch_build_lists(mask, B, n, w.goff, w.rows, w.row_count, w.units, w.unit_count, st))
@@ -434,6 +434,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   {
     EdgeMlpInArgs a{E, mask, h->in_E1.W, h->in_E1.b, h->in_E2.W, h->in_E2.b, w.E0, B, n, c.in_E};
     if (launch_edge_mlp_in(a, c.in_E, c.hid_E, de, st)) return fail("edge_mlp_in: unsupported dims");
+    if (signal(ev_e0, st)) return fail("event record failed");
   }
   float* Ecur = w.E0;
   float* Enext = w.E1;
@@ -476,6 +477,13 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       launch_node_stats(ns, ax);
     }
     if (signal(ev(l, EV_NS), ax)) return fail("event record failed");
+    // Etoy of the layer INPUT E(l) (:239-243).  Fused y path: E(0) here, E(l+1) at the end of round l (beside the node
+    // kernel); unfused: every layer here, straight into the ycat row.
+    if (L.predicts_y && (l == 0 || !fused_y)) {
+      if (l == 0 && await(ax, ev_e0)) return fail("stream wait failed");
+      EdgePoolArgs ep{Ecur, mask, fused_y ? w.epool : w.ycat, B, n, de, fused_y ? 4 * de : kcat, fused_y ? 0 : dy + 4 * dx};
+      if (launch_edge_pool_stats(ep, ax)) return fail("edge_pool_stats: unsupported de=%d or n=%d", de, n);
+    }
 
     // ---- main: fused edge kernel
     if (await(st, ev(l, EV_FILM))) return fail("stream wait failed");
@@ -488,7 +496,6 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       a.b_out = L.b_out;
       a.attn_part = w.attn; a.units = w.units; a.unit_count = w.unit_count;
       a.ln1_g = L.ln1_g; a.ln1_b = L.ln1_b; a.ln2_g = L.ln2_g; a.ln2_b = L.ln2_b;
-      a.stats_part = L.predicts_y ? w.stats : nullptr;
       a.inv_sqrt_df = 1.0f / sqrtf((float)(dx / c.n_head));
       a.B = B; a.n = n;
       const bool timed = prof_now && h->prof_used + 2 <= h->prof_ev.size();
@@ -533,12 +540,13 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     if (fused_y) {
       if (L.predicts_y || next_layer) {
         YLayerArgs ya{};
-        ya.y = w.y; ya.ycat = w.ycat; ya.B = B; ya.dy = dy; ya.ffy = c.dim_ffy; ya.kcat = kcat; ya.dx = dx;
+        ya.y = w.y; ya.ycat = w.ycat; ya.etoy = w.epool + (size_t)(l & 1) * B * 4 * de;
+        ya.B = B; ya.dy = dy; ya.ffy = c.dim_ffy; ya.kcat = kcat; ya.dx = dx;
         ya.update = L.predicts_y ? 1 : 0;
+        // (the y round needs nothing from edge kernel l; it is held back until that kernel is done because the two
+        //  cannot share a CU -- the edge kernel owns every register -- and the node kernel can)
+        if (await(ax, ev(l, EV_EDGE))) return fail("stream wait failed");
         if (L.predicts_y) {
-          if (await(ax, ev(l, EV_EDGE))) return fail("stream wait failed");
-          EdgeStatsArgs es{w.stats, mask, w.ycat, B, n, de, kcat, dy + 4 * dx};   // Etoy of the layer input (partials from
-          if (launch_edge_stats_finish(es, ax)) return fail("edge_stats: unsupported de=%d", de);   // the edge kernel above)
           const Param* o0b = P_(h, sa + "y_out.0.bias", dy); const Param* o2b = P_(h, sa + "y_out.2.bias", dy);
           const Param* g1 = P_(h, p + "norm_y1.weight", dy); const Param* b1 = P_(h, p + "norm_y1.bias", dy);
           const Param* g2 = P_(h, p + "norm_y2.weight", dy); const Param* b2 = P_(h, p + "norm_y2.bias", dy);
@@ -553,10 +561,13 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
         if (launch_y_layer(ya, ax)) return fail("y_layer launch failed");
         if (next_layer && signal(ev(l + 1, EV_FILM), ax)) return fail("event record failed");
       }
+      if (next_layer && h->layers[l + 1].predicts_y) {   // Etoy of E(l+1), the tensor edge kernel l has just written
+        if (await(ax, ev(l, EV_EDGE))) return fail("stream wait failed");
+        EdgePoolArgs ep{Enext, mask, w.epool + (size_t)((l + 1) & 1) * B * 4 * de, B, n, de, 4 * de, 0};
+        if (launch_edge_pool_stats(ep, ax)) return fail("edge_pool_stats: unsupported de=%d or n=%d", de, n);
+      }
     } else if (L.predicts_y) {
       if (await(ax, ev(l, EV_EDGE))) return fail("stream wait failed");
-      EdgeStatsArgs es{w.stats, mask, w.ycat, B, n, de, kcat, dy + 4 * dx};   // Etoy of the layer input (partials from the
-      if (launch_edge_stats_finish(es, ax)) return fail("edge_stats: unsupported de=%d", de);   // layer kernel above)
       if (gemm_raw(w.ycat, kcat, L.Wycat, L.bycat, w.yt1, dy, B, dy, kcat, 0, nullptr, ax)) return -1;
       if (gemm(w.yt1, dy, P_(h, sa + "y_out.0.weight", (int64_t)dy * dy), P_(h, sa + "y_out.0.bias", dy), w.yt2, dy, B, dy,
                dy, GEMM_RELU, nullptr, ax)) return -1;

@@ -58,10 +58,14 @@ __device__ __forceinline__ float groups_max(float v) {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x4 splat4(float v) { f32x4 x = {v, v, v, v}; return x; }
 
-// acc += F . x : 16 output channels x 16 input channels (4 K-steps of v_mfma_f32_16x16x4_f32)
-__device__ __forceinline__ void mfma4(f32x4& acc, const f32x4& f, const f32x4& x) {
+// two independent accumulators, same input block, MFMAs interleaved: v_mfma_f32_16x16x4_f32 issues every 32 cycles but
+// a dependent accumulation needs 40 (MI355X_MICROARCH.md cycle constants), so a single chain would idle the pipe 20 %
+__device__ __forceinline__ void mfma4x2(f32x4& acc0, f32x4& acc1, const f32x4& f0, const f32x4& f1, const f32x4& x) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f[r], x[r], acc, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f0[r], x[r], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f1[r], x[r], acc1, 0, 0, 0);
+  }
 }
 
 template <int NXB, int NEB, int NFB>
@@ -173,9 +177,11 @@ int launch_build_lists(const uint8_t* mask, int B, int n, int* goff, int* rows, 
 // ---------------------------------------------------------------------------------------------------------
 // Phase images from the raw (torch layout) weights.  Fragment t of a phase is 64 float4: lane l holds
 // W[row0 + (l & 15)][col0 + 4 (l >> 4) + 0..3]; fragments are stored in the order the kernel consumes them:
-//   cb phase : e_mul rows 32cb+16ob (ob 0,1) x in blocks ib | same for e_add | e_out rows 16ob x cols 32cb+16ib (ib 0,1)
-//   FFN1 f   : linE1 rows 64f+16ob (ob 0..3) x ib
-//   FFN2 rb  : linE2 rows 32rb+16ob (ob 0,1) x ib
+// (fragments come in PAIRS that share the input block and feed two different output blocks, see mfma4x2)
+//   cb phase : e_mul: for ib: rows 32cb+16ob, ob = 0,1 | same for e_add | e_out: for ob pair, for ib = 0,1 (cols 32cb+16ib):
+//              rows 16ob of the pair
+//   FFN1 f   : linE1: for ob pair (of 0..3), for ib: rows 64f+16ob of the pair
+//   FFN2 rb  : linE2: for ib: rows 32rb+16ob, ob = 0,1
 // bias area (floats, at float4 slot WMAX): cb: (e_mul.bias+1)[32cb..] | e_add.bias[32cb..]; FFN1: linE1.bias[64f..];
 // FFN2: linE2.bias[32rb..].
 // ---------------------------------------------------------------------------------------------------------
@@ -193,10 +199,11 @@ __global__ __launch_bounds__(512) void edge_unit_pack_kernel(EdgeUnitPackArgs a)
       const int cb = ph;
       if (t < 4 * IBE) {
         W = t < 2 * IBE ? a.W_mul : a.W_add;
-        row0 = 32 * cb + 16 * ((t / IBE) & 1); col0 = 16 * (t % IBE); K = DE;
+        const int rem = t % (2 * IBE);
+        row0 = 32 * cb + 16 * (rem & 1); col0 = 16 * (rem >> 1); K = DE;
       } else if (t < 6 * IBE) {
         const int u = t - 4 * IBE;
-        W = a.W_out; row0 = 16 * (u >> 1); col0 = 32 * cb + 16 * (u & 1); K = DX;
+        W = a.W_out; row0 = 16 * (2 * (u >> 2) + (u & 1)); col0 = 32 * cb + 16 * ((u >> 1) & 1); K = DX;
       } else if (idx >= G::WMAX && idx < G::WMAX + 16) {
         const int f = (idx - G::WMAX) * 4;   // float offset in the bias area
 #pragma unroll
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(512) void edge_unit_pack_kernel(EdgeUnitPackArgs a)
     } else if (ph < NXB + NFB / 2) {
       const int f = ph - NXB;
       if (t < 4 * IBE) {
-        W = a.W_ff1; row0 = 64 * f + 16 * (t / IBE); col0 = 16 * (t % IBE); K = DE;
+        W = a.W_ff1; row0 = 64 * f + 16 * (2 * (t / (2 * IBE)) + (t & 1)); col0 = 16 * ((t >> 1) % IBE); K = DE;
       } else if (idx >= G::WMAX && idx < G::WMAX + 16) {
         const int o = (idx - G::WMAX) * 4;
 #pragma unroll
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(512) void edge_unit_pack_kernel(EdgeUnitPackArgs a)
     } else {
       const int rb = ph - NXB - NFB / 2;
       if (t < 2 * IBF) {
-        W = a.W_ff2; row0 = 32 * rb + 16 * (t / IBF); col0 = 16 * (t % IBF); K = FFE;
+        W = a.W_ff2; row0 = 32 * rb + 16 * (t & 1); col0 = 16 * (t >> 1); K = FFE;
       } else if (idx >= G::WMAX && idx < G::WMAX + 8) {
         const int o = (idx - G::WMAX) * 4;
 #pragma unroll
@@ -246,8 +253,8 @@ __device__ __forceinline__ void load_frags2(f32x4 (&f)[2], const f32x4* w, int l
 }
 
 // NG (even) groups of two fragments starting at W; on entry fa holds group 0, on exit fa holds the group at `after`
-// (when not null).  body(t, frag) issues the four MFMAs of fragment t.  The next group's two ds_read_b128 are issued
-// before the current group's 8 MFMAs; sched_barrier pins that order (see edge_layer history: left alone hipcc either
+// (when not null).  body(g, f0, f1) issues the eight MFMAs of fragment pair g.  The next group's two ds_read_b128 are
+// issued before the current group's 8 MFMAs; sched_barrier pins that order (see edge_layer history: left alone hipcc either
 // serialises read -> wait -> MFMA or hoists a phase worth of fragments and spills).
 template <int NG, class Body>
 __device__ __forceinline__ void frag_pipeline(const f32x4* W, const f32x4* after, f32x4 (&fa)[2], f32x4 (&fb)[2],
@@ -257,14 +264,12 @@ __device__ __forceinline__ void frag_pipeline(const f32x4* W, const f32x4* after
   for (int gq = 0; gq < NG; gq += 2) {
     load_frags2(fb, W + (gq + 1) * 128, lane);
     __builtin_amdgcn_sched_barrier(0);
-    body(2 * gq, fa[0]);
-    body(2 * gq + 1, fa[1]);
+    body(gq, fa[0], fa[1]);
     __builtin_amdgcn_sched_barrier(0);
     if (gq + 2 < NG) load_frags2(fa, W + (gq + 2) * 128, lane);
     else if (after != nullptr) load_frags2(fa, after, lane);
     __builtin_amdgcn_sched_barrier(0);
-    body(2 * gq + 2, fb[0]);
-    body(2 * gq + 3, fb[1]);
+    body(gq + 1, fb[0], fb[1]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -357,33 +362,6 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_kernel(EdgeLayerArgs 
       accO[eb] = ld4(a.b_out + 16 * eb + 4 * g);
     }
 
-    // ---- Etoy pooling partials of the layer INPUT for this unit: per channel sum | min | max | M2 about the unit mean
-    //      over the valid keys (the zero diagonal included, layers.py:34-40); merged by edge_stats_finish_kernel.
-    if (a.stats_part != nullptr && active) {
-      const float cntf = (float)__popc((unsigned)__ballot(vj) & 0xFFFFu);
-      const float rc = 1.0f / cntf;                                     // a unit has at least one valid key
-      float* dst = a.stats_part + ((long long)u * 4) * DE + 4 * g;
-#pragma unroll
-      for (int eb = 0; eb < IBE; ++eb) {
-        f32x4 sm, mn, mx, m2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float x = e[eb][r];
-          sm[r] = row_sum16(vj ? x : 0.f);
-          mn[r] = row_min16(vj ? x : INFINITY);
-          mx[r] = row_max16(vj ? x : -INFINITY);
-          const float d = x - sm[r] * rc;
-          m2[r] = row_sum16(vj ? d * d : 0.f);
-        }
-        if (p == 0) {
-          *reinterpret_cast<f32x4*>(dst + 16 * eb) = sm;
-          *reinterpret_cast<f32x4*>(dst + DE + 16 * eb) = mn;
-          *reinterpret_cast<f32x4*>(dst + 2 * DE + 16 * eb) = mx;
-          *reinterpret_cast<f32x4*>(dst + 3 * DE + 16 * eb) = m2;
-        }
-      }
-    }
-
     f32x4 fa[2], fb[2];                                                 // A fragments: group in use / group in flight
     // ================================================================== channel-block phases
 #pragma unroll 1
@@ -405,10 +383,9 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_kernel(EdgeLayerArgs 
           a1[ob] = ld4(bias + 16 * ob + 4 * g);                         // e_mul bias + 1
           a2[ob] = ld4(bias + 32 + 16 * ob + 4 * g);                    // e_add bias
         }
-        frag_pipeline<2 * IBE>(W, W + 4 * IBE * 64, fa, fb, lane, [&](int t, const f32x4& f) {
-          const int ob = (t / IBE) & 1, ib = t % IBE;
-          if (t < 2 * IBE) mfma4(a1[ob], f, e[ib]);
-          else mfma4(a2[ob], f, e[ib]);
+        frag_pipeline<2 * IBE>(W, W + 4 * IBE * 64, fa, fb, lane, [&](int gp, const f32x4& f0, const f32x4& f1) {
+          if (gp < IBE) mfma4x2(a1[0], a1[1], f0, f1, e[gp]);           // e_mul, input block gp
+          else mfma4x2(a2[0], a2[1], f0, f1, e[gp - IBE]);              // e_add
         });
         f32x4 y[2], v[2], z[2];
         float mloc = -INFINITY;
@@ -429,8 +406,9 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_kernel(EdgeLayerArgs 
           }
         }
         // newE += W_out[:, block cb] . z
-        frag_pipeline<IBE>(W + 4 * IBE * 64, nullptr, fa, fb, lane,
-                           [&](int t, const f32x4& f) { mfma4(accO[t >> 1], f, z[t & 1]); });
+        frag_pipeline<IBE>(W + 4 * IBE * 64, nullptr, fa, fb, lane, [&](int gp, const f32x4& f0, const f32x4& f1) {
+          mfma4x2(accO[2 * (gp >> 1)], accO[2 * (gp >> 1) + 1], f0, f1, z[gp & 1]);
+        });
 
         // ---- attention statistics of this (unit, channel block)
         const float M = groups_max(row_max16(mloc));                    // wave-uniform shift
@@ -491,8 +469,9 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_kernel(EdgeLayerArgs 
         const float* bias = reinterpret_cast<const float*>(W + G::WMAX);
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) hid[4 * f + ob] = ld4(bias + 16 * ob + 4 * g);
-        frag_pipeline<2 * IBE>(W, nullptr, fa, fb, lane,
-                               [&](int t, const f32x4& fr) { mfma4(hid[4 * f + t / IBE], fr, e[t % IBE]); });
+        frag_pipeline<2 * IBE>(W, nullptr, fa, fb, lane, [&](int gp, const f32x4& f0, const f32x4& f1) {
+          mfma4x2(hid[4 * f + 2 * (gp / IBE)], hid[4 * f + 2 * (gp / IBE) + 1], f0, f1, e[gp % IBE]);
+        });
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
@@ -512,8 +491,9 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_kernel(EdgeLayerArgs 
         f32x4 f2[2];
 #pragma unroll
         for (int ob = 0; ob < 2; ++ob) f2[ob] = ld4(bias + 16 * ob + 4 * g);
-        frag_pipeline<IBF>(W, nullptr, fa, fb, lane,
-                           [&](int t, const f32x4& fr) { mfma4(f2[t / IBF], fr, hid[t % IBF]); });
+        frag_pipeline<IBF>(W, nullptr, fa, fb, lane, [&](int gp, const f32x4& f0, const f32x4& f1) {
+          mfma4x2(f2[0], f2[1], f0, f1, hid[gp]);
+        });
 #pragma unroll
         for (int ob = 0; ob < 2; ++ob) e[2 * rb + ob] += f2[ob];
       }
@@ -576,56 +556,107 @@ int launch_attn_finish(const AttnFinishArgs& a, int M, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// merge the per-unit partials of one graph into z[b] = [mean | min | max | biased variance] (layers.py:34-41)
+// Etoy pooling of a hidden E (layers.py:34-41): z[b] = [mean | min | max | biased variance] per channel over the n_b x n_b
+// pairs of the valid nodes of the SYMMETRISED masked tensor (the stored one is not: mfma_chain.h load_sym_tile), zero
+// diagonal included.  One workgroup per graph; thread = (channel, slice of the unordered pairs); each stored element
+// is read once per pass (pair {i,j} = 0.5 (E_ij + E_ji), weight 2); two passes (mean, then centred squares -- the
+// second pass is an L2 read).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void edge_stats_finish_kernel(EdgeStatsArgs a) {
-  // thread = (channel c, row slice s); slices merge through LDS in a fixed order (Chan's formula is order dependent
-  // only in round-off, the fixed order keeps it reproducible)
-  __shared__ float sN[256], sMean[256], sM2[256], sMn[256], sMx[256];
-  const int b = blockIdx.x, n = a.n, DE = a.de, tid = threadIdx.x;
-  const int S = 256 / DE, c = tid % DE, s = tid / DE;
-  const uint8_t* m = a.mask + b * n;
-  const int nch = (n + 15) >> 4;
-  float N = 0.f, mean = 0.f, M2 = 0.f, mn = INFINITY, mx = -INFINITY;
-  if (s < S)
-    for (int jc = 0; jc < nch; ++jc) {
-      int cnt = 0;
-      for (int j = jc * 16; j < min(n, jc * 16 + 16); ++j) cnt += m[j] != 0;
-      if (cnt == 0) continue;
-      const float nb = (float)cnt;
-      for (int i = s; i < n; i += S) {
-        if (!m[i]) continue;
-        const float* p = a.part + (((long long)b * n + i) * nch + jc) * (4 * DE) + c;
-        const float mb = p[0] / nb, tot = N + nb, delta = mb - mean;
-        M2 += p[3 * DE] + delta * delta * (N * nb / tot);
-        mean += delta * (nb / tot);
-        N = tot;
-        mn = fminf(mn, p[DE]);
-        mx = fmaxf(mx, p[2 * DE]);
+__global__ __launch_bounds__(256) void edge_pool_stats_kernel(EdgePoolArgs a) {
+  __shared__ float red[3][256];
+  __shared__ float smean[256];
+  __shared__ short vidx[512];                                             // the valid nodes, in order
+  __shared__ int wcount[4];
+  const int b = blockIdx.x, n = a.n, DE = a.de, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = 256 / DE, c = tid % DE, sl = tid / DE;
+  const uint8_t* m = a.mask + (long long)b * n;
+  int nv = 0;
+  for (int i0 = 0; i0 < n; i0 += 256) {                                   // compaction of the mask, 256 nodes a round
+    const int i = i0 + tid;
+    const bool v = i < n && m[i] != 0;
+    const unsigned long long bal = __ballot(v);
+    if (lane == 0) wcount[wave] = __popcll(bal);
+    __syncthreads();
+    int off = nv;
+    for (int w = 0; w < wave; ++w) off += wcount[w];
+    if (v) vidx[off + __popcll(bal & ((1ull << lane) - 1ull))] = (short)i;
+    nv += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    __syncthreads();
+  }
+  const float* E = a.E + (long long)b * n * n * DE + c;
+  const float cnt = (float)nv * (float)nv;
+  // ---- pass 1: sum, min, max over the unordered pairs ii < jj (slice sl takes rows ii = sl, sl+S, ...)
+  float sum = 0.f, mn = INFINITY, mx = -INFINITY;
+  if (sl < S)
+    for (int ii = sl; ii < nv; ii += S) {
+      const long long i = vidx[ii];
+      int jj = ii + 1;
+      for (; jj + 3 < nv; jj += 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long long j = vidx[jj + u];
+          v[u] = 0.5f * (E[(i * n + j) * DE] + E[(j * n + i) * DE]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { sum += v[u]; mn = fminf(mn, v[u]); mx = fmaxf(mx, v[u]); }
+      }
+      for (; jj < nv; ++jj) {
+        const long long j = vidx[jj];
+        const float v = 0.5f * (E[(i * n + j) * DE] + E[(j * n + i) * DE]);
+        sum += v; mn = fminf(mn, v); mx = fmaxf(mx, v);
       }
     }
-  sN[tid] = N; sMean[tid] = mean; sM2[tid] = M2; sMn[tid] = mn; sMx[tid] = mx;
+  if (nv > 0) { mn = fminf(mn, 0.f); mx = fmaxf(mx, 0.f); }             // the diagonal
+  red[0][tid] = sum; red[1][tid] = mn; red[2][tid] = mx;
   __syncthreads();
-  if (s == 0) {
+  if (sl == 0) {
     for (int t = 1; t < S; ++t) {
-      const int o = t * DE + c;
-      const float nb = sN[o];
-      if (nb == 0.f) continue;
-      const float tot = N + nb, delta = sMean[o] - mean;
-      M2 += sM2[o] + delta * delta * (N * nb / tot);
-      mean += delta * (nb / tot);
-      N = tot;
-      mn = fminf(mn, sMn[o]);
-      mx = fmaxf(mx, sMx[o]);
+      sum += red[0][t * DE + c];
+      mn = fminf(mn, red[1][t * DE + c]);
+      mx = fmaxf(mx, red[2][t * DE + c]);
     }
+    smean[c] = 2.f * sum / cnt;
+    red[1][c] = mn; red[2][c] = mx;
+  }
+  __syncthreads();
+  // ---- pass 2: centred squares (L2 reads)
+  const float mean = smean[c];
+  float q = 0.f;
+  if (sl < S)
+    for (int ii = sl; ii < nv; ii += S) {
+      const long long i = vidx[ii];
+      int jj = ii + 1;
+      for (; jj + 3 < nv; jj += 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long long j = vidx[jj + u];
+          v[u] = 0.5f * (E[(i * n + j) * DE] + E[(j * n + i) * DE]) - mean;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q += v[u] * v[u];
+      }
+      for (; jj < nv; ++jj) {
+        const long long j = vidx[jj];
+        const float d = 0.5f * (E[(i * n + j) * DE] + E[(j * n + i) * DE]) - mean;
+        q += d * d;
+      }
+    }
+  __syncthreads();
+  red[0][tid] = q;
+  __syncthreads();
+  if (sl == 0) {
+    for (int t = 1; t < S; ++t) q += red[0][t * DE + c];
+    q = 2.f * q + (float)nv * mean * mean;                                // pairs count twice; nv diagonal zeros
     float* z = a.z + (long long)b * a.z_stride + a.z_offset;
-    z[c] = mean; z[DE + c] = mn; z[2 * DE + c] = mx; z[3 * DE + c] = M2 / N;
+    z[c] = mean; z[DE + c] = red[1][c]; z[2 * DE + c] = red[2][c]; z[3 * DE + c] = q / cnt;
   }
 }
 
-int launch_edge_stats_finish(const EdgeStatsArgs& a, hipStream_t st) {
-  if (a.de > 256 || 256 % a.de != 0) return -1;
-  hipLaunchKernelGGL(edge_stats_finish_kernel, dim3(a.B), dim3(256), 0, st, a);
+int launch_edge_pool_stats(const EdgePoolArgs& a, hipStream_t st) {
+  if (a.de > 256 || 256 % a.de != 0 || a.n > 512) return -1;
+  hipLaunchKernelGGL(edge_pool_stats_kernel, dim3(a.B), dim3(256), 0, st, a);
   return 0;
 }
 
@@ -653,7 +684,7 @@ int launch_edge_unit_pack(const EdgeUnitPackArgs& a, int dx, int de, int ffe, hi
 }
 
 #ifndef SCGG_UNIT_WAVES
-#define SCGG_UNIT_WAVES 16
+#define SCGG_UNIT_WAVES 8
 #endif
 
 template <int NXB, int NEB, int NFB>

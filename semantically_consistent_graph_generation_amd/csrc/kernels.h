@@ -36,7 +36,6 @@ struct EdgeLayerArgs {
   const float* ln1_b;
   const float* ln2_g;
   const float* ln2_b;
-  float* stats_part;      // [B*n*nch, 4, de] Etoy partials of the layer input per unit (or null)
   float* attn_part;       // [B*n*nch, 3, dx] per unit and channel: softmax max | sum p | sum p V
   const int* units;       // row * nch + jc of every unit, built by launch_build_unit_list (nch = ceil(n/16))
   const int* unit_count;  // device scalar
@@ -79,15 +78,6 @@ struct EdgeMlpOutArgs {
   int B, n, dE_in, C;
 };
 
-struct EdgeStatsArgs {
-  const float* part;      // [B*n, nch, 4, de] per-unit partials written by the layer kernel (nch = ceil(n/16))
-  const uint8_t* mask;
-  float* z;               // row b at z + b*z_stride + z_offset : [mean|min|max|var] (4*de floats)
-  int B, n, de, z_stride, z_offset;
-};
-
-
-
 int launch_edge_mlp_in(const EdgeMlpInArgs& a, int dE_in, int hid, int de, hipStream_t st);
 int launch_edge_layer(const EdgeLayerArgs& a, int dx, int de, int ffe, hipStream_t st);
 long long edge_phase_img_f4(int dx, int de, int ffe);   // float4 count of one layer's phase images, -1 if unsupported
@@ -97,7 +87,14 @@ int launch_build_lists(const uint8_t* mask, int B, int n, int* goff, int* rows, 
                        int* unit_count, hipStream_t st);
 int launch_attn_finish(const AttnFinishArgs& a, int M, hipStream_t st);
 int launch_edge_mlp_out(const EdgeMlpOutArgs& a, int de, int hid, hipStream_t st);
-int launch_edge_stats_finish(const EdgeStatsArgs& a, hipStream_t st);
+
+struct EdgePoolArgs {     // Etoy pooling straight from a hidden (unsymmetrised) E, n <= 512
+  const float* E;         // [B,n,n,de]
+  const uint8_t* mask;
+  float* z;
+  int B, n, de, z_stride, z_offset;
+};
+int launch_edge_pool_stats(const EdgePoolArgs& a, hipStream_t st);
 
 // ---- node / global path -------------------------------------------------------------------------
 enum GemmFlags : int { GEMM_RELU = 1, GEMM_ROWMASK = 2, GEMM_ADD_ONE_COLS = 4 };
@@ -160,7 +157,8 @@ int launch_node_layer(const NodeLayerArgs& a, int dx, int ffx, int M, hipStream_
 
 struct YLayerArgs {       // fused global-feature part of one layer (y_layer.hip); weights TRANSPOSED to [K][N]
   float* y;               // [B,dy] in / out
-  const float* ycat;      // [B,kcat]: columns [dy, dy+4dx) = Xtoy stats, [dy+4dx, kcat) = Etoy stats (columns < dy unused)
+  const float* ycat;      // [B,kcat]: columns [dy, dy+4dx) = Xtoy stats (the other columns are not read)
+  const float* etoy;      // [B,4de] Etoy stats of the layer input (edge_pool_stats_kernel)
   const float* Wt_cat;  const float* b_cat;   // [kcat,dy] = [y_y | x_y.lin | e_y.lin]^T, summed biases
   const float* Wt_o0;   const float* b_o0;    // y_out.0
   const float* Wt_o2;   const float* b_o2;    // y_out.2

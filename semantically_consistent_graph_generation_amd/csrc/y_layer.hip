@@ -129,7 +129,9 @@ __global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
     for (int idx = tid; idx < YG * kcat; idx += YT) {
       const int g = idx / kcat, c = idx - g * kcat;
       const int b = min(b0 + g, a.B - 1);
-      cat[idx] = c < dy ? a.y[(size_t)b * dy + c] : a.ycat[(size_t)b * kcat + c];
+      const int e0 = dy + 4 * a.dx;
+      cat[idx] = c < dy ? a.y[(size_t)b * dy + c]
+                        : (c < e0 ? a.ycat[(size_t)b * kcat + c] : a.etoy[(size_t)b * (kcat - e0) + (c - e0)]);
     }
   }
   for (int idx = tid; idx < YG * dy; idx += YT) {
