@@ -2,8 +2,8 @@
 import csv, glob, sys, collections
 f = (glob.glob(sys.argv[1] + '/*/*kernel_trace.csv') + glob.glob(sys.argv[1] + '/*kernel_trace.csv'))[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'edge_mlp_in' in r['Kernel_Name']]
-s, e = idx[-2] - 4, idx[-1] - 4
+idx = [i for i, r in enumerate(rows) if 'graph_scan' in r['Kernel_Name']]
+s, e = idx[-2], idx[-1]
 t0 = int(rows[s]['Start_Timestamp']); prev = t0
 agg = collections.OrderedDict()
 for r in rows[s:e]:

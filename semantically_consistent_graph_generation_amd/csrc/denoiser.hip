@@ -70,7 +70,7 @@ struct scgg_denoiser {
   bool finalized = false;
   char* arena = nullptr;
   size_t arena_bytes = 0;
-  PackedLinear in_E1, in_E2, out_E1, out_E2;
+  f32x4_t *in_E_img = nullptr, *out_E_img = nullptr;   // LDS images of the edge input / output MLPs (edge_mlp_unit.hip)
   PackedLinear in_X2, out_X1;
   std::vector<LayerPack> layers;
   // optional live timing of the dominant kernel (edge_layer_kernel): HIP events on the launch stream
@@ -187,10 +187,23 @@ __global__ void vec_sum3_kernel(const float* a, const float* b, const float* c, 
 int build(scgg_denoiser* h, bool fill, hipStream_t st) {
   const scgg_denoiser_config& c = h->c;
   Arena ar(fill ? h->arena : nullptr);
-  if (pack_linear(h, ar, fill, "mlp_in_E.0", c.hid_E, c.in_E, 0.f, h->in_E1, st)) return -1;
-  if (pack_linear(h, ar, fill, "mlp_in_E.3", c.de, c.hid_E, 0.f, h->in_E2, st)) return -1;
-  if (pack_linear(h, ar, fill, "mlp_out_E.0", c.hid_E, c.de, 0.f, h->out_E1, st)) return -1;
-  if (pack_linear(h, ar, fill, "mlp_out_E.3", c.out_E, c.hid_E, 0.f, h->out_E2, st)) return -1;
+  {
+    const long long n_in = edge_mlp_img_f4(c.in_E, c.hid_E, c.de), n_out = edge_mlp_img_f4(c.de, c.hid_E, c.out_E);
+    if (n_in < 0 || n_out < 0) return fail("edge MLP kernels have no build for hid_E=%d", c.hid_E);
+    h->in_E_img = ar.take<f32x4_t>((size_t)n_in);
+    h->out_E_img = ar.take<f32x4_t>((size_t)n_out);
+    if (fill) {
+      const Param* w0 = find(h, "mlp_in_E.0.weight", (int64_t)c.hid_E * c.in_E); const Param* b0 = find(h, "mlp_in_E.0.bias", c.hid_E);
+      const Param* w3 = find(h, "mlp_in_E.3.weight", (int64_t)c.de * c.hid_E); const Param* b3 = find(h, "mlp_in_E.3.bias", c.de);
+      const Param* v0 = find(h, "mlp_out_E.0.weight", (int64_t)c.hid_E * c.de); const Param* d0 = find(h, "mlp_out_E.0.bias", c.hid_E);
+      const Param* v3 = find(h, "mlp_out_E.3.weight", (int64_t)c.out_E * c.hid_E); const Param* d3 = find(h, "mlp_out_E.3.bias", c.out_E);
+      if (!w0 || !b0 || !w3 || !b3 || !v0 || !d0 || !v3 || !d3) return -1;
+      EdgeMlpPackArgs pi{w0->p, b0->p, w3->p, b3->p, h->in_E_img, c.in_E, c.hid_E, c.de};
+      EdgeMlpPackArgs po{v0->p, d0->p, v3->p, d3->p, h->out_E_img, c.de, c.hid_E, c.out_E};
+      if (launch_edge_mlp_pack(pi, st) || launch_edge_mlp_pack(po, st))
+        return fail("edge MLP pack: unsupported dims in_E=%d hid_E=%d de=%d out_E=%d", c.in_E, c.hid_E, c.de, c.out_E);
+    }
+  }
   if (pack_named(h, ar, fill, "mlp_in_X.3", c.dx, c.hid_X, h->in_X2, st)) return -1;
   if (pack_named(h, ar, fill, "mlp_out_X.0", c.hid_X, c.dx, h->out_X1, st)) return -1;
   h->layers.resize(c.n_layers);
@@ -415,8 +428,8 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     const Param* w3 = P_(h, "mlp_in_X.3.weight", (int64_t)dx * c.hid_X); const Param* b3 = P_(h, "mlp_in_X.3.bias", dx);
     if (!w0 || !b0 || !w3 || !b3) return -1;
     if (h->in_X2.W != nullptr && c.in_X <= 64 && c.hid_X % 4 == 0) {
-      // valid rows only: the padded rows of the residual stream are zeroed once, nothing writes them afterwards
-      if (hipMemsetAsync(w.Xh, 0, (size_t)M * dx * sizeof(float), ax) != hipSuccess) return fail("memset failed");
+      // valid rows only: the masked rows of the residual stream are zeroed once, nothing writes them afterwards
+      launch_zero_masked_rows(w.Xh, mask, M, dx, ax);
       NarrowLinearArgs na{X, w0->p, b0->p, w.hidX, w.rows, w.row_count, c.hid_X, c.in_X, c.in_X, c.hid_X, 1};
       if (launch_narrow_linear(na, M, ax)) return fail("narrow_linear rejected");
       NodeLinearArgs la{w.hidX, h->in_X2.W, h->in_X2.b, w.Xh, w.rows, w.row_count, dx, c.hid_X, (dx + 31) / 32, c.hid_X, dx,
@@ -432,7 +445,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   if (gemm(w.hidy, c.hid_y, P_(h, "mlp_in_y.3.weight", (int64_t)dy * c.hid_y), P_(h, "mlp_in_y.3.bias", dy), w.y, dy, B,
            dy, c.hid_y, GEMM_RELU, nullptr, ax)) return -1;
   {
-    EdgeMlpInArgs a{E, mask, h->in_E1.W, h->in_E1.b, h->in_E2.W, h->in_E2.b, w.E0, B, n, c.in_E};
+    EdgeMlpUnitArgs a{E, nullptr, mask, h->in_E_img, w.E0, w.units, w.unit_count, B, n, c.in_E, c.out_E};
     if (launch_edge_mlp_in(a, c.in_E, c.hid_E, de, st)) return fail("edge_mlp_in: unsupported dims");
     if (signal(ev_e0, st)) return fail("event record failed");
   }
@@ -619,8 +632,10 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     launch_x_out_residual(w.yt1, y, c.in_y, nullptr, o3, B, c.out_y, ax);
   }
   {
-    EdgeMlpOutArgs a{Ecur, E, mask, h->out_E1.W, h->out_E1.b, h->out_E2.W, h->out_E2.b, o2, B, n, c.in_E, c.out_E};
-    if (launch_edge_mlp_out(a, de, c.hid_E, st)) return fail("edge_mlp_out: unsupported dims");
+    // logits are zero outside the live pairs (utils.py:154); the unit kernel writes the chunks that hold valid keys
+    if (hipMemsetAsync(o2, 0, (size_t)M * n * c.out_E * sizeof(float), st) != hipSuccess) return fail("memset failed");
+    EdgeMlpUnitArgs a{Ecur, E, mask, h->out_E_img, o2, w.units, w.unit_count, B, n, c.in_E, c.out_E};
+    if (launch_edge_mlp_out(a, de, c.hid_E, c.out_E, st)) return fail("edge_mlp_out: unsupported dims");
   }
   // join: everything the aux stream did is ordered before what follows on the caller's stream
   if (signal(ev_join, ax) || await(st, ev_join)) return fail("stream join failed");

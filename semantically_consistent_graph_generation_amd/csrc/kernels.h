@@ -10,15 +10,24 @@ const char* last_error();
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-struct EdgeMlpInArgs {
-  const float* E_in;      // [B,n,n,dE_in]
-  const uint8_t* mask;    // [B,n]
-  const f32x4_t* W1;      // packed [hid x dE_in]
-  const float* b1;        // padded
-  const f32x4_t* W2;      // packed [de x hid]
+struct EdgeMlpPackArgs {  // raw (torch layout) two-layer MLP -> LDS image of edge_mlp_unit_kernel
+  const float* W1;        // [N1, K1]
+  const float* b1;
+  const float* W2;        // [N2, N1]
   const float* b2;
-  float* E_out;           // [B,n,n,de]  unsymmetrised, zero on dead pairs
-  int B, n, dE_in;
+  f32x4_t* img;           // [edge_mlp_img_f4(K1, N1, N2)]
+  int K1, N1, N2;
+};
+
+struct EdgeMlpUnitArgs {  // mlp_in_E / mlp_out_E over the 16-key units
+  const float* src;       // in: model input E [B,n,n,dE_in]; out: hidden E [B,n,n,de] (unsymmetrised)
+  const float* E_in;      // out only: model input E (residual uses channels [0,C))
+  const uint8_t* mask;
+  const f32x4_t* img;
+  float* dst;             // in: hidden E [B,n,n,de]; out: logits [B,n,n,C] (zero-filled by the caller beforehand)
+  const int* units;
+  const int* unit_count;
+  int B, n, dE_in, C;
 };
 
 struct EdgeLayerArgs {
@@ -66,19 +75,9 @@ struct AttnFinishArgs {   // merge the units of every valid row: newX_pre = y_x_
   int n, dx;
 };
 
-struct EdgeMlpOutArgs {
-  const float* E_hid;     // [B,n,n,de]
-  const float* E_in;      // [B,n,n,dE_in] original model input (residual uses channels [0,C))
-  const uint8_t* mask;
-  const f32x4_t* W1;      // packed [hid x de]
-  const float* b1;
-  const f32x4_t* W2;      // packed [C x hid] (one row block)
-  const float* b2;
-  float* logits;          // [B,n,n,C]
-  int B, n, dE_in, C;
-};
-
-int launch_edge_mlp_in(const EdgeMlpInArgs& a, int dE_in, int hid, int de, hipStream_t st);
+int launch_edge_mlp_in(const EdgeMlpUnitArgs& a, int dE_in, int hid, int de, hipStream_t st);
+long long edge_mlp_img_f4(int K1, int N1, int N2);      // -1 if unsupported
+int launch_edge_mlp_pack(const EdgeMlpPackArgs& a, hipStream_t st);
 int launch_edge_layer(const EdgeLayerArgs& a, int dx, int de, int ffe, hipStream_t st);
 long long edge_phase_img_f4(int dx, int de, int ffe);   // float4 count of one layer's phase images, -1 if unsupported
 int launch_edge_unit_pack(const EdgeUnitPackArgs& a, int dx, int de, int ffe, hipStream_t st);
@@ -86,7 +85,7 @@ int launch_edge_unit_pack(const EdgeUnitPackArgs& a, int dx, int de, int ffe, hi
 int launch_build_lists(const uint8_t* mask, int B, int n, int* goff, int* rows, int* row_count, int* units,
                        int* unit_count, hipStream_t st);
 int launch_attn_finish(const AttnFinishArgs& a, int M, hipStream_t st);
-int launch_edge_mlp_out(const EdgeMlpOutArgs& a, int de, int hid, hipStream_t st);
+int launch_edge_mlp_out(const EdgeMlpUnitArgs& a, int de, int hid, int C, hipStream_t st);
 
 struct EdgePoolArgs {     // Etoy pooling straight from a hidden (unsymmetrised) E, n <= 512
   const float* E;         // [B,n,n,de]
@@ -185,6 +184,7 @@ struct NarrowLinearArgs { // row-list Linear with a narrow input (K <= 64), torc
   int N, K, lda, ldc, relu;
 };
 int launch_narrow_linear(const NarrowLinearArgs& a, int M, hipStream_t st);
+int launch_zero_masked_rows(float* X, const uint8_t* mask, int M, int D, hipStream_t st);
 
 struct NodeStatsArgs {    // Xtoy pooling: z[b] = [mean|min|max|var] over valid nodes
   const float* X;         // [B,n,dx]

@@ -332,29 +332,52 @@ __global__ void copy_cols_kernel(const float* src, int lds, float* dst, int ldd,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Row-list Linear for a very narrow input (K <= 64: the raw node features): thread = (valid row, 4 outputs).
+// Row-list Linear for a very narrow input (K <= 64: the raw node features).  The transposed weights ([K][N]) and a
+// slab of 64 input rows sit in LDS; thread = (row of the slab, 4 adjacent outputs).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void narrow_linear_kernel(NarrowLinearArgs a) {
-  const int N4 = a.N >> 2;
-  const long long item = blockIdx.x * 256ll + threadIdx.x;
-  const int ridx = (int)(item / N4), o4 = (int)(item - (long long)ridx * N4);
-  if (ridx >= *a.row_count) return;
-  const long long row = a.rows[ridx];
-  const float* x = a.A + row * a.lda;
-  f32x4 acc = *reinterpret_cast<const f32x4*>(a.bias + 4 * o4);
-  const float* w = a.W + (size_t)(4 * o4) * a.K;
-  for (int k = 0; k < a.K; ++k) {
-    const float xv = x[k];
-    acc[0] += w[k] * xv; acc[1] += w[a.K + k] * xv; acc[2] += w[2 * a.K + k] * xv; acc[3] += w[3 * a.K + k] * xv;
+  extern __shared__ __attribute__((aligned(16))) float nsm[];
+  float* wt = nsm;                       // [K][N]
+  float* xs = nsm + a.K * a.N;           // [64][K]
+  const int tid = threadIdx.x, N4 = a.N >> 2;
+  const int count = *a.row_count;
+  const int r0 = blockIdx.x * 64;
+  if (r0 >= count) return;
+  for (int idx = tid; idx < a.N * a.K; idx += 256) {
+    const int o = idx / a.K, k = idx - o * a.K;
+    wt[k * a.N + o] = a.W[idx];
   }
-  if (a.relu) { acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f); acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f); }
-  *reinterpret_cast<f32x4*>(a.C + row * a.ldc + 4 * o4) = acc;
+  for (int idx = tid; idx < 64 * a.K; idx += 256) {
+    const int r = idx / a.K, k = idx - r * a.K;
+    const int ridx = r0 + r;
+    xs[idx] = ridx < count ? a.A[(long long)a.rows[ridx] * a.lda + k] : 0.f;
+  }
+  __syncthreads();
+  for (int item = tid; item < 64 * N4; item += 256) {
+    const int r = item / N4, o4 = item - r * N4;
+    if (r0 + r >= count) break;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(a.bias + 4 * o4);
+    for (int k = 0; k < a.K; ++k) acc += *reinterpret_cast<const f32x4*>(wt + k * a.N + 4 * o4) * xs[r * a.K + k];
+    if (a.relu) { acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f); acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f); }
+    *reinterpret_cast<f32x4*>(a.C + (long long)a.rows[r0 + r] * a.ldc + 4 * o4) = acc;
+  }
 }
 
 int launch_narrow_linear(const NarrowLinearArgs& a, int M, hipStream_t st) {
-  if (a.N % 4 != 0 || a.ldc % 4 != 0 || a.K > 64) return -1;
-  const long long items = (long long)M * (a.N >> 2);
-  hipLaunchKernelGGL(narrow_linear_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, a);
+  if (a.N % 4 != 0 || a.ldc % 4 != 0 || a.K > 64 || (size_t)(a.K * a.N + 64 * a.K) * 4 > 64 * 1024) return -1;
+  hipLaunchKernelGGL(narrow_linear_kernel, dim3((M + 63) / 64), dim3(256), (size_t)(a.K * a.N + 64 * a.K) * 4, st, a);
+  return 0;
+}
+
+// rows of X[M, D] whose mask byte is 0 <- 0 (one wave per row)
+__global__ __launch_bounds__(256) void zero_masked_rows_kernel(float* X, const uint8_t* mask, int M, int D) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M || mask[row] != 0) return;
+  for (int c = lane; c < D; c += 64) X[(long long)row * D + c] = 0.f;
+}
+
+int launch_zero_masked_rows(float* X, const uint8_t* mask, int M, int D, hipStream_t st) {
+  hipLaunchKernelGGL(zero_masked_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, X, mask, M, D);
   return 0;
 }
 
