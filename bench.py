@@ -9,7 +9,8 @@ synchronize and the MAX over ranks is reported.
 Also printed in the same JSON line:
   roofline      the fused edge-layer kernel (dominant): achieved fp32 TFLOP/s = algorithmic flops of one launch
                 (valid pairs x (6 de dx + 4 de ffE)) / its average duration, measured live with HIP events on the
-                launch stream inside the timed region (every 16th forward); peak = 157.3 TFLOP/s fp32 MFMA.
+                launch stream inside the timed region (every 16th forward); peak = 157.3 TFLOP/s fp32 MFMA;
+                traffic = HBM bytes per launch from the committed rocprofv3 PMC passes of this command.
   cpu_baseline  the CPU oracle (eager torch fp32 "port" of the reference algorithm) timed on this host for a bounded
                 sample (B = 32 graphs, a few reverse steps), extrapolated to graphs/s for the full chain.
 """
@@ -30,6 +31,17 @@ DIMS = dict(hidden_mlp_dims={"X": 256, "E": 128, "y": 128},
 C_E, N_LAYERS, TOP_K, N_MAX = 14, 5, 4, 32
 NU = dict(x=1, c=1, e=1, y=1, e_small=1, e_mid=1, e_large=1)
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def measured_traffic():
+    """HBM-side bytes of one edge-layer launch at this workload, from the committed rocprofv3 PMC passes (FETCH_SIZE
+    doubled per the guide's gfx950 correction + WRITE_SIZE; profiles/README.md).  PMC counters cannot be collected
+    from inside the timed process, so the number is read back from the profile summary; None when it is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "edge_layer_traffic.json")) as f:
+            return float(json.load(f)["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def ns(X, E, y, charges=0):
@@ -159,7 +171,9 @@ def main():
                        "graphs_per_gpu": a.batch, "diffusion_steps": a.T, "valid_pairs_per_forward": valid_pairs,
                        "sampled_edges_last_chain": edges},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": measured_traffic() if a.batch == 512 else None,
+                         "algorithmic_bytes_per_launch": 3 * valid_pairs * hd["de"] * 4,
                          "kernel": "scgg::edge_unit_layer_kernel<8,2,4,16> (fused XEy layer, edge path, fp32 MFMA 16x16x4)",
                          "avg_launch_ms": kernel_ms, "launches_timed": n_launch,
                          "algorithmic_flops_per_launch": flops_per_launch,
