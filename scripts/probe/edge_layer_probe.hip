@@ -52,7 +52,6 @@ int main(int argc, char** argv) {
   a.ln1_g = dev_rand(DE, 1.f, g); a.ln1_b = dev_rand(DE, 1.f, g);
   a.ln2_g = dev_rand(DE, 1.f, g); a.ln2_b = dev_rand(DE, 1.f, g);
   const int nch = (n + 15) / 16;
-  a.stats_part = dev<float>((size_t)B * n * nch * 4 * DE);
   a.attn_part = dev<float>((size_t)B * n * nch * 3 * DX);
   int* units = dev<int>((size_t)B * n * nch); int* cnt = dev<int>(1);
   a.units = units; a.unit_count = cnt;

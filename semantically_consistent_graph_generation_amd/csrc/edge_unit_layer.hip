@@ -20,7 +20,7 @@
 //   FFN2 x de/32    : two row blocks of linE2                                                 (64)
 // copied global -> LDS by LDS-DMA into a double buffer while the previous phase computes; one __syncthreads per phase.
 //
-// Attention: per (row, channel) softmax over the keys with one wave-uniform shift M per (unit, channel block); a unit
+// Attention: per (row, channel) softmax over the keys with one shift M per (unit, 8 channels of a lane row); a unit
 // writes per channel [max | sum p | sum p V] and attn_finish_kernel merges the units of a row (exact rescaling) into
 // newX_pre.  If a channel underflows against M the unit falls back to exact per-channel maxima.
 #include "mfma_chain.h"
@@ -43,18 +43,35 @@ __device__ __forceinline__ float row_max16(float v) {
   v = fmaxf(v, SCGG_DPP(v, 0x140));
   return v;
 }
-__device__ __forceinline__ float row_min16(float v) { return -row_max16(-v); }
+// the same maximum as one fused v_max_f32_dpp per step (hipcc expands fmaxf(x, dpp(x)) into mov_dpp + two canonicalising
+// maxes); the leading s_nop covers the VALU-write -> DPP-read hazard, which the compiler cannot see inside an asm
+#define SCGG_DPP_MAX_STEP(v, ctrl_text) \
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " ctrl_text " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(v) : "v"(v))
+__device__ __forceinline__ float row_max16_fused(float v) {
+  SCGG_DPP_MAX_STEP(v, "quad_perm:[1,0,3,2]");
+  SCGG_DPP_MAX_STEP(v, "quad_perm:[2,3,0,1]");
+  SCGG_DPP_MAX_STEP(v, "row_half_mirror");
+  SCGG_DPP_MAX_STEP(v, "row_mirror");
+  return v;
+}
+// N independent 16-lane sums, step-major: consecutive DPP instructions never read the register the previous one wrote,
+// so no hazard nops are needed between them (a dependent DPP chain pays 2 wait states per step)
+template <int N>
+__device__ __forceinline__ void row_sum16_many(float (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += SCGG_DPP(v[i], 0xB1);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += SCGG_DPP(v[i], 0x4E);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += SCGG_DPP(v[i], 0x141);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += SCGG_DPP(v[i], 0x140);
+}
 // across the four channel groups (same key): lane ^ 16 then lane ^ 32
 __device__ __forceinline__ float groups_sum(float v) {
   v = swap_rows16_sum(v);
   return other_half_sum(v);
 }
-__device__ __forceinline__ float groups_max(float v) {
-  v = swap_rows16_max(v);
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x4 splat4(float v) { f32x4 x = {v, v, v, v}; return x; }
 
@@ -411,22 +428,35 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_kernel(EdgeLayerArgs 
         });
 
         // ---- attention statistics of this (unit, channel block)
-        const float M = groups_max(row_max16(mloc));                    // wave-uniform shift
+        // softmax shift: the maximum over this lane row's 16 keys x 8 channels.  A channel lives in ONE 16-lane row,
+        // so the shift only has to be uniform inside the row, and the row maximum needs no cross-row exchange.
+        const float M = row_max16_fused(mloc);
         const float nM = M == -INFINITY ? 0.f : -M * LOG2E;
         f32x4 cm[2], cs[2], ca[2];
         bool under = false;
+        {
+          float red[16];                                                // 8 x exp(y - M) (0 on invalid keys), 8 x p V
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+          for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pe = __builtin_amdgcn_exp2f(fmaf(y[blk][r], LOG2E, nM));   // exp(y - M); 0 on invalid keys
-            cs[blk][r] = row_sum16(pe);
-            ca[blk][r] = row_sum16(pe * v[blk][r]);
-            cm[blk][r] = M;
-            under |= cs[blk][r] == 0.f;
-          }
-        if (M > -INFINITY && __any(under)) {
-          // a channel underflowed against the block-wide shift: exact per-channel maxima
+            for (int r = 0; r < 4; ++r) {
+              const float pe = __builtin_amdgcn_exp2f(fmaf(y[blk][r], LOG2E, nM));
+              red[4 * blk + r] = pe;
+              red[8 + 4 * blk + r] = pe * v[blk][r];
+            }
+          row_sum16_many<16>(red);
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              cs[blk][r] = red[4 * blk + r];
+              ca[blk][r] = red[8 + 4 * blk + r];
+              cm[blk][r] = M;
+              under |= cs[blk][r] == 0.f;
+            }
+        }
+        if (__any(under && M > -INFINITY)) {
+          // a channel underflowed against the row-wide shift: exact per-channel maxima for the whole unit
 #pragma unroll
           for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
