@@ -340,44 +340,88 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_kernel(EdgeLayerArgs 
   stage_phase_unit<G::PH_F4, NW>(a.phase_img, wbuf, wave, lane);
   int cur = 0;   // buffer holding the phase about to run
 
-  for (int it = 0; it < iters; ++it) {
-    const int uidx = (it * gridDim.x + blockIdx.x) * NW + wave;
-    const bool active = uidx < count;                                  // wave-uniform
-    const int u = active ? a.units[uidx] : 0;
-    const int row = u / nch, jc = u - row * nch;
-    const int b = row / n, i = row - b * n;
-    const float* film = a.film + (long long)b * (4 * DX);
-    if (active) {   // per-row vectors into this wave's LDS slice
-      for (int c = lane * 4; c < 3 * DX; c += 256) {
-        const float* src = c < DX ? a.Q + (long long)row * a.ldqkv + c : film + (c - DX);
-        f32x4 val = ld4(src);
-        if (c < DX) val = val * a.inv_sqrt_df;                         // fold 1/sqrt(df) into the query row
-        *reinterpret_cast<f32x4*>(vecw + c) = val;
-      }
-    }
+  // everything a wave needs to know about a unit
+  struct Unit {
+    bool active, inb, vj, live;
+    int u, row, b, i;
+    long long off_ij, off_ji;
+    const float *Kj, *Vj, *film, *qrow;
+  };
+  auto unit_of = [&](int uidx) {
+    Unit t;
+    t.active = uidx < count;                                           // wave-uniform
+    t.u = t.active ? a.units[uidx] : 0;
+    t.row = t.u / nch;
+    const int jc = t.u - t.row * nch;
+    t.b = t.row / n;
+    t.i = t.row - t.b * n;
     const int j = jc * 16 + p;
-    const bool inb = j < n;
-    const int jj = inb ? j : 0;
-    const bool vj = active && inb && a.mask[b * n + jj] != 0;
-    const bool live = vj && j != i;
-    const long long off_ij = ((long long)row * n + jj) * DE;
-    const long long off_ji = (((long long)b * n + jj) * n + i) * DE;
-    const float* Kj = a.K + ((long long)b * n + jj) * a.ldqkv + 4 * g;
-    const float* Vj = a.V + ((long long)b * n + jj) * a.ldqkv + 4 * g;
-
-    // ---- symmetrised input tile (transformer_model.py:99 of the previous layer, applied on load), e_out accumulators
-    f32x4 e[IBE], accO[IBE];
+    t.inb = j < n;
+    const int jj = t.inb ? j : 0;
+    t.vj = t.active && t.inb && a.mask[t.b * n + jj] != 0;
+    t.live = t.vj && j != t.i;
+    t.off_ij = ((long long)t.row * n + jj) * DE;
+    t.off_ji = (((long long)t.b * n + jj) * n + t.i) * DE;
+    t.Kj = a.K + ((long long)t.b * n + jj) * a.ldqkv + 4 * g;
+    t.Vj = a.V + ((long long)t.b * n + jj) * a.ldqkv + 4 * g;
+    t.film = a.film + (long long)t.b * (4 * DX);
+    t.qrow = a.Q + (long long)t.row * a.ldqkv;
+    return t;
+  };
+  // per-row vectors (Q row / sqrt(df) | y_e_add | y_e_mul+1): global -> registers -> this wave's LDS slice
+  constexpr int NV = (3 * DX + 255) / 256;
+  auto vec_load = [&](const Unit& t, f32x4 (&vr)[NV]) {
 #pragma unroll
-    for (int eb = 0; eb < IBE; ++eb) {
-      if (live) {
-        const f32x4 x0 = ld4(a.E_in + off_ij + 16 * eb + 4 * g);
-        const f32x4 x1 = ld4(a.E_in + off_ji + 16 * eb + 4 * g);
-        e[eb] = 0.5f * (x0 + x1);
-      } else {
-        e[eb] = splat4(0.f);
+    for (int k = 0; k < NV; ++k) {
+      const int c = lane * 4 + 256 * k;
+      if (t.active && c < 3 * DX) {
+        vr[k] = ld4(c < DX ? t.qrow + c : t.film + (c - DX));
+        if (c < DX) vr[k] = vr[k] * a.inv_sqrt_df;                     // fold 1/sqrt(df) into the query row
       }
-      accO[eb] = ld4(a.b_out + 16 * eb + 4 * g);
     }
+  };
+  auto vec_store = [&](const Unit& t, const f32x4 (&vr)[NV]) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = lane * 4 + 256 * k;
+      if (t.active && c < 3 * DX) *reinterpret_cast<f32x4*>(vecw + c) = vr[k];
+    }
+  };
+  // symmetrised input tile (transformer_model.py:99 of the previous layer, applied on load): raw loads / combination
+  auto tile_load = [&](const Unit& t, f32x4 (&x0)[IBE], f32x4 (&x1)[IBE]) {
+#pragma unroll
+    for (int eb = 0; eb < IBE; ++eb)
+      if (t.live) {
+        x0[eb] = ld4(a.E_in + t.off_ij + 16 * eb + 4 * g);
+        x1[eb] = ld4(a.E_in + t.off_ji + 16 * eb + 4 * g);
+      }
+  };
+  auto tile_make = [&](const Unit& t, const f32x4 (&x0)[IBE], const f32x4 (&x1)[IBE], f32x4 (&e)[IBE]) {
+#pragma unroll
+    for (int eb = 0; eb < IBE; ++eb) e[eb] = t.live ? 0.5f * (x0[eb] + x1[eb]) : splat4(0.f);
+  };
+
+  // first unit: loaded synchronously; every later unit is fetched during the FFN phases of its predecessor (its loads
+  // would otherwise stall all the waves of the workgroup at once, right after the unit boundary)
+  Unit un = unit_of(blockIdx.x * NW + wave);
+  f32x4 e[IBE];
+  {
+    f32x4 vr[NV], x0[IBE], x1[IBE];
+    vec_load(un, vr);
+    tile_load(un, x0, x1);
+    vec_store(un, vr);
+    tile_make(un, x0, x1, e);
+  }
+
+  for (int it = 0; it < iters; ++it) {
+    const bool active = un.active, inb = un.inb, vj = un.vj, live = un.live;
+    const int u = un.u;
+    const long long off_ij = un.off_ij;
+    const float *Kj = un.Kj, *Vj = un.Vj;
+    const Unit nx = unit_of(((it + 1) * gridDim.x + blockIdx.x) * NW + wave);
+    f32x4 accO[IBE];
+#pragma unroll
+    for (int eb = 0; eb < IBE; ++eb) accO[eb] = ld4(a.b_out + 16 * eb + 4 * g);
 
     f32x4 fa[2], fb[2];                                                 // A fragments: group in use / group in flight
     // ================================================================== channel-block phases
@@ -484,11 +528,13 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_kernel(EdgeLayerArgs 
 
     // ================================================================== E <- LN1(E + newE), FFN phases
     f32x4 hid[IBF];
+    f32x4 nvr[NV], nx0[IBE], nx1[IBE];                                  // next unit, in flight
 #pragma unroll
     for (int f = 0; f < NFB / 2; ++f) {
       __syncthreads();
       stage_phase_unit<G::PH_F4, NW>(a.phase_img + (size_t)(NXB + f + 1) * G::PH_F4, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
       const f32x4* W = wbuf + cur * G::PH_F4;
+      if (f == 0) vec_load(nx, nvr);                                    // FiLM reads of this unit are over
       if (active) {
         load_frags2(fa, W, lane);
         if (f == 0) {
@@ -514,6 +560,10 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_kernel(EdgeLayerArgs 
       __syncthreads();
       const int nxt = (NXB + NFB / 2 + rb + 1) % NPH;                   // wraps to the first phase of the next unit
       stage_phase_unit<G::PH_F4, NW>(a.phase_img + (size_t)nxt * G::PH_F4, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
+      if (rb == 0) {
+        vec_store(nx, nvr);
+        tile_load(nx, nx0, nx1);
+      }
       const f32x4* W = wbuf + cur * G::PH_F4;
       if (active) {
         load_frags2(fa, W, lane);
@@ -537,6 +587,8 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_kernel(EdgeLayerArgs 
         for (int eb = 0; eb < IBE; ++eb) *reinterpret_cast<f32x4*>(dst + 16 * eb) = live ? e[eb] : splat4(0.f);
       }
     }
+    tile_make(nx, nx0, nx1, e);
+    un = nx;
   }
 }
 
