@@ -47,7 +47,17 @@ int main(int argc, char** argv) {
   float* qkv = dev_rand((size_t)B * n * 3 * DX, 1.f, g);
   a.Q = qkv; a.K = qkv + DX; a.V = qkv + 2 * DX; a.ldqkv = 3 * DX;
   a.film = dev_rand((size_t)B * 4 * DX, 1.f, g);
-  a.phase_img = (const scgg::f32x4_t*)dev_rand((size_t)scgg::edge_phase_img_f4(DX, DE, FFE) * 4, 0.1f, g);
+  {  // phase images from raw weights, through the library's own pack kernel (fp32 or bf16x3 images, per SCGG_EDGE_MODE)
+    scgg::EdgeUnitPackArgs pa{};
+    pa.W_mul = dev_rand((size_t)DX * DE, 0.1f, g); pa.b_mul = dev_rand(DX, 0.1f, g);
+    pa.W_add = dev_rand((size_t)DX * DE, 0.1f, g); pa.b_add = dev_rand(DX, 0.1f, g);
+    pa.W_out = dev_rand((size_t)DE * DX, 0.1f, g);
+    pa.W_ff1 = dev_rand((size_t)FFE * DE, 0.1f, g); pa.b_ff1 = dev_rand(FFE, 0.1f, g);
+    pa.W_ff2 = dev_rand((size_t)DE * FFE, 0.1f, g); pa.b_ff2 = dev_rand(DE, 0.1f, g);
+    pa.img = dev<scgg::f32x4_t>((size_t)scgg::edge_phase_img_f4(DX, DE, FFE));
+    if (scgg::launch_edge_unit_pack(pa, DX, DE, FFE, 0) != 0) { fprintf(stderr, "pack failed\n"); return 1; }
+    a.phase_img = pa.img;
+  }
   a.b_out = dev_rand(DE, 1.f, g);
   a.ln1_g = dev_rand(DE, 1.f, g); a.ln1_b = dev_rand(DE, 1.f, g);
   a.ln2_g = dev_rand(DE, 1.f, g); a.ln2_b = dev_rand(DE, 1.f, g);

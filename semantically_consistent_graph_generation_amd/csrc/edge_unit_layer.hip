@@ -23,6 +23,8 @@
 // Attention: per (row, channel) softmax over the keys with one shift M per (unit, 8 channels of a lane row); a unit
 // writes per channel [max | sum p | sum p V] and attn_finish_kernel merges the units of a row (exact rescaling) into
 // newX_pre.  If a channel underflows against M the unit falls back to exact per-channel maxima.
+#include <stdlib.h>
+
 #include "mfma_chain.h"
 #include "kernels.h"
 
@@ -250,17 +252,22 @@ __global__ __launch_bounds__(512) void edge_unit_pack_kernel(EdgeUnitPackArgs a)
   }
 }
 
-// LDS-DMA copy of one phase image into buf: wave w issues the 64-float4 pieces w, w+NW, ... (each 1 KiB, lane-linear)
+// LDS-DMA copy of one phase image into buf: wave w issues the 64-float4 pieces w, w+NW, ... (each 1 KiB, lane-linear).
+// The global address is (uniform base of the piece row) + (one 32-bit lane offset): the saddr form of the instruction,
+// so that no per-phase 64-bit address vectors are kept (hoisted out of the unit loop they cost ~30 VGPRs and spilled, and a
+// scratch reload in front of a DMA instruction waits for vmcnt(0), i.e. for every DMA and prefetch in flight).
 template <int PH_F4, int NW>
 __device__ __forceinline__ void stage_phase_unit(const f32x4* __restrict__ src, f32x4* buf, int wave, int lane) {
   static_assert(PH_F4 % 64 == 0, "phase image must be whole wave instructions");
+  unsigned voff = (unsigned)(wave * 64 + lane) * 16u;
+  asm volatile("" : "+v"(voff));   // opaque per call: keeps (uniform base) + zext(lane offset) from being re-associated
 #pragma unroll
   for (int s = 0; s < (PH_F4 / 64 + NW - 1) / NW; ++s) {
     const int piece = wave + NW * s;                                  // wave-uniform
+    typedef const __attribute__((address_space(1))) char* gptr;
+    const gptr base = (gptr)(reinterpret_cast<const char*>(src)) + (size_t)s * NW * 1024;   // uniform
     if (piece < PH_F4 / 64)
-      __builtin_amdgcn_global_load_lds(
-          reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(src + piece * 64 + lane)),
-          (__attribute__((address_space(3))) void*)(buf + piece * 64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(base + voff, (__attribute__((address_space(3))) void*)(buf + piece * 64), 16, 0, 0);
   }
 }
 
@@ -592,6 +599,484 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_kernel(EdgeLayerArgs 
   }
 }
 
+// =========================================================================================================
+// The same layer on the bf16 matrix pipe with fp32 accuracy ("x3" path).
+//
+// On gfx950 an fp32 MFMA runs at the vector rate and its time adds to the VALU time of the SIMD; a bf16 MFMA is 16x
+// faster and executes beside the VALU.  Every fp32 operand is therefore split EXACTLY into three bf16 terms by
+// truncation (x = h + m + l, 8 mantissa bits each, |x - h - m - l| <= 2^-24 |x|) and a product is evaluated as the six
+// leading partial products  hl' + lh' + mm' + mh' + hm' + hh'  on v_mfma_f32_16x16x32_bf16 (bf16 x bf16 products are
+// exact in the fp32 accumulator): the dropped terms are below 2^-24 relative, i.e. the result has fp32 accuracy, at
+// 6/16 of the fp32 MFMA time.  Weights are split once at pack time, activations per 32-channel chunk in registers
+// (5.5 VALU per value: and / sub / and / sub + three byte-permute packs per pair).
+//
+// Layouts.  C16 as above for everything that is not an MFMA operand.  K runs in chunks of 32 channels = two C16 blocks:
+// lane (key p, group g) supplies the 8 k-slots  [blk0 r=0..3 | blk1 r=0..3]  = channels 32q + {4g..4g+3, 16+4g..16+4g+3};
+// the weight fragment of (16-row output block ob, chunk q) holds, for lane (o = l & 15, g), W[16ob+o][the same 8
+// channels] -- one 16-byte LDS read per term.  A phase image is a list of such blocks (3 terms x 1 KiB each).
+// =========================================================================================================
+#ifdef SCGG_STAMP
+__device__ unsigned long long g_stamps[8][96];
+#define STAMP(k)                                                                                        \
+  do {                                                                                                  \
+    if (blockIdx.x == 0 && it == 1 && lane == 0) g_stamps[wave][k] = __builtin_amdgcn_s_memtime();      \
+  } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int NXB, int NEB, int NFB>
+struct UnitGeomX3 {
+  static constexpr int DX = 32 * NXB, DE = 32 * NEB, FFE = 32 * NFB;
+  static constexpr int IBE = DE / 16, IBF = FFE / 16;
+  static constexpr int QE = NEB, QF = NFB;                   // 32-channel K chunks of the E width / FFN width
+  static constexpr int B_CB = 4 * QE + IBE;                  // blocks of a channel-block phase: e_mul, e_add, e_out slice
+  static constexpr int B_F1 = 4 * QE;                        // four 16-row blocks of linE1
+  static constexpr int B_F2 = 2 * QF;                        // two 16-row blocks of linE2
+  static constexpr int BMAX = B_CB > B_F1 ? (B_CB > B_F2 ? B_CB : B_F2) : (B_F1 > B_F2 ? B_F1 : B_F2);
+  static constexpr int WMAX = BMAX * 192;                    // float4 slots: 3 terms x 64 lanes per block
+  static constexpr int PH_F4 = WMAX + 64;                    // + bias area (fp32, as in the fp32 path)
+  static constexpr int NPH = NXB + NFB / 2 + NEB;
+  static constexpr size_t lds_bytes(int nw) { return (size_t)2 * PH_F4 * 16 + (size_t)nw * 3 * DX * 4; }
+};
+
+// exact three-way bf16 split of 8 fp32 values (two C16 blocks of one lane) into MFMA operand form
+__device__ __forceinline__ void split3(const f32x4& b0, const f32x4& b1, u32x4& hi, u32x4& mid, u32x4& lo) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const float x0 = d < 2 ? b0[2 * d] : b1[2 * d - 4], x1 = d < 2 ? b0[2 * d + 1] : b1[2 * d - 3];
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    hi[d] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                 // [bf16(x1) : bf16(x0)], truncating
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    mid[d] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    lo[d] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+  }
+}
+
+struct Frag3 { u32x4 h, m, l; };   // one weight block: the three bf16 terms of this lane's 8 k-slots
+
+__device__ __forceinline__ void load_frag3(Frag3& f, const f32x4* w, int lane) {
+  const u32x4* p = reinterpret_cast<const u32x4*>(w);
+  f.h = p[lane];
+  f.m = p[64 + lane];
+  f.l = p[128 + lane];
+}
+
+// acc += W . x with fp32 accuracy: the six leading partial products, smallest first
+__device__ __forceinline__ void mfma_x3(f32x4& acc, const Frag3& w, const u32x4& xh, const u32x4& xm, const u32x4& xl) {
+#define SCGG_BF(v) __builtin_bit_cast(bf16x8, v)
+#ifdef SCGG_X3_SPLIT_ACC
+  // two interleaved chains (small terms from zero, large terms on acc): no MFMA waits for its predecessor
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(w.l), SCGG_BF(xh), s, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(w.m), SCGG_BF(xh), acc, 0, 0, 0);
+  s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(w.h), SCGG_BF(xl), s, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(w.h), SCGG_BF(xm), acc, 0, 0, 0);
+  s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(w.m), SCGG_BF(xm), s, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(w.h), SCGG_BF(xh), acc, 0, 0, 0);
+  acc += s;
+#else
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(w.l), SCGG_BF(xh), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(w.h), SCGG_BF(xl), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(w.m), SCGG_BF(xm), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(w.m), SCGG_BF(xh), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(w.h), SCGG_BF(xm), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(w.h), SCGG_BF(xh), acc, 0, 0, 0);
+#endif
+#undef SCGG_BF
+}
+
+// NB weight blocks starting at W (192 float4 slots each); block t+1 is read from LDS under the MFMAs of block t.  P0 says
+// which register set holds block 0 on entry (0: fa, 1: fb); on exit the set (P0 + NB) & 1 holds the block at `after`.
+template <int NB, int P0, class Body>
+__device__ __forceinline__ void block_pipeline(const f32x4* W, const f32x4* after, Frag3& fa, Frag3& fb, int lane, Body body) {
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+    Frag3& cur = ((t + P0) & 1) ? fb : fa;
+    Frag3& nxt = ((t + P0) & 1) ? fa : fb;
+    if (t + 1 < NB) load_frag3(nxt, W + (t + 1) * 192, lane);
+    else if (after != nullptr) load_frag3(nxt, after, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    body(t, cur);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Phase images of the x3 path from the raw (torch layout) weights; block order = order of use:
+//   cb phase : e_mul (q-major: for q, for ob = 0,1: rows 32cb+16ob) | e_add likewise | e_out rows 16ob (ob = 0..IBE-1), cols
+//              32cb..32cb+31
+//   FFN1 f   : linE1: for q, for ob = 0..3: rows 64f+16ob
+//   FFN2 rb  : linE2: for q, for ob = 0,1: rows 32rb+16ob
+// bias area as in the fp32 path.
+template <int NXB, int NEB, int NFB>
+__global__ __launch_bounds__(512) void edge_unit_pack_x3_kernel(EdgeUnitPackArgs a) {
+  using G = UnitGeomX3<NXB, NEB, NFB>;
+  constexpr int DX = G::DX, DE = G::DE, FFE = G::FFE, IBE = G::IBE, QE = G::QE, QF = G::QF;
+  const int ph = blockIdx.x;
+  u32x4* img = reinterpret_cast<u32x4*>(a.img) + (size_t)ph * G::PH_F4;
+  for (int idx = threadIdx.x; idx < G::PH_F4; idx += blockDim.x) {
+    u32x4 out = {0u, 0u, 0u, 0u};
+    if (idx < G::WMAX) {
+      const int t = idx / 192, term = (idx % 192) >> 6, l = idx & 63;
+      const float* W = nullptr;
+      int row0 = 0, col0 = 0, K = 0;
+      if (ph < NXB) {
+        const int cb = ph;
+        if (t < 4 * QE) {
+          W = t < 2 * QE ? a.W_mul : a.W_add;
+          const int rem = t % (2 * QE);
+          row0 = 32 * cb + 16 * (rem & 1); col0 = 32 * (rem >> 1); K = DE;
+        } else if (t < 4 * QE + IBE) {
+          W = a.W_out; row0 = 16 * (t - 4 * QE); col0 = 32 * cb; K = DX;
+        }
+      } else if (ph < NXB + NFB / 2) {
+        const int f = ph - NXB;
+        if (t < 4 * QE) { W = a.W_ff1; row0 = 64 * f + 16 * (t & 3); col0 = 32 * (t >> 2); K = DE; }
+      } else {
+        const int rb = ph - NXB - NFB / 2;
+        if (t < 2 * QF) { W = a.W_ff2; row0 = 32 * rb + 16 * (t & 1); col0 = 32 * (t >> 1); K = FFE; }
+      }
+      if (W != nullptr) {
+        const int o = row0 + (l & 15), g = l >> 4;
+        unsigned hw[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int col = col0 + (i < 4 ? 4 * g + i : 16 + 4 * g + i - 4);
+          float x = W[(size_t)o * K + col];
+          for (int tt = 0; tt < term; ++tt) x = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+          hw[i] = __float_as_uint(x) >> 16;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) out[d] = hw[2 * d] | (hw[2 * d + 1] << 16);
+      }
+    } else if (idx < G::WMAX + 16) {
+      const int fo = (idx - G::WMAX) * 4;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (ph < NXB) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fo < 32 ? a.b_mul[32 * ph + fo + e] + 1.0f : a.b_add[32 * ph + fo - 32 + e];
+      } else if (ph < NXB + NFB / 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = a.b_ff1[64 * (ph - NXB) + fo + e];
+      } else if (fo < 32) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = a.b_ff2[32 * (ph - NXB - NFB / 2) + fo + e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[e] = __float_as_uint(v[e]);
+    }
+    img[idx] = out;
+  }
+}
+
+template <int NXB, int NEB, int NFB, int NW>
+__global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerArgs a) {
+  using G = UnitGeomX3<NXB, NEB, NFB>;
+  constexpr int DX = G::DX, DE = G::DE, IBE = G::IBE, IBF = G::IBF, NPH = G::NPH, QE = G::QE, QF = G::QF;
+  static_assert(NFB % 2 == 0, "dim_ffE must be a multiple of 64");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* wbuf = reinterpret_cast<f32x4*>(smem);                        // [2][PH_F4]
+  float* fl = reinterpret_cast<float*>(wbuf + 2 * G::PH_F4);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const bool late = __builtin_amdgcn_readfirstlane(wave / (NW / 2)) & 1;   // wave w and w + NW/2 share a SIMD
+  float* vecw = fl + wave * (3 * DX);                                  // Q row / sqrt(df) | y_e_add | y_e_mul+1
+  const int n = a.n;
+  const int nch = (n + 15) >> 4;
+  const int count = *a.unit_count;
+  const int per_iter = NW * gridDim.x;
+  const int iters = (count + per_iter - 1) / per_iter;
+  constexpr float LOG2E = 1.4426950408889634f;
+
+  stage_phase_unit<G::PH_F4, NW>(a.phase_img, wbuf, wave, lane);
+  int cur = 0;   // buffer holding the phase about to run
+
+  struct Unit {
+    bool active, inb, vj, live;
+    int u, row, b, i;
+    long long off_ij, off_ji;
+    const float *Kj, *Vj, *film, *qrow;
+  };
+  auto unit_of = [&](int uidx) {
+    Unit t;
+    t.active = uidx < count;                                           // wave-uniform
+    t.u = t.active ? a.units[uidx] : 0;
+    t.row = t.u / nch;
+    const int jc = t.u - t.row * nch;
+    t.b = t.row / n;
+    t.i = t.row - t.b * n;
+    const int j = jc * 16 + p;
+    t.inb = j < n;
+    const int jj = t.inb ? j : 0;
+    t.vj = t.active && t.inb && a.mask[t.b * n + jj] != 0;
+    t.live = t.vj && j != t.i;
+    t.off_ij = ((long long)t.row * n + jj) * DE;
+    t.off_ji = (((long long)t.b * n + jj) * n + t.i) * DE;
+    t.Kj = a.K + ((long long)t.b * n + jj) * a.ldqkv + 4 * g;
+    t.Vj = a.V + ((long long)t.b * n + jj) * a.ldqkv + 4 * g;
+    t.film = a.film + (long long)t.b * (4 * DX);
+    t.qrow = a.Q + (long long)t.row * a.ldqkv;
+    return t;
+  };
+  constexpr int NV = (3 * DX + 255) / 256;
+  auto vec_load = [&](const Unit& t, f32x4 (&vr)[NV]) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = lane * 4 + 256 * k;
+      if (t.active && c < 3 * DX) {
+        vr[k] = ld4(c < DX ? t.qrow + c : t.film + (c - DX));
+        if (c < DX) vr[k] = vr[k] * a.inv_sqrt_df;                     // fold 1/sqrt(df) into the query row
+      }
+    }
+  };
+  auto vec_store = [&](const Unit& t, const f32x4 (&vr)[NV]) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = lane * 4 + 256 * k;
+      if (t.active && c < 3 * DX) *reinterpret_cast<f32x4*>(vecw + c) = vr[k];
+    }
+  };
+  auto tile_load = [&](const Unit& t, f32x4 (&x0)[IBE], f32x4 (&x1)[IBE]) {
+#pragma unroll
+    for (int eb = 0; eb < IBE; ++eb)
+      if (t.live) {
+        x0[eb] = ld4(a.E_in + t.off_ij + 16 * eb + 4 * g);
+        x1[eb] = ld4(a.E_in + t.off_ji + 16 * eb + 4 * g);
+      }
+  };
+  auto tile_make = [&](const Unit& t, const f32x4 (&x0)[IBE], const f32x4 (&x1)[IBE], f32x4 (&e)[IBE]) {
+#pragma unroll
+    for (int eb = 0; eb < IBE; ++eb) e[eb] = t.live ? 0.5f * (x0[eb] + x1[eb]) : splat4(0.f);
+  };
+
+  Unit un = unit_of(blockIdx.x * NW + wave);
+  f32x4 e[IBE];
+  {
+    f32x4 vr[NV], x0[IBE], x1[IBE];
+    vec_load(un, vr);
+    tile_load(un, x0, x1);
+    vec_store(un, vr);
+    tile_make(un, x0, x1, e);
+  }
+
+  for (int it = 0; it < iters; ++it) {
+    const bool active = un.active, inb = un.inb, vj = un.vj, live = un.live;
+    const int u = un.u;
+    const long long off_ij = un.off_ij;
+    const float *Kj = un.Kj, *Vj = un.Vj;
+    const Unit nx = unit_of(((it + 1) * gridDim.x + blockIdx.x) * NW + wave);
+    f32x4 accO[IBE];
+#pragma unroll
+    for (int eb = 0; eb < IBE; ++eb) accO[eb] = ld4(a.b_out + 16 * eb + 4 * g);
+    // the unit's E tile as MFMA operand: three bf16 terms per 32-channel chunk, kept through the channel-block phases
+    u32x4 eh[QE], em[QE], el[QE];
+#pragma unroll
+    for (int q = 0; q < QE; ++q) split3(e[2 * q], e[2 * q + 1], eh[q], em[q], el[q]);
+
+    Frag3 fa, fb;
+    STAMP(0);
+    // ---- attention statistics of one (unit, channel block), as in the fp32 kernel.  The waves of a workgroup run them in
+    // two groups: the first half right after the matrix part of the phase, the second half (the SIMD partners of the
+    // first) at the start of the NEXT phase, so that on every SIMD one wave is in its VALU-bound softmax part while the
+    // other streams weights through the matrix pipe, instead of both doing the same thing in lockstep behind the barrier.
+    f32x4 y[2], v[2];
+    float mloc = -INFINITY;
+    auto softmax_part = [&](int cb) {
+      const float M = row_max16_fused(mloc);
+      const float nM = M == -INFINITY ? 0.f : -M * LOG2E;
+      f32x4 cm[2], cs[2], ca[2];
+      bool under = false;
+      {
+        float red[16];                                                // 8 x exp(y - M) (0 on invalid keys), 8 x p V
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pe = __builtin_amdgcn_exp2f(fmaf(y[blk][r], LOG2E, nM));
+            red[4 * blk + r] = pe;
+            red[8 + 4 * blk + r] = pe * v[blk][r];
+          }
+        row_sum16_many<16>(red);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            cs[blk][r] = red[4 * blk + r];
+            ca[blk][r] = red[8 + 4 * blk + r];
+            cm[blk][r] = M;
+            under |= cs[blk][r] == 0.f;
+          }
+      }
+#ifdef SCGG_NO_FALLBACK
+      if (false) {
+#else
+      if (__any(under && M > -INFINITY)) {
+#endif
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float yy = y[blk][r];
+            const float mx = row_max16(yy);
+            const float ex = yy == -INFINITY ? 0.f : __expf(yy - mx);
+            cm[blk][r] = mx;
+            cs[blk][r] = row_sum16(ex);
+            ca[blk][r] = row_sum16(ex * v[blk][r]);
+          }
+      }
+      if (p == 0) {
+        float* dst = a.attn_part + (long long)u * (3 * DX) + 32 * cb + 4 * g;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          *reinterpret_cast<f32x4*>(dst + 16 * blk) = cm[blk];
+          *reinterpret_cast<f32x4*>(dst + DX + 16 * blk) = cs[blk];
+          *reinterpret_cast<f32x4*>(dst + 2 * DX + 16 * blk) = ca[blk];
+        }
+      }
+    };
+    // ================================================================== channel-block phases
+#pragma unroll 1
+    for (int cb = 0; cb < NXB; ++cb) {
+      STAMP(1 + 6 * cb);
+      __syncthreads();
+      STAMP(2 + 6 * cb);
+      stage_phase_unit<G::PH_F4, NW>(a.phase_img + (size_t)(cb + 1) * G::PH_F4, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
+      const f32x4* W = wbuf + cur * G::PH_F4;
+      if (active) {
+        f32x4 k[2], vn[2], a1[2], a2[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          k[blk] = ld4(Kj + 32 * cb + 16 * blk);
+          vn[blk] = ld4(Vj + 32 * cb + 16 * blk);
+        }
+        if (late && cb > 0) softmax_part(cb - 1);
+        load_frag3(fa, W, lane);
+        const float* bias = reinterpret_cast<const float*>(W + G::WMAX);
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+          a1[ob] = ld4(bias + 16 * ob + 4 * g);                         // e_mul bias + 1
+          a2[ob] = ld4(bias + 32 + 16 * ob + 4 * g);                    // e_add bias
+        }
+        block_pipeline<4 * QE, 0>(W, W + 4 * QE * 192, fa, fb, lane, [&](int t, const Frag3& w) {
+          const int rem = t % (2 * QE), q = rem >> 1, ob = rem & 1;
+          if (t < 2 * QE) mfma_x3(a1[ob], w, eh[q], em[q], el[q]);      // e_mul
+          else mfma_x3(a2[ob], w, eh[q], em[q], el[q]);                 // e_add
+        });
+        STAMP(3 + 6 * cb);
+        f32x4 z[2];
+        mloc = -INFINITY;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          const int co = 32 * cb + 16 * blk + 4 * g;
+          const f32x4 q = ld4(vecw + co);                               // Q_i / sqrt(df)
+          const f32x4 yea = ld4(vecw + DX + co);
+          const f32x4 yem = ld4(vecw + 2 * DX + co);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float kk = vj ? k[blk][r] : 0.f;
+            const float yy = (q[r] * kk) * a1[blk][r] + a2[blk][r];     // Y = QK/sqrt(df) * (E1+1) + E2
+            z[blk][r] = yea[r] + yem[r] * yy;                           // FiLM by y before e_out
+            y[blk][r] = vj ? yy : -INFINITY;
+            v[blk][r] = vj ? vn[blk][r] : 0.f;
+            mloc = fmaxf(mloc, y[blk][r]);
+          }
+        }
+        // newE += W_out[:, block cb] . z   (the (4 QE)-block pipeline above left the first e_out block in fa)
+        STAMP(4 + 6 * cb);
+        {
+          u32x4 zh, zm, zl;
+          split3(z[0], z[1], zh, zm, zl);
+          block_pipeline<IBE, 0>(W + 4 * QE * 192, nullptr, fa, fb, lane,
+                                 [&](int t, const Frag3& w) { mfma_x3(accO[t], w, zh, zm, zl); });
+        }
+
+        STAMP(5 + 6 * cb);
+        if (!late) softmax_part(cb);
+      }
+      STAMP(6 + 6 * cb);
+      cur ^= 1;
+    }
+
+    // ================================================================== E <- LN1(E + newE), FFN phases
+    f32x4 hid[IBF];
+    f32x4 nvr[NV], nx0[IBE], nx1[IBE];                                  // next unit, in flight
+#pragma unroll
+    for (int f = 0; f < NFB / 2; ++f) {
+      STAMP(1 + 6 * NXB + 2 * f);
+      __syncthreads();
+      STAMP(2 + 6 * NXB + 2 * f);
+      stage_phase_unit<G::PH_F4, NW>(a.phase_img + (size_t)(NXB + f + 1) * G::PH_F4, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
+      const f32x4* W = wbuf + cur * G::PH_F4;
+      if (f == 0) vec_load(nx, nvr);                                    // FiLM reads of this unit are over
+      if (active) {
+        if (f == 0 && late) softmax_part(NXB - 1);
+        load_frag3(fa, W, lane);
+        if (f == 0) {
+#pragma unroll
+          for (int eb = 0; eb < IBE; ++eb) e[eb] += accO[eb];
+          layernorm_c16<IBE>(e, a.ln1_g, a.ln1_b, g);
+#pragma unroll
+          for (int q = 0; q < QE; ++q) split3(e[2 * q], e[2 * q + 1], eh[q], em[q], el[q]);
+        }
+        const float* bias = reinterpret_cast<const float*>(W + G::WMAX);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) hid[4 * f + ob] = ld4(bias + 16 * ob + 4 * g);
+        block_pipeline<4 * QE, 0>(W, nullptr, fa, fb, lane, [&](int t, const Frag3& w) {
+          mfma_x3(hid[4 * f + (t & 3)], w, eh[t >> 2], em[t >> 2], el[t >> 2]);
+        });
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hid[4 * f + ob][r] = fmaxf(hid[4 * f + ob][r], 0.f);
+      }
+      cur ^= 1;
+    }
+#pragma unroll
+    for (int rb = 0; rb < NEB; ++rb) {
+      STAMP(1 + 6 * NXB + NFB + 2 * rb);
+      __syncthreads();
+      STAMP(2 + 6 * NXB + NFB + 2 * rb);
+      const int nxt = (NXB + NFB / 2 + rb + 1) % NPH;                   // wraps to the first phase of the next unit
+      stage_phase_unit<G::PH_F4, NW>(a.phase_img + (size_t)nxt * G::PH_F4, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
+      if (rb == 0) {
+        vec_store(nx, nvr);
+        tile_load(nx, nx0, nx1);
+      }
+      const f32x4* W = wbuf + cur * G::PH_F4;
+      if (active) {
+        load_frag3(fa, W, lane);
+        const float* bias = reinterpret_cast<const float*>(W + G::WMAX);
+        f32x4 f2[2];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) f2[ob] = ld4(bias + 16 * ob + 4 * g);
+        u32x4 hh, hm, hl;
+        block_pipeline<2 * QF, 0>(W, nullptr, fa, fb, lane, [&](int t, const Frag3& w) {
+          if ((t & 1) == 0) split3(hid[2 * (t >> 1)], hid[2 * (t >> 1) + 1], hh, hm, hl);   // chunk q = t >> 1, once
+          mfma_x3(f2[t & 1], w, hh, hm, hl);
+        });
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) e[2 * rb + ob] += f2[ob];
+      }
+      cur ^= 1;
+    }
+    STAMP(1 + 6 * NXB + NFB + 2 * NEB);
+    if (active) {
+      layernorm_c16<IBE>(e, a.ln2_g, a.ln2_b, g);
+      if (inb) {
+        float* dst = a.E_out + off_ij + 4 * g;
+#pragma unroll
+        for (int eb = 0; eb < IBE; ++eb) *reinterpret_cast<f32x4*>(dst + 16 * eb) = live ? e[eb] : splat4(0.f);
+      }
+    }
+    tile_make(nx, nx0, nx1, e);
+    STAMP(2 + 6 * NXB + NFB + 2 * NEB);
+    un = nx;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // newX_pre[row] = y_x_add + (y_x_mul + 1) * softmax-weighted V, merged over the row's units
 // (transformer_model.py:207-214, :230-232).  One block per valid row, one thread per channel.
@@ -745,10 +1230,21 @@ int launch_edge_pool_stats(const EdgePoolArgs& a, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------
 #define SCGG_UNIT_CASES CASE(8, 2, 4) CASE(4, 2, 4) CASE(1, 1, 2)
 
+// SCGG_EDGE_MODE=f32 selects the plain fp32-MFMA kernel (development A/B switch); default: the x3 path
+static bool edge_x3() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("SCGG_EDGE_MODE");
+    mode = (e != nullptr && e[0] == 'f') ? 0 : 1;
+  }
+  return mode == 1;
+}
+
 long long edge_phase_img_f4(int dx, int de, int ffe) {
-#define CASE(NXB, NEB, NFB)                                \
-  if (dx == 32 * NXB && de == 32 * NEB && ffe == 32 * NFB) \
-    return (long long)UnitGeom<NXB, NEB, NFB>::NPH * UnitGeom<NXB, NEB, NFB>::PH_F4;
+#define CASE(NXB, NEB, NFB)                                                                                   \
+  if (dx == 32 * NXB && de == 32 * NEB && ffe == 32 * NFB)                                                    \
+    return edge_x3() ? (long long)UnitGeomX3<NXB, NEB, NFB>::NPH * UnitGeomX3<NXB, NEB, NFB>::PH_F4           \
+                     : (long long)UnitGeom<NXB, NEB, NFB>::NPH * UnitGeom<NXB, NEB, NFB>::PH_F4;
   SCGG_UNIT_CASES
 #undef CASE
   return -1;
@@ -757,7 +1253,10 @@ long long edge_phase_img_f4(int dx, int de, int ffe) {
 int launch_edge_unit_pack(const EdgeUnitPackArgs& a, int dx, int de, int ffe, hipStream_t st) {
 #define CASE(NXB, NEB, NFB)                                                                                        \
   if (dx == 32 * NXB && de == 32 * NEB && ffe == 32 * NFB) {                                                       \
-    hipLaunchKernelGGL((edge_unit_pack_kernel<NXB, NEB, NFB>), dim3(UnitGeom<NXB, NEB, NFB>::NPH), dim3(512), 0, st, a); \
+    if (edge_x3())                                                                                                 \
+      hipLaunchKernelGGL((edge_unit_pack_x3_kernel<NXB, NEB, NFB>), dim3(UnitGeomX3<NXB, NEB, NFB>::NPH), dim3(512), 0, st, a); \
+    else                                                                                                           \
+      hipLaunchKernelGGL((edge_unit_pack_kernel<NXB, NEB, NFB>), dim3(UnitGeom<NXB, NEB, NFB>::NPH), dim3(512), 0, st, a); \
     return 0;                                                                                                      \
   }
   SCGG_UNIT_CASES
@@ -771,11 +1270,11 @@ int launch_edge_unit_pack(const EdgeUnitPackArgs& a, int dx, int de, int ffe, hi
 
 template <int NXB, int NEB, int NFB>
 static int launch_one(const EdgeLayerArgs& a, int n_cu, hipStream_t st) {
-  using G = UnitGeom<NXB, NEB, NFB>;
   constexpr int NW = SCGG_UNIT_WAVES;
   static bool attr_set = false;
-  auto kern = edge_unit_layer_kernel<NXB, NEB, NFB, NW>;
-  const size_t lds = G::lds_bytes(NW);
+  const bool x3 = edge_x3();
+  auto kern = x3 ? edge_unit_layer_x3_kernel<NXB, NEB, NFB, NW> : edge_unit_layer_kernel<NXB, NEB, NFB, NW>;
+  const size_t lds = x3 ? UnitGeomX3<NXB, NEB, NFB>::lds_bytes(NW) : UnitGeom<NXB, NEB, NFB>::lds_bytes(NW);
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess)
