@@ -259,6 +259,9 @@ __global__ __launch_bounds__(512) void edge_unit_pack_kernel(EdgeUnitPackArgs a)
 template <int PH_F4, int NW>
 __device__ __forceinline__ void stage_phase_unit(const f32x4* __restrict__ src, f32x4* buf, int wave, int lane) {
   static_assert(PH_F4 % 64 == 0, "phase image must be whole wave instructions");
+#ifdef SCGG_ABL_NO_DMA
+  return;
+#endif
   unsigned voff = (unsigned)(wave * 64 + lane) * 16u;
   asm volatile("" : "+v"(voff));   // opaque per call: keeps (uniform base) + zext(lane offset) from being re-associated
 #pragma unroll
@@ -615,15 +618,6 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_kernel(EdgeLayerArgs 
 // the weight fragment of (16-row output block ob, chunk q) holds, for lane (o = l & 15, g), W[16ob+o][the same 8
 // channels] -- one 16-byte LDS read per term.  A phase image is a list of such blocks (3 terms x 1 KiB each).
 // =========================================================================================================
-#ifdef SCGG_STAMP
-__device__ unsigned long long g_stamps[8][96];
-#define STAMP(k)                                                                                        \
-  do {                                                                                                  \
-    if (blockIdx.x == 0 && it == 1 && lane == 0) g_stamps[wave][k] = __builtin_amdgcn_s_memtime();      \
-  } while (0)
-#else
-#define STAMP(k) do { } while (0)
-#endif
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -633,12 +627,13 @@ struct UnitGeomX3 {
   static constexpr int IBE = DE / 16, IBF = FFE / 16;
   static constexpr int QE = NEB, QF = NFB;                   // 32-channel K chunks of the E width / FFN width
   static constexpr int B_CB = 4 * QE + IBE;                  // blocks of a channel-block phase: e_mul, e_add, e_out slice
-  static constexpr int B_F1 = 4 * QE;                        // four 16-row blocks of linE1
-  static constexpr int B_F2 = 2 * QF;                        // two 16-row blocks of linE2
-  static constexpr int BMAX = B_CB > B_F1 ? (B_CB > B_F2 ? B_CB : B_F2) : (B_F1 > B_F2 ? B_F1 : B_F2);
-  static constexpr int WMAX = BMAX * 192;                    // float4 slots: 3 terms x 64 lanes per block
-  static constexpr int PH_F4 = WMAX + 64;                    // + bias area (fp32, as in the fp32 path)
-  static constexpr int NPH = NXB + NFB / 2 + NEB;
+  static constexpr int B_FF = 4 * QE + 2 * IBE;              // blocks of an FFN phase: 64 hidden rows of linE1, their columns of linE2
+  static constexpr int BMAX = B_CB > B_FF ? B_CB : B_FF;
+  static constexpr int BIAS_F4 = 64;                         // fp32 bias area at the head of every phase image
+  static constexpr int CB_F4 = BIAS_F4 + B_CB * 192, FF_F4 = BIAS_F4 + B_FF * 192;   // float4 slots actually used
+  static constexpr int PH_F4 = BIAS_F4 + BMAX * 192;         // stride of the phase images
+  static constexpr int NFF = NFB / 2;                        // FFN phases (64 hidden channels each)
+  static constexpr int NPH = NXB + NFF;
   static constexpr size_t lds_bytes(int nw) { return (size_t)2 * PH_F4 * 16 + (size_t)nw * 3 * DX * 4; }
 };
 
@@ -668,6 +663,10 @@ __device__ __forceinline__ void load_frag3(Frag3& f, const f32x4* w, int lane) {
 
 // acc += W . x with fp32 accuracy: the six leading partial products, smallest first
 __device__ __forceinline__ void mfma_x3(f32x4& acc, const Frag3& w, const u32x4& xh, const u32x4& xm, const u32x4& xl) {
+#ifdef SCGG_ABL_NO_MFMA
+  acc[0] += __uint_as_float(w.h[0] ^ xh[0] ^ w.m[1] ^ xm[1] ^ w.l[2] ^ xl[2]);
+  return;
+#endif
 #define SCGG_BF(v) __builtin_bit_cast(bf16x8, v)
 #ifdef SCGG_X3_SPLIT_ACC
   // two interleaved chains (small terms from zero, large terms on acc): no MFMA waits for its predecessor
@@ -706,22 +705,22 @@ __device__ __forceinline__ void block_pipeline(const f32x4* W, const f32x4* afte
   }
 }
 
-// Phase images of the x3 path from the raw (torch layout) weights; block order = order of use:
+// Phase images of the x3 path from the raw (torch layout) weights: 64 float4 of fp32 biases, then the blocks in order of use:
 //   cb phase : e_mul (q-major: for q, for ob = 0,1: rows 32cb+16ob) | e_add likewise | e_out rows 16ob (ob = 0..IBE-1), cols
-//              32cb..32cb+31
-//   FFN1 f   : linE1: for q, for ob = 0..3: rows 64f+16ob
-//   FFN2 rb  : linE2: for q, for ob = 0,1: rows 32rb+16ob
-// bias area as in the fp32 path.
+//              32cb..32cb+31;   biases: [0,32) e_mul bias + 1, [32,64) e_add bias
+//   FFN f    : linE1: for q, for ob = 0..3: rows 64f+16ob | linE2: for hq = 0,1, for ob = 0..IBE-1: rows 16ob, cols 64f+32hq;
+//              biases: [0,64) linE1 bias of the 64 hidden channels, [64,64+DE) linE2 bias
 template <int NXB, int NEB, int NFB>
 __global__ __launch_bounds__(512) void edge_unit_pack_x3_kernel(EdgeUnitPackArgs a) {
   using G = UnitGeomX3<NXB, NEB, NFB>;
-  constexpr int DX = G::DX, DE = G::DE, FFE = G::FFE, IBE = G::IBE, QE = G::QE, QF = G::QF;
+  constexpr int DX = G::DX, DE = G::DE, FFE = G::FFE, IBE = G::IBE, QE = G::QE;
   const int ph = blockIdx.x;
   u32x4* img = reinterpret_cast<u32x4*>(a.img) + (size_t)ph * G::PH_F4;
   for (int idx = threadIdx.x; idx < G::PH_F4; idx += blockDim.x) {
     u32x4 out = {0u, 0u, 0u, 0u};
-    if (idx < G::WMAX) {
-      const int t = idx / 192, term = (idx % 192) >> 6, l = idx & 63;
+    if (idx >= G::BIAS_F4) {
+      const int bi = idx - G::BIAS_F4;
+      const int t = bi / 192, term = (bi % 192) >> 6, l = bi & 63;
       const float* W = nullptr;
       int row0 = 0, col0 = 0, K = 0;
       if (ph < NXB) {
@@ -733,12 +732,13 @@ __global__ __launch_bounds__(512) void edge_unit_pack_x3_kernel(EdgeUnitPackArgs
         } else if (t < 4 * QE + IBE) {
           W = a.W_out; row0 = 16 * (t - 4 * QE); col0 = 32 * cb; K = DX;
         }
-      } else if (ph < NXB + NFB / 2) {
+      } else {
         const int f = ph - NXB;
         if (t < 4 * QE) { W = a.W_ff1; row0 = 64 * f + 16 * (t & 3); col0 = 32 * (t >> 2); K = DE; }
-      } else {
-        const int rb = ph - NXB - NFB / 2;
-        if (t < 2 * QF) { W = a.W_ff2; row0 = 32 * rb + 16 * (t & 1); col0 = 32 * (t >> 1); K = FFE; }
+        else if (t < 4 * QE + 2 * IBE) {
+          const int tt = t - 4 * QE;
+          W = a.W_ff2; row0 = 16 * (tt % IBE); col0 = 64 * f + 32 * (tt / IBE); K = FFE;
+        }
       }
       if (W != nullptr) {
         const int o = row0 + (l & 15), g = l >> 4;
@@ -753,18 +753,20 @@ __global__ __launch_bounds__(512) void edge_unit_pack_x3_kernel(EdgeUnitPackArgs
 #pragma unroll
         for (int d = 0; d < 4; ++d) out[d] = hw[2 * d] | (hw[2 * d + 1] << 16);
       }
-    } else if (idx < G::WMAX + 16) {
-      const int fo = (idx - G::WMAX) * 4;
+    } else {
+      const int fo = idx * 4;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (ph < NXB) {
+        if (fo < 64) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fo < 32 ? a.b_mul[32 * ph + fo + e] + 1.0f : a.b_add[32 * ph + fo - 32 + e];
-      } else if (ph < NXB + NFB / 2) {
+          for (int e = 0; e < 4; ++e) v[e] = fo < 32 ? a.b_mul[32 * ph + fo + e] + 1.0f : a.b_add[32 * ph + fo - 32 + e];
+        }
+      } else if (fo < 64) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = a.b_ff1[64 * (ph - NXB) + fo + e];
-      } else if (fo < 32) {
+      } else if (fo < 64 + DE) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = a.b_ff2[32 * (ph - NXB - NFB / 2) + fo + e];
+        for (int e = 0; e < 4; ++e) v[e] = a.b_ff2[fo - 64 + e];
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) out[e] = __float_as_uint(v[e]);
@@ -781,8 +783,8 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* wbuf = reinterpret_cast<f32x4*>(smem);                        // [2][PH_F4]
   float* fl = reinterpret_cast<float*>(wbuf + 2 * G::PH_F4);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, g = lane >> 4;
-  const bool late = __builtin_amdgcn_readfirstlane(wave / (NW / 2)) & 1;   // wave w and w + NW/2 share a SIMD
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: everything per unit below stays in SGPRs
   float* vecw = fl + wave * (3 * DX);                                  // Q row / sqrt(df) | y_e_add | y_e_mul+1
   const int n = a.n;
   const int nch = (n + 15) >> 4;
@@ -790,171 +792,125 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
   const int per_iter = NW * gridDim.x;
   const int iters = (count + per_iter - 1) / per_iter;
   constexpr float LOG2E = 1.4426950408889634f;
+  typedef const char* cptr;
+  auto ldo = [](cptr base, unsigned off) { return *reinterpret_cast<const f32x4*>(base + off); };   // scalar base + lane offset
 
-  stage_phase_unit<G::PH_F4, NW>(a.phase_img, wbuf, wave, lane);
+  stage_phase_unit<G::CB_F4, NW>(a.phase_img, wbuf, wave, lane);
   int cur = 0;   // buffer holding the phase about to run
 
+  // A unit = (row (b, i), 16-key chunk jc): all scalar.  The lane's key is j = 16 jc + p.
   struct Unit {
-    bool active, inb, vj, live;
-    int u, row, b, i;
-    long long off_ij, off_ji;
-    const float *Kj, *Vj, *film, *qrow;
+    bool active;
+    int u, row, b, i, j0;
   };
   auto unit_of = [&](int uidx) {
     Unit t;
-    t.active = uidx < count;                                           // wave-uniform
-    t.u = t.active ? a.units[uidx] : 0;
+    t.active = uidx < count;
+    t.u = t.active ? __builtin_amdgcn_readfirstlane(a.units[uidx]) : 0;
     t.row = t.u / nch;
-    const int jc = t.u - t.row * nch;
+    t.j0 = (t.u - t.row * nch) * 16;
     t.b = t.row / n;
     t.i = t.row - t.b * n;
-    const int j = jc * 16 + p;
-    t.inb = j < n;
-    const int jj = t.inb ? j : 0;
-    t.vj = t.active && t.inb && a.mask[t.b * n + jj] != 0;
-    t.live = t.vj && j != t.i;
-    t.off_ij = ((long long)t.row * n + jj) * DE;
-    t.off_ji = (((long long)t.b * n + jj) * n + t.i) * DE;
-    t.Kj = a.K + ((long long)t.b * n + jj) * a.ldqkv + 4 * g;
-    t.Vj = a.V + ((long long)t.b * n + jj) * a.ldqkv + 4 * g;
-    t.film = a.film + (long long)t.b * (4 * DX);
-    t.qrow = a.Q + (long long)t.row * a.ldqkv;
     return t;
+  };
+  auto mask_byte = [&](const Unit& t) -> int {                         // of the lane's key (0 beyond n)
+    const int j = t.j0 + p;
+    return (t.active && j < n) ? (int)a.mask[t.b * n + j] : 0;
   };
   constexpr int NV = (3 * DX + 255) / 256;
   auto vec_load = [&](const Unit& t, f32x4 (&vr)[NV]) {
+    const cptr qrow = reinterpret_cast<cptr>(a.Q + (long long)t.row * a.ldqkv);
+    const cptr film = reinterpret_cast<cptr>(a.film + (long long)t.b * (4 * DX));
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int c = lane * 4 + 256 * k;
-      if (t.active && c < 3 * DX) {
-        vr[k] = ld4(c < DX ? t.qrow + c : t.film + (c - DX));
+      if (c < 3 * DX) {
+        vr[k] = c < DX ? ldo(qrow, 4u * c) : ldo(film, 4u * (c - DX));
         if (c < DX) vr[k] = vr[k] * a.inv_sqrt_df;                     // fold 1/sqrt(df) into the query row
       }
     }
   };
-  auto vec_store = [&](const Unit& t, const f32x4 (&vr)[NV]) {
+  auto vec_store = [&](const f32x4 (&vr)[NV]) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int c = lane * 4 + 256 * k;
-      if (t.active && c < 3 * DX) *reinterpret_cast<f32x4*>(vecw + c) = vr[k];
+      if (c < 3 * DX) *reinterpret_cast<f32x4*>(vecw + c) = vr[k];
     }
   };
-  auto tile_load = [&](const Unit& t, f32x4 (&x0)[IBE], f32x4 (&x1)[IBE]) {
+  // the symmetrised tile row: 0.5 (E[b,i,j,:] + E[b,j,i,:]) on live pairs, 0 elsewhere
+  auto tile_load = [&](const Unit& t, int jj, f32x4 (&x0)[IBE], f32x4 (&x1)[IBE]) {
+    const cptr bij = reinterpret_cast<cptr>(a.E_in + (long long)t.row * n * DE);
+    const cptr bji = reinterpret_cast<cptr>(a.E_in + ((long long)t.b * n * n + t.i) * DE);
+    const unsigned oij = 4u * (jj * DE + 4 * g), oji = 4u * (jj * n * DE + 4 * g);
 #pragma unroll
-    for (int eb = 0; eb < IBE; ++eb)
-      if (t.live) {
-        x0[eb] = ld4(a.E_in + t.off_ij + 16 * eb + 4 * g);
-        x1[eb] = ld4(a.E_in + t.off_ji + 16 * eb + 4 * g);
-      }
-  };
-  auto tile_make = [&](const Unit& t, const f32x4 (&x0)[IBE], const f32x4 (&x1)[IBE], f32x4 (&e)[IBE]) {
-#pragma unroll
-    for (int eb = 0; eb < IBE; ++eb) e[eb] = t.live ? 0.5f * (x0[eb] + x1[eb]) : splat4(0.f);
+    for (int eb = 0; eb < IBE; ++eb) {
+      x0[eb] = ldo(bij, oij + 64u * eb);
+      x1[eb] = ldo(bji, oji + 64u * eb);
+    }
   };
 
   Unit un = unit_of(blockIdx.x * NW + wave);
+  int mk = mask_byte(un);
   f32x4 e[IBE];
-  {
+  if (un.active) {
     f32x4 vr[NV], x0[IBE], x1[IBE];
+    const int j = un.j0 + p, jj = j < n ? j : 0;
+    const bool live = mk != 0 && j != un.i;
     vec_load(un, vr);
-    tile_load(un, x0, x1);
-    vec_store(un, vr);
-    tile_make(un, x0, x1, e);
+    tile_load(un, jj, x0, x1);
+    vec_store(vr);
+#pragma unroll
+    for (int eb = 0; eb < IBE; ++eb) e[eb] = live ? 0.5f * (x0[eb] + x1[eb]) : splat4(0.f);
   }
 
   for (int it = 0; it < iters; ++it) {
-    const bool active = un.active, inb = un.inb, vj = un.vj, live = un.live;
-    const int u = un.u;
-    const long long off_ij = un.off_ij;
-    const float *Kj = un.Kj, *Vj = un.Vj;
+    const bool active = un.active;
+    const int j = un.j0 + p;
+    const bool inb = j < n, vj = mk != 0, live = vj && j != un.i;
+    const int jj = inb ? j : 0;
+    // the next unit: scalars now, the mask byte of the lane's key in flight until the FFN phases
     const Unit nx = unit_of(((it + 1) * gridDim.x + blockIdx.x) * NW + wave);
-    f32x4 accO[IBE];
-#pragma unroll
-    for (int eb = 0; eb < IBE; ++eb) accO[eb] = ld4(a.b_out + 16 * eb + 4 * g);
-    // the unit's E tile as MFMA operand: three bf16 terms per 32-channel chunk, kept through the channel-block phases
-    u32x4 eh[QE], em[QE], el[QE];
-#pragma unroll
-    for (int q = 0; q < QE; ++q) split3(e[2 * q], e[2 * q + 1], eh[q], em[q], el[q]);
+    const int nmk = mask_byte(nx);
 
+    const cptr kbase = reinterpret_cast<cptr>(a.K + (long long)un.b * n * a.ldqkv);
+    const cptr vbase = reinterpret_cast<cptr>(a.V + (long long)un.b * n * a.ldqkv);
+    const unsigned kvoff = 4u * (jj * a.ldqkv + 4 * g);
+
+    // per-layer vectors are re-read per unit (L1/L2 hits): hoisted out of the unit loop they would hold ~80 VGPRs
+    const float *b_out = a.b_out, *ln1_g = a.ln1_g, *ln1_b = a.ln1_b, *ln2_g = a.ln2_g, *ln2_b = a.ln2_b;
+    asm volatile("" : "+s"(b_out), "+s"(ln1_g), "+s"(ln1_b), "+s"(ln2_g), "+s"(ln2_b));
+    f32x4 accO[IBE];
+    u32x4 eh[QE], em[QE], el[QE];                                       // E tile as MFMA operand, kept through the cb phases
     Frag3 fa, fb;
-    STAMP(0);
-    // ---- attention statistics of one (unit, channel block), as in the fp32 kernel.  The waves of a workgroup run them in
-    // two groups: the first half right after the matrix part of the phase, the second half (the SIMD partners of the
-    // first) at the start of the NEXT phase, so that on every SIMD one wave is in its VALU-bound softmax part while the
-    // other streams weights through the matrix pipe, instead of both doing the same thing in lockstep behind the barrier.
-    f32x4 y[2], v[2];
-    float mloc = -INFINITY;
-    auto softmax_part = [&](int cb) {
-      const float M = row_max16_fused(mloc);
-      const float nM = M == -INFINITY ? 0.f : -M * LOG2E;
-      f32x4 cm[2], cs[2], ca[2];
-      bool under = false;
-      {
-        float red[16];                                                // 8 x exp(y - M) (0 on invalid keys), 8 x p V
+    if (active) {
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+      for (int eb = 0; eb < IBE; ++eb) accO[eb] = ld4(b_out + 16 * eb + 4 * g);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pe = __builtin_amdgcn_exp2f(fmaf(y[blk][r], LOG2E, nM));
-            red[4 * blk + r] = pe;
-            red[8 + 4 * blk + r] = pe * v[blk][r];
-          }
-        row_sum16_many<16>(red);
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            cs[blk][r] = red[4 * blk + r];
-            ca[blk][r] = red[8 + 4 * blk + r];
-            cm[blk][r] = M;
-            under |= cs[blk][r] == 0.f;
-          }
-      }
-#ifdef SCGG_NO_FALLBACK
-      if (false) {
-#else
-      if (__any(under && M > -INFINITY)) {
-#endif
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float yy = y[blk][r];
-            const float mx = row_max16(yy);
-            const float ex = yy == -INFINITY ? 0.f : __expf(yy - mx);
-            cm[blk][r] = mx;
-            cs[blk][r] = row_sum16(ex);
-            ca[blk][r] = row_sum16(ex * v[blk][r]);
-          }
-      }
-      if (p == 0) {
-        float* dst = a.attn_part + (long long)u * (3 * DX) + 32 * cb + 4 * g;
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-          *reinterpret_cast<f32x4*>(dst + 16 * blk) = cm[blk];
-          *reinterpret_cast<f32x4*>(dst + DX + 16 * blk) = cs[blk];
-          *reinterpret_cast<f32x4*>(dst + 2 * DX + 16 * blk) = ca[blk];
-        }
-      }
-    };
+      for (int q = 0; q < QE; ++q) split3(e[2 * q], e[2 * q + 1], eh[q], em[q], el[q]);
+    }
+
     // ================================================================== channel-block phases
 #pragma unroll 1
     for (int cb = 0; cb < NXB; ++cb) {
-      STAMP(1 + 6 * cb);
       __syncthreads();
-      STAMP(2 + 6 * cb);
-      stage_phase_unit<G::PH_F4, NW>(a.phase_img + (size_t)(cb + 1) * G::PH_F4, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
-      const f32x4* W = wbuf + cur * G::PH_F4;
+      if (cb + 1 < NXB)
+        stage_phase_unit<G::CB_F4, NW>(a.phase_img + (size_t)(cb + 1) * G::PH_F4, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
+      else
+        stage_phase_unit<G::FF_F4, NW>(a.phase_img + (size_t)(cb + 1) * G::PH_F4, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
+      const float* bias = reinterpret_cast<const float*>(wbuf + cur * G::PH_F4);
+      const f32x4* W = wbuf + cur * G::PH_F4 + G::BIAS_F4;
       if (active) {
         f32x4 k[2], vn[2], a1[2], a2[2];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
-          k[blk] = ld4(Kj + 32 * cb + 16 * blk);
-          vn[blk] = ld4(Vj + 32 * cb + 16 * blk);
+#ifdef SCGG_ABL_NO_KV
+          k[blk] = splat4(0.5f); vn[blk] = splat4(0.25f);
+#else
+          k[blk] = ldo(kbase, kvoff + 4u * (32 * cb + 16 * blk));
+          vn[blk] = ldo(vbase, kvoff + 4u * (32 * cb + 16 * blk));
+#endif
         }
-        if (late && cb > 0) softmax_part(cb - 1);
         load_frag3(fa, W, lane);
-        const float* bias = reinterpret_cast<const float*>(W + G::WMAX);
 #pragma unroll
         for (int ob = 0; ob < 2; ++ob) {
           a1[ob] = ld4(bias + 16 * ob + 4 * g);                         // e_mul bias + 1
@@ -965,9 +921,8 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
           if (t < 2 * QE) mfma_x3(a1[ob], w, eh[q], em[q], el[q]);      // e_mul
           else mfma_x3(a2[ob], w, eh[q], em[q], el[q]);                 // e_add
         });
-        STAMP(3 + 6 * cb);
-        f32x4 z[2];
-        mloc = -INFINITY;
+        f32x4 y[2], v[2], z[2];
+        float mloc = -INFINITY;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
           const int co = 32 * cb + 16 * blk + 4 * g;
@@ -985,95 +940,132 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
           }
         }
         // newE += W_out[:, block cb] . z   (the (4 QE)-block pipeline above left the first e_out block in fa)
-        STAMP(4 + 6 * cb);
         {
           u32x4 zh, zm, zl;
           split3(z[0], z[1], zh, zm, zl);
           block_pipeline<IBE, 0>(W + 4 * QE * 192, nullptr, fa, fb, lane,
                                  [&](int t, const Frag3& w) { mfma_x3(accO[t], w, zh, zm, zl); });
         }
-
-        STAMP(5 + 6 * cb);
-        if (!late) softmax_part(cb);
+        // ---- attention statistics of this (unit, channel block), as in the fp32 kernel
+#ifdef SCGG_ABL_NO_SM
+        if (mloc == 12345.f)
+#endif
+        {
+        const float M = row_max16_fused(mloc);
+        const float nM = M == -INFINITY ? 0.f : -M * LOG2E;
+        f32x4 cm[2], cs[2], ca[2];
+        bool under = false;
+        {
+          float red[16];                                                // 8 x exp(y - M) (0 on invalid keys), 8 x p V
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pe = __builtin_amdgcn_exp2f(fmaf(y[blk][r], LOG2E, nM));
+              red[4 * blk + r] = pe;
+              red[8 + 4 * blk + r] = pe * v[blk][r];
+            }
+          row_sum16_many<16>(red);
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              cs[blk][r] = red[4 * blk + r];
+              ca[blk][r] = red[8 + 4 * blk + r];
+              cm[blk][r] = M;
+              under |= cs[blk][r] == 0.f;
+            }
+        }
+        if (__any(under && M > -INFINITY)) {
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float yy = y[blk][r];
+              const float mx = row_max16(yy);
+              const float ex = yy == -INFINITY ? 0.f : __expf(yy - mx);
+              cm[blk][r] = mx;
+              cs[blk][r] = row_sum16(ex);
+              ca[blk][r] = row_sum16(ex * v[blk][r]);
+            }
+        }
+        if (p == 0) {
+          float* dst = a.attn_part + (long long)un.u * (3 * DX) + 32 * cb + 4 * g;
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk) {
+            *reinterpret_cast<f32x4*>(dst + 16 * blk) = cm[blk];
+            *reinterpret_cast<f32x4*>(dst + DX + 16 * blk) = cs[blk];
+            *reinterpret_cast<f32x4*>(dst + 2 * DX + 16 * blk) = ca[blk];
+          }
+        }
+        }
       }
-      STAMP(6 + 6 * cb);
       cur ^= 1;
     }
 
     // ================================================================== E <- LN1(E + newE), FFN phases
-    f32x4 hid[IBF];
-    f32x4 nvr[NV], nx0[IBE], nx1[IBE];                                  // next unit, in flight
+    // One FFN phase = 64 hidden channels: linE1 + ReLU into 4 register blocks, then their contribution through linE2
+    // accumulated directly onto E (which holds the LN1 output, i.e. the residual).  The next unit's row vectors are fetched
+    // during the first FFN phase and put into this wave's LDS slot at the end of the last (the FiLM reads of this unit
+    // are over); its E tile is fetched during the last FFN phase.
+    f32x4 nvr[NV], nx0[IBE], nx1[IBE];
+    const int nj = nx.j0 + p, njj = nj < n ? nj : 0;
 #pragma unroll
-    for (int f = 0; f < NFB / 2; ++f) {
-      STAMP(1 + 6 * NXB + 2 * f);
+    for (int f = 0; f < G::NFF; ++f) {
       __syncthreads();
-      STAMP(2 + 6 * NXB + 2 * f);
-      stage_phase_unit<G::PH_F4, NW>(a.phase_img + (size_t)(NXB + f + 1) * G::PH_F4, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
-      const f32x4* W = wbuf + cur * G::PH_F4;
-      if (f == 0) vec_load(nx, nvr);                                    // FiLM reads of this unit are over
+      if (f + 1 < G::NFF)
+        stage_phase_unit<G::FF_F4, NW>(a.phase_img + (size_t)(NXB + f + 1) * G::PH_F4, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
+      else                                                              // wraps to the first phase of the next unit
+        stage_phase_unit<G::CB_F4, NW>(a.phase_img, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
+      const float* bias = reinterpret_cast<const float*>(wbuf + cur * G::PH_F4);
+      const f32x4* W = wbuf + cur * G::PH_F4 + G::BIAS_F4;
+      if (f == 0 && nx.active) vec_load(nx, nvr);
+      if (f == G::NFF - 1 && nx.active) tile_load(nx, njj, nx0, nx1);
       if (active) {
-        if (f == 0 && late) softmax_part(NXB - 1);
         load_frag3(fa, W, lane);
         if (f == 0) {
 #pragma unroll
           for (int eb = 0; eb < IBE; ++eb) e[eb] += accO[eb];
-          layernorm_c16<IBE>(e, a.ln1_g, a.ln1_b, g);
+          layernorm_c16<IBE>(e, ln1_g, ln1_b, g);
 #pragma unroll
           for (int q = 0; q < QE; ++q) split3(e[2 * q], e[2 * q + 1], eh[q], em[q], el[q]);
-        }
-        const float* bias = reinterpret_cast<const float*>(W + G::WMAX);
 #pragma unroll
-        for (int ob = 0; ob < 4; ++ob) hid[4 * f + ob] = ld4(bias + 16 * ob + 4 * g);
-        block_pipeline<4 * QE, 0>(W, nullptr, fa, fb, lane, [&](int t, const Frag3& w) {
-          mfma_x3(hid[4 * f + (t & 3)], w, eh[t >> 2], em[t >> 2], el[t >> 2]);
+          for (int eb = 0; eb < IBE; ++eb) e[eb] += ld4(bias + 64 + 16 * eb + 4 * g);   // linE2 bias
+        }
+        f32x4 hid[4];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) hid[ob] = ld4(bias + 16 * ob + 4 * g);
+        block_pipeline<4 * QE, 0>(W, W + 4 * QE * 192, fa, fb, lane, [&](int t, const Frag3& w) {
+          mfma_x3(hid[t & 3], w, eh[t >> 2], em[t >> 2], el[t >> 2]);
         });
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) hid[4 * f + ob][r] = fmaxf(hid[4 * f + ob][r], 0.f);
-      }
-      cur ^= 1;
-    }
-#pragma unroll
-    for (int rb = 0; rb < NEB; ++rb) {
-      STAMP(1 + 6 * NXB + NFB + 2 * rb);
-      __syncthreads();
-      STAMP(2 + 6 * NXB + NFB + 2 * rb);
-      const int nxt = (NXB + NFB / 2 + rb + 1) % NPH;                   // wraps to the first phase of the next unit
-      stage_phase_unit<G::PH_F4, NW>(a.phase_img + (size_t)nxt * G::PH_F4, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
-      if (rb == 0) {
-        vec_store(nx, nvr);
-        tile_load(nx, nx0, nx1);
-      }
-      const f32x4* W = wbuf + cur * G::PH_F4;
-      if (active) {
-        load_frag3(fa, W, lane);
-        const float* bias = reinterpret_cast<const float*>(W + G::WMAX);
-        f32x4 f2[2];
-#pragma unroll
-        for (int ob = 0; ob < 2; ++ob) f2[ob] = ld4(bias + 16 * ob + 4 * g);
+          for (int r = 0; r < 4; ++r) hid[ob][r] = fmaxf(hid[ob][r], 0.f);
         u32x4 hh, hm, hl;
-        block_pipeline<2 * QF, 0>(W, nullptr, fa, fb, lane, [&](int t, const Frag3& w) {
-          if ((t & 1) == 0) split3(hid[2 * (t >> 1)], hid[2 * (t >> 1) + 1], hh, hm, hl);   // chunk q = t >> 1, once
-          mfma_x3(f2[t & 1], w, hh, hm, hl);
+        block_pipeline<2 * IBE, 0>(W + 4 * QE * 192, nullptr, fa, fb, lane, [&](int t, const Frag3& w) {
+          if (t % IBE == 0) split3(hid[2 * (t / IBE)], hid[2 * (t / IBE) + 1], hh, hm, hl);   // hidden chunk hq = t / IBE, once
+          mfma_x3(e[t % IBE], w, hh, hm, hl);
         });
-#pragma unroll
-        for (int ob = 0; ob < 2; ++ob) e[2 * rb + ob] += f2[ob];
       }
+      if (f == G::NFF - 1 && nx.active) vec_store(nvr);
       cur ^= 1;
     }
-    STAMP(1 + 6 * NXB + NFB + 2 * NEB);
     if (active) {
-      layernorm_c16<IBE>(e, a.ln2_g, a.ln2_b, g);
+      layernorm_c16<IBE>(e, ln2_g, ln2_b, g);
       if (inb) {
-        float* dst = a.E_out + off_ij + 4 * g;
+        float* dst = a.E_out + ((long long)un.row * n + jj) * DE + 4 * g;
 #pragma unroll
         for (int eb = 0; eb < IBE; ++eb) *reinterpret_cast<f32x4*>(dst + 16 * eb) = live ? e[eb] : splat4(0.f);
       }
     }
-    tile_make(nx, nx0, nx1, e);
-    STAMP(2 + 6 * NXB + NFB + 2 * NEB);
+    if (nx.active) {
+      const bool nlive = nmk != 0 && nj != nx.i;
+#pragma unroll
+      for (int eb = 0; eb < IBE; ++eb) e[eb] = nlive ? 0.5f * (nx0[eb] + nx1[eb]) : splat4(0.f);
+    }
     un = nx;
+    mk = nmk;
   }
 }
 
