@@ -67,6 +67,15 @@ int scgg_denoiser_forward(scgg_denoiser* h, const float* X, const float* E, cons
                           int32_t B, int32_t n, float* out_X, float* out_E, float* out_y, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* The engine's second stream (a hipStream_t, owned by the handle; NULL + scgg_last_error on failure).  The forward
+ * runs every consumer of its X and y arguments on this stream and only the edge path on the caller's, so work that
+ * PRODUCES X or y may be enqueued on it before scgg_denoiser_forward is called (after making it wait for whatever that
+ * work reads): it is then ordered before the node / global input MLPs but runs beside the edge input MLP, the long
+ * pole of the prologue.  The sampling loop (diffusion_model_discrete.py:653-663) runs the eigen features, which feed
+ * only X and y (extra_features.py:41-60), this way.  E and node_mask must be complete on the forward's own stream as
+ * usual.  No counterpart in the reference (PyTorch serialises the whole step on one stream). */
+void* scgg_denoiser_side_stream(scgg_denoiser* h);
+
 /* Debug / test tap: runs the input MLPs and the first `n_run_layers` layers of the same network and returns the
  * hidden state as the reference holds it after that layer (transformer_model.py:360-369): hid_X[B,n,dx],
  * hid_E[B,n,n,de] (symmetrised, masked), hid_y[B,dy].  Any output pointer may be NULL. */

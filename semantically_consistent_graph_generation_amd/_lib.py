@@ -35,6 +35,7 @@ SIGNATURES = {
     "scgg_denoiser_workspace_bytes": (_sz, [_vp, _i32, _i32]),
     "scgg_denoiser_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "scgg_denoiser_forward_hidden": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "scgg_denoiser_side_stream": (C.c_void_p, [_vp]),
     "scgg_denoiser_profile": (C.c_int, [_vp, _i32, _i32]),
     "scgg_denoiser_profile_read": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "scgg_reverse_step_edges": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,

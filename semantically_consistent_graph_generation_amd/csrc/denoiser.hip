@@ -384,21 +384,26 @@ __global__ void sym_copy_kernel(const float* E, const uint8_t* mask, float* out,
   out[idx] = live ? 0.5f * (E[idx] + E[(((long long)b * n + j) * n + i) * de + c]) : 0.f;
 }
 
+// the second stream and the fork / join events: created on first use, on the device the caller has made current
+int ensure_streams(scgg_denoiser* h) {
+  if (h->aux != nullptr) return 0;
+  int prio_lo = 0, prio_hi = 0;   // the y kernels are short and feed the next edge launch: let them jump the queue
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if (hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, prio_hi) != hipSuccess)
+    return fail("aux stream creation failed");
+  h->sync_ev.resize((size_t)(h->c.n_layers + 1) * 4);
+  for (hipEvent_t& e : h->sync_ev)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail("event creation failed");
+  return 0;
+}
+
 int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y, const uint8_t* mask, int B, int n,
                 int n_run_layers, bool tap, float* o1, float* o2, float* o3, void* workspace, size_t ws_bytes,
                 hipStream_t st) {
   if (!h || !h->finalized) return fail("denoiser not finalized");
   if (B <= 0 || n <= 0) return fail("bad batch shape B=%d n=%d", B, n);
   const scgg_denoiser_config& c = h->c;
-  if (h->aux == nullptr) {   // created on first use, on the device the caller has made current
-    int prio_lo = 0, prio_hi = 0;   // the y kernels are short and feed the next edge launch: let them jump the queue
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    if (hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, prio_hi) != hipSuccess)
-      return fail("aux stream creation failed");
-    h->sync_ev.resize((size_t)(c.n_layers + 1) * 4);
-    for (hipEvent_t& e : h->sync_ev)
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail("event creation failed");
-  }
+  if (ensure_streams(h)) return -1;
   if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) return fail("workspace must be 256-byte aligned");
   Workspace w = carve(c, B, n, static_cast<char*>(workspace));
   if (ws_bytes < w.bytes) return fail("workspace too small: %zu < %zu", ws_bytes, w.bytes);
@@ -716,6 +721,12 @@ int scgg_denoiser_forward_hidden(scgg_denoiser* h, const float* X, const float* 
   if (!h || n_run_layers < 0 || n_run_layers > h->c.n_layers) return fail("forward_hidden: bad layer count");
   return run_forward(h, X, E, y, node_mask, B, n, n_run_layers, true, hid_X, hid_E, hid_y, workspace, workspace_bytes,
                      static_cast<hipStream_t>(stream));
+}
+
+void* scgg_denoiser_side_stream(scgg_denoiser* h) {
+  if (!h || !h->finalized) { fail("side_stream: denoiser not finalized"); return nullptr; }
+  if (ensure_streams(h)) return nullptr;
+  return h->aux;
 }
 
 int scgg_denoiser_profile(scgg_denoiser* h, int32_t every_n_forwards, int32_t max_launches) {

@@ -13,6 +13,8 @@ graph draws the same Philox stream whatever the sharding.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -76,8 +78,19 @@ class DiscreteSampler:
             ky = 4 + ef.num_degree + 2 + 1 + C_e
             _, _, _, lap = ef.adjacency_features(labels, node_mask, C_e, e_dst=st["E_in"], e_off=C_e, want_onehot=True,
                                                  x_dst=st["X_in"], x_off=1, y_dst=st["y_in"], y_off=1)
-            ef.eigen_features(lap, node_mask, evl_dst=st["y_in"], evl_off=1 + ky, evc_dst=st["X_in"], evc_off=4)
             st["y_in"][:, -1] = t / self.T
+            # The eigen features feed only X and y (extra_features.py:41-60): they run on the denoiser's second stream,
+            # ahead of its consumers of X / y and beside its edge input MLP (scgg_denoiser_side_stream).
+            if os.environ.get("SCGG_NO_SIDE_STREAM"):   # development A/B switch
+                ef.eigen_features(lap, node_mask, evl_dst=st["y_in"], evl_off=1 + ky, evc_dst=st["X_in"], evc_off=4)
+            else:
+                side = st.get("side_stream")
+                if side is None:
+                    side = st["side_stream"] = self.model.side_stream(node_mask.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    lap.record_stream(side)
+                    ef.eigen_features(lap, node_mask, evl_dst=st["y_in"], evl_off=1 + ky, evc_dst=st["X_in"], evc_off=4)
         else:
             _lib.check(_lib.lib().scgg_labels_to_onehot(_lib.ptr(labels), None, B * n * n, C_e, 0, _lib.ptr(st["E_in"]), None,
                                                         _lib.stream_ptr()), "labels_to_onehot")

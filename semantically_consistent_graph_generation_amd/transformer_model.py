@@ -181,6 +181,15 @@ class GraphTransformer(nn.Module):
         return (X.detach().float().contiguous(), E.detach().float().contiguous(), y.detach().float().contiguous(),
                 m.to(torch.bool).contiguous(), B, n)
 
+    def side_stream(self, device):
+        """The engine's second stream as a torch stream: producers of the forward's X / y inputs may run on it (see
+        scgg_denoiser_side_stream in include/scgg.h)."""
+        eng = self._ensure_engine(device)
+        p = _lib.lib().scgg_denoiser_side_stream(eng)
+        if not p:
+            raise _lib.ScggError("scgg_denoiser_side_stream: " + _lib.lib().scgg_last_error().decode())
+        return torch.cuda.ExternalStream(p, device=device)
+
     # ------------------------------------------------------------------------------------------------- forward
     @torch.no_grad()
     def forward(self, model_input):
