@@ -7,10 +7,14 @@ own B graphs (weak scaling), no collective on the data path; the timed region is
 synchronize and the MAX over ranks is reported.
 
 Also printed in the same JSON line:
-  roofline      the fused edge-layer kernel (dominant): achieved fp32 TFLOP/s = algorithmic flops of one launch
-                (valid pairs x (6 de dx + 4 de ffE)) / its average duration, measured live with HIP events on the
-                launch stream inside the timed region (every 16th forward); peak = 157.3 TFLOP/s fp32 MFMA;
-                traffic = HBM bytes per launch from the committed rocprofv3 PMC passes of this command.
+  roofline      the fused edge-layer kernel (dominant), measured live with HIP events on the launch stream inside the
+                timed region (every 16th forward).  The kernel evaluates every fp32 product as six bf16 x bf16 partial
+                products on v_mfma_f32_16x16x32_bf16 (exact three-term split, fp32 accumulate: DESIGN.md section 4.1), so
+                achieved = EXECUTED bf16 flops (6 x the algorithmic flops, valid pairs x (6 de dx + 4 de ffE)) per
+                launch / average duration, against the dense bf16 MFMA peak (2500 TFLOP/s); the algorithmic fp32 rate
+                and its ratio to the fp32 MFMA peak (157.3 TFLOP/s, the bound of the fp32-MFMA kernel this one
+                replaced) are reported beside it.  traffic = HBM bytes per launch from the committed rocprofv3 PMC
+                passes of this command.
   cpu_baseline  the CPU oracle (eager torch fp32 "port" of the reference algorithm) timed on this host for a bounded
                 sample (B = 32 graphs, a few reverse steps), extrapolated to graphs/s for the full chain.
 """
@@ -31,6 +35,8 @@ DIMS = dict(hidden_mlp_dims={"X": 256, "E": 128, "y": 128},
 C_E, N_LAYERS, TOP_K, N_MAX = 14, 5, 4, 32
 NU = dict(x=1, c=1, e=1, y=1, e_small=1, e_mid=1, e_large=1)
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same table, "Peak BF16/FP16 MFMA", dense
+X3_PRODUCTS = 6                   # bf16 partial products per fp32 product in the x3 path
 
 
 def measured_traffic():
@@ -159,7 +165,8 @@ def main():
 
     if rank == 0:
         kernel_ms = ms / max(n_launch, 1)
-        achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12 if n_launch else 0.0
+        algorithmic = flops_per_launch / (kernel_ms * 1e-3) / 1e12 if n_launch else 0.0
+        achieved = X3_PRODUCTS * algorithmic
         out = {
             "metric": "sampled graphs/sec (full T-step reverse diffusion)", "value": world * a.batch * a.steps / elapsed,
             "unit": "graphs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -170,11 +177,14 @@ def main():
                                    "absorbing_edges, projector None (BASELINE configs[1])",
                        "graphs_per_gpu": a.batch, "diffusion_steps": a.T, "valid_pairs_per_forward": valid_pairs,
                        "sampled_edges_last_chain": edges},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_MFMA_TFLOPS,
+                         "algorithmic_f32_TFLOPs": algorithmic,
+                         "algorithmic_over_f32_mfma_peak": algorithmic / PEAK_F32_MFMA_TFLOPS,
                          "traffic": measured_traffic() if a.batch == 512 else None,
                          "algorithmic_bytes_per_launch": 3 * valid_pairs * hd["de"] * 4,
-                         "kernel": "scgg::edge_unit_layer_kernel<8,2,4,16> (fused XEy layer, edge path, fp32 MFMA 16x16x4)",
+                         "kernel": "scgg::edge_unit_layer_x3_kernel<8,2,4,8> (fused XEy layer, edge path; fp32 results from 6 bf16 "
+                                   "MFMA 16x16x32 partial products per product, fp32 accumulate)",
                          "avg_launch_ms": kernel_ms, "launches_timed": n_launch,
                          "algorithmic_flops_per_launch": flops_per_launch,
                          "edge_stream_GBps": 2 * valid_pairs * hd["de"] * 4 / (kernel_ms * 1e-3) / 1e9 if n_launch else 0.0},
