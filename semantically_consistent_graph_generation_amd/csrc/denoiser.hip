@@ -44,6 +44,7 @@ struct Param {
 
 struct PackedLinear {   // chain-kernel operand
   f32x4_t* W = nullptr;
+  f32x4_t* W3 = nullptr;  // three-term bf16 image of the same matrix (node_layer_x3_kernel)
   float* b = nullptr;
   int N = 0, K = 0;
 };
@@ -141,10 +142,13 @@ int pack_raw(Arena& ar, bool fill, const float* W, const float* b, int N, int K,
   out.N = N;
   out.K = K;
   out.W = ar.take<f32x4_t>((size_t)NB * KB * 256);
+  out.W3 = ar.take<f32x4_t>((size_t)NB * (K / 16) * 192);
   out.b = ar.take<float>((size_t)NB * 32);
   if (!fill) return 0;
   PackArgs pa{W, out.W, N, K, NB, KB};
   launch_pack_linear(pa, st);
+  PackArgs p3{W, out.W3, N, K, NB, KB};
+  launch_pack_linear_x3(p3, st);
   launch_pad_vec(b, out.b, N, NB * 32, 0.f, st);
   return check_launch("pack_raw");
 }
@@ -263,6 +267,8 @@ int build(scgg_denoiser* h, bool fill, hipStream_t st) {
     if (L.qkv.W != nullptr) {
       PackArgs pa{L.Wqkv, L.qkv.W, 3 * dx, dx, (3 * dx + 31) / 32, dx / 32};
       launch_pack_linear(pa, st);
+      PackArgs p3{L.Wqkv, L.qkv.W3, 3 * dx, dx, (3 * dx + 31) / 32, dx / 32};
+      launch_pack_linear_x3(p3, st);
       launch_pad_vec(L.bqkv, L.qkv.b, 3 * dx, (3 * dx + 31) / 32 * 32, 0.f, st);
     }
     const char* fl[4] = {"y_e_add", "y_e_mul", "y_x_add", "y_x_mul"};
@@ -536,7 +542,8 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
         const bool next = l + 1 < n_run_layers;
         NodeLayerArgs na{w.attn, mask, film, w.Xh, w.rows, w.row_count, L.x_out.W, L.x_out.b, g1->p, b1->p,
                          L.linX1.W, L.linX1.b, L.linX2.W, L.linX2.b, g2->p, b2->p,
-                         next ? h->layers[l + 1].qkv.W : nullptr, next ? h->layers[l + 1].qkv.b : nullptr, w.qkv, n};
+                         next ? h->layers[l + 1].qkv.W : nullptr, next ? h->layers[l + 1].qkv.b : nullptr, w.qkv, n,
+                         L.x_out.W3, L.linX1.W3, L.linX2.W3, next ? h->layers[l + 1].qkv.W3 : nullptr};
         if (launch_node_layer(na, dx, c.dim_ffX, M, st)) return fail("node_layer launch failed");
       } else {
         if (node_lin(h, L.x_out, sa + "x_out", w.newX, dx, w.t1, dx, M, dx, dx, false, true, mask, w.rows, w.row_count, st))
@@ -561,9 +568,8 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
         ya.y = w.y; ya.ycat = w.ycat; ya.etoy = w.epool + (size_t)(l & 1) * B * 4 * de;
         ya.B = B; ya.dy = dy; ya.ffy = c.dim_ffy; ya.kcat = kcat; ya.dx = dx;
         ya.update = L.predicts_y ? 1 : 0;
-        // (the y round needs nothing from edge kernel l; it is held back until that kernel is done because the two
-        //  cannot share a CU -- the edge kernel owns every register -- and the node kernel can)
-        if (await(ax, ev(l, EV_EDGE))) return fail("stream wait failed");
+        // The y round needs nothing from edge kernel l and is not held back for it: one y workgroup (50 VGPRs, 36 KB of
+        // LDS at ConStruct dims) fits on a CU beside one edge workgroup (2 x 200 VGPRs per SIMD lane, 122 KB).
         if (L.predicts_y) {
           const Param* o0b = P_(h, sa + "y_out.0.bias", dy); const Param* o2b = P_(h, sa + "y_out.2.bias", dy);
           const Param* g1 = P_(h, p + "norm_y1.weight", dy); const Param* b1 = P_(h, p + "norm_y1.bias", dy);

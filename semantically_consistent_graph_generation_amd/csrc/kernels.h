@@ -150,6 +150,8 @@ struct NodeLayerArgs {    // fused node part of one layer (node_layer.hip); pack
   const f32x4_t* W_qkv;   const float* b_qkv;   // next layer's q|k|v (null: not computed)
   float* qkv;             // [B,n,3*dx]
   int n;
+  // the same four weight matrices as three-term bf16 images (launch_pack_linear_x3) for the x3 kernel
+  const f32x4_t* W3_xout; const f32x4_t* W3_lin1; const f32x4_t* W3_lin2; const f32x4_t* W3_qkv;
 };
 bool node_layer_supported(int dx, int ffx);
 int launch_node_layer(const NodeLayerArgs& a, int dx, int ffx, int M, hipStream_t st);
@@ -200,6 +202,8 @@ struct PackArgs {
   int N, K, NB, KB;
 };
 int launch_pack_linear(const PackArgs& a, hipStream_t st);
+// three-term bf16 image of W for node_layer_x3_kernel: [NB][K/16][term][64 lanes] x 16 bytes (Wp holds NB*(K/16)*192 slots)
+int launch_pack_linear_x3(const PackArgs& a, hipStream_t st);
 int launch_pad_vec(const float* src, float* dst, int n, int n_pad, float add, hipStream_t st);
 int launch_copy_cols(const float* src, int lds, float* dst, int ldd, int M, int ncols, hipStream_t st);
 int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t st);   // dst[c][r] = src[r][c]

@@ -15,6 +15,7 @@
 // linX1, linX2, LN) and the separate q|k|v launch, and the activations make no HBM round trip between them.
 #include "mfma_chain.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 namespace scgg {
 
@@ -181,18 +182,250 @@ __global__ __launch_bounds__(512) void node_layer_kernel(NodeLayerArgs a) {
   }
 }
 
+// =========================================================================================================
+// The same layer on the bf16 matrix pipe with fp32 accuracy ("x3", see edge_unit_layer.hip): every Linear operand is
+// split exactly into three bf16 terms (weights at pack time: launch_pack_linear_x3; activations when they are written
+// to LDS, once per element) and a product is the six leading partial products on v_mfma_f32_32x32x16_bf16 = 6/16 of
+// the fp32 MFMA time.  The tile's operand lives in LDS as three bf16 planes [32][K + 8]; results that feed a LayerNorm
+// go through an fp32 buffer.  Weight blocks (3 x 16 B per lane per 16-channel K chunk) stream from L2 four chunks
+// ahead of their MFMAs.
+// =========================================================================================================
+typedef unsigned nu32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned nu32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 nbf16x8 __attribute__((ext_vector_type(8)));
+
+template <int DXB, int FXB>
+struct NodeGeomX3 {
+  static constexpr int DX = 32 * DXB, FX = 32 * FXB;
+  static constexpr int KMAX = DX > FX ? DX : FX;
+  static constexpr int KS = KMAX + 8;                       // bf16 row stride of a plane: 4 banks (mod 32) per row
+  static constexpr int PLANE = 32 * KS;                     // bf16 elements per term plane
+  static constexpr int LD = KMAX + 4;                       // fp32 result buffer stride
+  static constexpr size_t SPLIT_BYTES = (size_t)3 * PLANE * 2;
+  static constexpr size_t LDS_BYTES = 2 * SPLIT_BYTES + (size_t)32 * LD * 4;
+};
+
+// exact three-way bf16 split of 4 consecutive channels -> 8 bytes per term
+__device__ __forceinline__ void split3_4(const f32x4& x, nu32x2& hi, nu32x2& mid, nu32x2& lo) {
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const float x0 = x[2 * d], x1 = x[2 * d + 1];
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    hi[d] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    mid[d] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    lo[d] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+  }
+}
+// write 4 consecutive channels of tile row `r` starting at channel c into the three planes
+template <int KS, int PLANE>
+__device__ __forceinline__ void put_split4(__bf16* planes, int r, int c, const f32x4& x) {
+  nu32x2 h, m, l;
+  split3_4(x, h, m, l);
+  __bf16* d = planes + r * KS + c;
+  *reinterpret_cast<nu32x2*>(d) = h;
+  *reinterpret_cast<nu32x2*>(d + PLANE) = m;
+  *reinterpret_cast<nu32x2*>(d + 2 * PLANE) = l;
+}
+
+struct NFrag3 { nu32x4 h, m, l; };
+
+// acc (C layout of the 32x32 MFMA: tile row on lane & 31, 32 output channels of block rb in the registers) += W[rb] . X^T
+// w3: the x3 image (block rb starts at rb * KC * 192 slots); planes: the split operand tile
+template <int KC, int KS, int PLANE>
+__device__ __forceinline__ void tile_linear_x3(f32x16& acc, const f32x4* __restrict__ w3, int rb, const __bf16* planes,
+                                               int p, int h, int lane) {
+  constexpr int D = 4;                                       // weight chunks in flight
+  const nu32x4* w = reinterpret_cast<const nu32x4*>(w3) + (size_t)rb * KC * 192 + lane;
+  const __bf16* x = planes + p * KS + 8 * h;
+  NFrag3 wf[D], xf[2];
+  auto wload = [&](NFrag3& f, int kc) {
+    f.h = w[kc * 192];
+    f.m = w[kc * 192 + 64];
+    f.l = w[kc * 192 + 128];
+  };
+  auto xload = [&](NFrag3& f, int kc) {
+    f.h = *reinterpret_cast<const nu32x4*>(x + 16 * kc);
+    f.m = *reinterpret_cast<const nu32x4*>(x + 16 * kc + PLANE);
+    f.l = *reinterpret_cast<const nu32x4*>(x + 16 * kc + 2 * PLANE);
+  };
+#pragma unroll
+  for (int d = 0; d < D && d < KC; ++d) wload(wf[d], d);
+  xload(xf[0], 0);
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    if (kc + 1 < KC) xload(xf[(kc + 1) & 1], kc + 1);
+    const NFrag3& a = wf[kc % D];
+    const NFrag3& b = xf[kc & 1];
+    __builtin_amdgcn_sched_barrier(0);
+#define SCGG_NB(v) __builtin_bit_cast(nbf16x8, v)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SCGG_NB(a.l), SCGG_NB(b.h), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SCGG_NB(a.h), SCGG_NB(b.l), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SCGG_NB(a.m), SCGG_NB(b.m), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SCGG_NB(a.m), SCGG_NB(b.h), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SCGG_NB(a.h), SCGG_NB(b.m), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SCGG_NB(a.h), SCGG_NB(b.h), acc, 0, 0, 0);
+#undef SCGG_NB
+    __builtin_amdgcn_sched_barrier(0);
+    if (kc + D < KC) wload(wf[kc % D], kc + D);
+  }
+}
+
+// as tile_add_layernorm, with the normalised rows written as split planes (the next Linear's operand)
+template <int DX, int LD, int KS, int PLANE>
+__device__ __forceinline__ void tile_add_layernorm_x3(f32x4 (&res)[4], const float* lin, __bf16* planes,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      int wave, int lane, float* gout, const long long* grow, const bool* gok) {
+  const int c = lane * 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = wave * 4 + t;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c < DX) v = res[t] + *reinterpret_cast<const f32x4*>(lin + r * LD + c);
+    const float mean = wave_sum64(v[0] + v[1] + v[2] + v[3]) * (1.0f / DX);
+    f32x4 d = v - mean;
+    if (c >= DX) d = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float var = wave_sum64(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.0f / DX);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    if (c < DX) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+      const f32x4 o = d * rstd * gm + bt;
+      res[t] = o;
+      put_split4<KS, PLANE>(planes, r, c, o);
+      if (gout != nullptr && gok[t]) *reinterpret_cast<f32x4*>(gout + grow[t] * DX + c) = o;
+    }
+  }
+}
+
+template <int DXB, int FXB>
+__global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
+  using G = NodeGeomX3<DXB, FXB>;
+  constexpr int DX = G::DX, FX = G::FX, LD = G::LD, KS = G::KS, PLANE = G::PLANE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* S1 = reinterpret_cast<__bf16*>(smem);                 // split operand tiles
+  __bf16* S2 = S1 + 3 * PLANE;
+  float* F = reinterpret_cast<float*>(S2 + 3 * PLANE);          // fp32 results in front of the LayerNorms
+  f32x4 res[4];                                                 // residual stream X of this wave's 4 rows (lane = 4 channels)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 31, h = lane >> 5;
+  const int count = *a.row_count;
+  const int tile = blockIdx.x;
+  if (tile * 32 >= count) return;
+
+  // ---- prologue: this wave's 4 rows: newX_pre from the attention partials of the row's units, residual X
+  const int n = a.n, nch = (n + 15) >> 4;
+  long long grow[4];
+  bool gok[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int ridx = tile * 32 + wave * 4 + t;
+    gok[t] = ridx < count;
+    const long long row = a.rows[gok[t] ? ridx : count - 1];
+    grow[t] = row;
+    const int b = (int)(row / n);
+    const uint8_t* mb = a.mask + (long long)b * n;
+    const float* film = a.film + (long long)b * (4 * DX);
+    const int c = lane * 4;
+    if (c < DX) {
+      f32x4 M = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, S = {0.f, 0.f, 0.f, 0.f}, A = {0.f, 0.f, 0.f, 0.f};
+      for (int jc = 0; jc < nch; ++jc) {
+        bool any = false;
+        for (int j = jc * 16; j < min(n, jc * 16 + 16); ++j) any |= mb[j] != 0;      // wave-uniform
+        if (!any) continue;
+        const float* pt = a.attn_part + (row * nch + jc) * (3 * DX) + c;
+        const f32x4 m = *reinterpret_cast<const f32x4*>(pt), s = *reinterpret_cast<const f32x4*>(pt + DX),
+                    ac = *reinterpret_cast<const f32x4*>(pt + 2 * DX);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float mn = fmaxf(M[e], m[e]);
+          const float fo = M[e] == -INFINITY ? 0.f : __expf(M[e] - mn);
+          const float fn = m[e] == -INFINITY ? 0.f : __expf(m[e] - mn);
+          S[e] = S[e] * fo + s[e] * fn;
+          A[e] = A[e] * fo + ac[e] * fn;
+          M[e] = mn;
+        }
+      }
+      const f32x4 fa = *reinterpret_cast<const f32x4*>(film + 2 * DX + c), fm = *reinterpret_cast<const f32x4*>(film + 3 * DX + c);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fa[e] + fm[e] * (A[e] / S[e]);
+      put_split4<KS, PLANE>(S1, wave * 4 + t, c, o);
+      res[t] = *reinterpret_cast<const f32x4*>(a.X + row * DX + c);
+    }
+  }
+  __syncthreads();
+
+  // ---- x_out: S1 -> F
+  for (int rb = wave; rb < DXB; rb += 8) {
+    f32x16 acc = load_vec_block(a.b_xout + 32 * rb, h);
+    tile_linear_x3<DX / 16, KS, PLANE>(acc, a.W3_xout, rb, S1, p, h, lane);
+    store_vec_block(F + p * LD + 32 * rb, h, acc);
+  }
+  __syncthreads();
+  // ---- X = normX1(X + newX): registers, and S1 as the next operand
+  tile_add_layernorm_x3<DX, LD, KS, PLANE>(res, F, S1, a.ln1_g, a.ln1_b, wave, lane, nullptr, grow, gok);
+  __syncthreads();
+  // ---- linX1 + relu: S1 -> S2
+  for (int rb = wave; rb < FXB; rb += 8) {
+    f32x16 acc = load_vec_block(a.b_lin1 + 32 * rb, h);
+    tile_linear_x3<DX / 16, KS, PLANE>(acc, a.W3_lin1, rb, S1, p, h, lane);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = fmaxf(acc[4 * g + e], 0.f);
+      put_split4<KS, PLANE>(S2, p, 32 * rb + 8 * g + 4 * h, t);
+    }
+  }
+  __syncthreads();
+  // ---- linX2: S2 -> F
+  for (int rb = wave; rb < DXB; rb += 8) {
+    f32x16 acc = load_vec_block(a.b_lin2 + 32 * rb, h);
+    tile_linear_x3<FX / 16, KS, PLANE>(acc, a.W3_lin2, rb, S2, p, h, lane);
+    store_vec_block(F + p * LD + 32 * rb, h, acc);
+  }
+  __syncthreads();
+  // ---- X = normX2(X + ff): global and S1 (every row of the tile is a valid node, so the node mask is 1)
+  tile_add_layernorm_x3<DX, LD, KS, PLANE>(res, F, S1, a.ln2_g, a.ln2_b, wave, lane, a.X, grow, gok);
+  if (a.W3_qkv == nullptr) return;
+  __syncthreads();
+  // ---- q | k | v of the next layer: S1 -> global
+  {
+    const int ridx = tile * 32 + p;
+    const bool ok = ridx < count;
+    const long long row = a.rows[ok ? ridx : count - 1];
+    for (int rb = wave; rb < 3 * DXB; rb += 8) {
+      f32x16 acc = load_vec_block(a.b_qkv + 32 * rb, h);
+      tile_linear_x3<DX / 16, KS, PLANE>(acc, a.W3_qkv, rb, S1, p, h, lane);
+      if (ok) store_vec_block(a.qkv + row * (3 * DX) + 32 * rb, h, acc);
+    }
+  }
+}
+
+// SCGG_NODE_MODE=f32 selects the plain fp32-MFMA kernel (development A/B switch); default: the x3 kernel
+static bool node_x3() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("SCGG_NODE_MODE");
+    mode = (e != nullptr && e[0] == 'f') ? 0 : 1;
+  }
+  return mode == 1;
+}
+
 template <int DXB, int FXB>
 static int launch_one(const NodeLayerArgs& a, int M, hipStream_t st) {
-  using G = NodeGeom<DXB, FXB>;
   static bool attr_set = false;
-  auto kern = node_layer_kernel<DXB, FXB>;
+  const bool x3 = node_x3() && a.W3_xout && a.W3_lin1 && a.W3_lin2;
+  auto kern = x3 ? node_layer_x3_kernel<DXB, FXB> : node_layer_kernel<DXB, FXB>;
+  const size_t lds = x3 ? NodeGeomX3<DXB, FXB>::LDS_BYTES : NodeGeom<DXB, FXB>::LDS_BYTES;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)G::LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
       return -2;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((M + 31) / 32), dim3(512), G::LDS_BYTES, st, a);
+  hipLaunchKernelGGL(kern, dim3((M + 31) / 32), dim3(512), lds, st, a);
   return 0;
 }
 

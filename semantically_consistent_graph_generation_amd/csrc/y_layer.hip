@@ -117,12 +117,13 @@ __global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
   extern __shared__ __attribute__((aligned(16))) float ysm[];
   const int tid = threadIdx.x;
   const int dy = a.dy, kcat = a.kcat;
-  const int ldf = a.ffy > YW ? a.ffy : YW;
+  const int ldy = a.dy;                                          // stride of the y-wide vectors
+  const int ldf = a.ffy > ldy ? a.ffy : ldy;
   yf4* red = reinterpret_cast<yf4*>(ysm);                       // [YG][YT] float4
   float* cat = ysm + YG * YT * 4;                                // [YG][kcat]  (y | Xtoy | Etoy)
-  float* yv = cat + YG * kcat;                                   // [YG][YW]    the y stream
-  float* t1 = yv + YG * YW;                                      // [YG][YW]
-  float* t2 = t1 + YG * YW;                                      // [YG][ldf]   (y_out hidden, then the lin_y1 hidden)
+  float* yv = cat + YG * kcat;                                   // [YG][dy]    the y stream
+  float* t1 = yv + YG * ldy;                                      // [YG][dy]
+  float* t2 = t1 + YG * ldy;                                      // [YG][ldf]   (y_out hidden, then the lin_y1 hidden)
   const int b0 = blockIdx.x * YG;
 
   if (a.update) {
@@ -136,22 +137,22 @@ __global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
   }
   for (int idx = tid; idx < YG * dy; idx += YT) {
     const int g = idx / dy, c = idx - g * dy;
-    yv[g * YW + c] = a.y[(size_t)min(b0 + g, a.B - 1) * dy + c];
+    yv[g * ldy + c] = a.y[(size_t)min(b0 + g, a.B - 1) * dy + c];
   }
   __syncthreads();
   if (a.update) {
-    y_dense(a.Wt_cat, a.b_cat, dy, kcat, cat, kcat, t1, YW, false, red, tid);        // y_y + x_y + e_y
-    y_dense(a.Wt_o0, a.b_o0, dy, dy, t1, YW, t2, ldf, true, red, tid);               // y_out.0 + relu
-    y_dense(a.Wt_o2, a.b_o2, dy, dy, t2, ldf, t1, YW, false, red, tid);              // y_out.2
-    y_add_layernorm(yv, t1, YW, dy, a.ln1_g, a.ln1_b, tid);
+    y_dense(a.Wt_cat, a.b_cat, dy, kcat, cat, kcat, t1, ldy, false, red, tid);        // y_y + x_y + e_y
+    y_dense(a.Wt_o0, a.b_o0, dy, dy, t1, ldy, t2, ldf, true, red, tid);               // y_out.0 + relu
+    y_dense(a.Wt_o2, a.b_o2, dy, dy, t2, ldf, t1, ldy, false, red, tid);              // y_out.2
+    y_add_layernorm(yv, t1, ldy, dy, a.ln1_g, a.ln1_b, tid);
     __syncthreads();
-    y_dense(a.Wt_l1, a.b_l1, a.ffy, dy, yv, YW, t2, ldf, true, red, tid);            // lin_y1 + relu
-    y_dense(a.Wt_l2, a.b_l2, dy, a.ffy, t2, ldf, t1, YW, false, red, tid);           // lin_y2
-    y_add_layernorm(yv, t1, YW, dy, a.ln2_g, a.ln2_b, tid);
+    y_dense(a.Wt_l1, a.b_l1, a.ffy, dy, yv, ldy, t2, ldf, true, red, tid);            // lin_y1 + relu
+    y_dense(a.Wt_l2, a.b_l2, dy, a.ffy, t2, ldf, t1, ldy, false, red, tid);           // lin_y2
+    y_add_layernorm(yv, t1, ldy, dy, a.ln2_g, a.ln2_b, tid);
     __syncthreads();
     for (int idx = tid; idx < YG * dy; idx += YT) {
       const int g = idx / dy, c = idx - g * dy;
-      if (b0 + g < a.B) a.y[(size_t)(b0 + g) * dy + c] = yv[g * YW + c];
+      if (b0 + g < a.B) a.y[(size_t)(b0 + g) * dy + c] = yv[g * ldy + c];
     }
   }
   if (a.Wt_film != nullptr) {
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
       for (int k = 0; k < dy; ++k) {
         const yf4 w = w4[(size_t)k * N4 + o4];
 #pragma unroll
-        for (int g = 0; g < YG; ++g) acc[g] += w * yv[g * YW + k];
+        for (int g = 0; g < YG; ++g) acc[g] += w * yv[g * ldy + k];
       }
 #pragma unroll
       for (int g = 0; g < YG; ++g)
@@ -178,17 +179,17 @@ __global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
   }
 }
 
-static size_t y_layer_lds(int ffy, int kcat) {
-  return (size_t)(YG * YT * 4 + YG * kcat + 2 * YG * YW + YG * (ffy > YW ? ffy : YW)) * 4;
+static size_t y_layer_lds(int dy, int ffy, int kcat) {
+  return (size_t)(YG * YT * 4 + YG * kcat + 2 * YG * dy + YG * (ffy > dy ? ffy : dy)) * 4;
 }
 
 bool y_layer_supported(int dy, int ffy, int kcat) {
-  return dy % 4 == 0 && ffy % 4 == 0 && kcat % 4 == 0 && dy <= YW && y_layer_lds(ffy, kcat) <= 64 * 1024;
+  return dy % 4 == 0 && ffy % 4 == 0 && kcat % 4 == 0 && dy <= YW && y_layer_lds(dy, ffy, kcat) <= 64 * 1024;
 }
 
 int launch_y_layer(const YLayerArgs& a, hipStream_t st) {
   if (!y_layer_supported(a.dy, a.ffy, a.kcat)) return -1;
-  const size_t lds = y_layer_lds(a.ffy, a.kcat);
+  const size_t lds = y_layer_lds(a.dy, a.ffy, a.kcat);
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(y_layer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
