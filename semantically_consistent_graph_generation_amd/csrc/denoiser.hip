@@ -433,6 +433,15 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     return fail("n=%d too large for the unit list (max 512)", n);
   if (signal(ev_fork, st) || await(ax, ev_fork)) return fail("stream fork failed");
 
+  // The residual stream X ping-pongs between two buffers when every layer runs the fused node kernel (w.t1 is only
+  // used by the unfused path): node kernel l then never overwrites the X whose pooled statistics the y path is taking.
+  bool dbl_X = node_layer_supported(dx, c.dim_ffX) && h->in_X2.W != nullptr && c.in_X <= 64 && c.hid_X % 4 == 0;
+  for (int l = 0; l < n_run_layers; ++l) {
+    const LayerPack& L = h->layers[l];
+    dbl_X = dbl_X && L.x_out.W && L.linX1.W && L.linX2.W && L.qkv.W;
+  }
+  float* Xcur = w.Xh;
+  float* Xalt = w.t1;
   // ---- input MLPs (transformer_model.py:358-366): E on the main stream, X and y beside it on the aux stream
   {
     const Param* w0 = P_(h, "mlp_in_X.0.weight", (int64_t)c.hid_X * c.in_X); const Param* b0 = P_(h, "mlp_in_X.0.bias", c.hid_X);
@@ -441,6 +450,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     if (h->in_X2.W != nullptr && c.in_X <= 64 && c.hid_X % 4 == 0) {
       // valid rows only: the masked rows of the residual stream are zeroed once, nothing writes them afterwards
       launch_zero_masked_rows(w.Xh, mask, M, dx, ax);
+      if (dbl_X) launch_zero_masked_rows(w.t1, mask, M, dx, ax);
       NarrowLinearArgs na{X, w0->p, b0->p, w.hidX, w.rows, w.row_count, c.hid_X, c.in_X, c.in_X, c.hid_X, 1};
       if (launch_narrow_linear(na, M, ax)) return fail("narrow_linear rejected");
       NodeLinearArgs la{w.hidX, h->in_X2.W, h->in_X2.b, w.Xh, w.rows, w.row_count, dx, c.hid_X, (dx + 31) / 32, c.hid_X, dx,
@@ -477,10 +487,10 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       hipStream_t qs = l == 0 ? ax : st;
       if (fused_node && l > 0) {
       } else if (L.qkv.W != nullptr) {
-        NodeLinearArgs qa{w.Xh, L.qkv.W, L.qkv.b, w.qkv, w.rows, w.row_count, 3 * dx, dx, (3 * dx + 31) / 32, dx, 3 * dx,
+        NodeLinearArgs qa{Xcur, L.qkv.W, L.qkv.b, w.qkv, w.rows, w.row_count, 3 * dx, dx, (3 * dx + 31) / 32, dx, 3 * dx,
                           dx >= 256 ? 8 : (3 * dx + 31) / 32, 0};
         if (launch_node_linear(qa, M, qs)) return fail("node_linear(qkv) rejected");
-      } else if (gemm_raw(w.Xh, dx, L.Wqkv, L.bqkv, w.qkv, 3 * dx, M, 3 * dx, dx, GEMM_ROWMASK, mask, qs)) return -1;
+      } else if (gemm_raw(Xcur, dx, L.Wqkv, L.bqkv, w.qkv, 3 * dx, M, 3 * dx, dx, GEMM_ROWMASK, mask, qs)) return -1;
     }
     // ---- aux: y-FiLM vectors (with the +1 folded in), Xtoy pooled statistics of the layer INPUT (:239-243)
     const bool fused_y = y_layer_supported(dy, c.dim_ffy, kcat);
@@ -497,7 +507,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     if (L.predicts_y) {
       if (!fused_y) launch_copy_cols(w.y, dy, w.ycat, kcat, B, dy, ax);
       if (l > 0 && await(ax, ev(l - 1, EV_X))) return fail("stream wait failed");
-      NodeStatsArgs ns{w.Xh, mask, w.ycat, B, n, dx, kcat, dy};
+      NodeStatsArgs ns{Xcur, mask, w.ycat, B, n, dx, kcat, dy};
       launch_node_stats(ns, ax);
     }
     if (signal(ev(l, EV_NS), ax)) return fail("event record failed");
@@ -509,8 +519,10 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       if (launch_edge_pool_stats(ep, ax)) return fail("edge_pool_stats: unsupported de=%d or n=%d", de, n);
     }
 
-    // ---- main: fused edge kernel
-    if (await(st, ev(l, EV_FILM))) return fail("stream wait failed");
+    // ---- main: fused edge kernel.  Its FiLM vectors: layer 0 (and the unfused y path) waits here; on the fused y path
+    //      the wait for layer l + 1 sits in front of node kernel l (the y round of layer l runs beside edge kernel l),
+    //      so node kernel l and edge kernel l + 1 go back to back (a cross-stream wait costs ~10 us of idle queue)
+    if ((l == 0 || !fused_y) && await(st, ev(l, EV_FILM))) return fail("stream wait failed");
     {
       EdgeLayerArgs a;
       a.E_in = Ecur; a.E_out = Enext; a.mask = mask;
@@ -531,33 +543,6 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
         AttnFinishArgs af{w.attn, mask, film, w.newX, w.rows, w.row_count, n, dx};
         launch_attn_finish(af, M, st);
       }
-    }
-    // ---- main: X path (transformer_model.py:234-235, :88-92)
-    {
-      const Param* g1 = P_(h, p + "normX1.weight", dx); const Param* b1 = P_(h, p + "normX1.bias", dx);
-      const Param* g2 = P_(h, p + "normX2.weight", dx); const Param* b2 = P_(h, p + "normX2.bias", dx);
-      if (!g1 || !b1 || !g2 || !b2) return -1;
-      if (await(st, ev(l, EV_NS))) return fail("stream wait failed");     // Xh is updated in place from here on
-      if (fused_node) {
-        const bool next = l + 1 < n_run_layers;
-        NodeLayerArgs na{w.attn, mask, film, w.Xh, w.rows, w.row_count, L.x_out.W, L.x_out.b, g1->p, b1->p,
-                         L.linX1.W, L.linX1.b, L.linX2.W, L.linX2.b, g2->p, b2->p,
-                         next ? h->layers[l + 1].qkv.W : nullptr, next ? h->layers[l + 1].qkv.b : nullptr, w.qkv, n,
-                         L.x_out.W3, L.linX1.W3, L.linX2.W3, next ? h->layers[l + 1].qkv.W3 : nullptr};
-        if (launch_node_layer(na, dx, c.dim_ffX, M, st)) return fail("node_layer launch failed");
-      } else {
-        if (node_lin(h, L.x_out, sa + "x_out", w.newX, dx, w.t1, dx, M, dx, dx, false, true, mask, w.rows, w.row_count, st))
-          return -1;
-        AddLnArgs ln1{w.Xh, w.t1, g1->p, b1->p, nullptr, w.Xh, M, dx, w.rows, w.row_count};
-        if (launch_add_layernorm(ln1, st)) return fail("layernorm width %d unsupported", dx);
-        if (node_lin(h, L.linX1, p + "linX1", w.Xh, dx, w.t2, c.dim_ffX, M, c.dim_ffX, dx, true, false, mask, w.rows,
-                     w.row_count, st)) return -1;
-        if (node_lin(h, L.linX2, p + "linX2", w.t2, c.dim_ffX, w.t1, dx, M, dx, c.dim_ffX, false, false, mask, w.rows,
-                     w.row_count, st)) return -1;
-        AddLnArgs ln2{w.Xh, w.t1, g2->p, b2->p, mask, w.Xh, M, dx, w.rows, w.row_count};
-        launch_add_layernorm(ln2, st);
-      }
-      if (signal(ev(l, EV_X), st)) return fail("event record failed");
     }
     // ---- aux: y update (transformer_model.py:239-246, :101-106) and the next layer's FiLM vectors
     const bool next_layer = l + 1 < n_run_layers;
@@ -609,6 +594,38 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       AddLnArgs ln2{w.y, w.yt1, g2->p, b2->p, nullptr, w.y, B, dy, nullptr, nullptr};
       launch_add_layernorm(ln2, ax);
     }
+    // ---- main: X path (transformer_model.py:234-235, :88-92)
+    {
+      const Param* g1 = P_(h, p + "normX1.weight", dx); const Param* b1 = P_(h, p + "normX1.bias", dx);
+      const Param* g2 = P_(h, p + "normX2.weight", dx); const Param* b2 = P_(h, p + "normX2.bias", dx);
+      if (!g1 || !b1 || !g2 || !b2) return -1;
+      if (fused_y && l + 1 < n_run_layers && await(st, ev(l + 1, EV_FILM))) return fail("stream wait failed");
+      // in place: X is overwritten from here on, its pooled statistics must have been taken; double-buffered: nothing
+      // to wait for (the buffer written now was last read two layers ago)
+      if (!dbl_X && await(st, ev(l, EV_NS))) return fail("stream wait failed");
+      if (fused_node) {
+        const bool next = l + 1 < n_run_layers;
+        NodeLayerArgs na{w.attn, mask, film, Xcur, w.rows, w.row_count, L.x_out.W, L.x_out.b, g1->p, b1->p,
+                         L.linX1.W, L.linX1.b, L.linX2.W, L.linX2.b, g2->p, b2->p,
+                         next ? h->layers[l + 1].qkv.W : nullptr, next ? h->layers[l + 1].qkv.b : nullptr, w.qkv, n,
+                         L.x_out.W3, L.linX1.W3, L.linX2.W3, next ? h->layers[l + 1].qkv.W3 : nullptr,
+                         dbl_X ? Xalt : Xcur};
+        if (launch_node_layer(na, dx, c.dim_ffX, M, st)) return fail("node_layer launch failed");
+        if (dbl_X) { float* tx = Xcur; Xcur = Xalt; Xalt = tx; }
+      } else {
+        if (node_lin(h, L.x_out, sa + "x_out", w.newX, dx, w.t1, dx, M, dx, dx, false, true, mask, w.rows, w.row_count, st))
+          return -1;
+        AddLnArgs ln1{Xcur, w.t1, g1->p, b1->p, nullptr, Xcur, M, dx, w.rows, w.row_count};
+        if (launch_add_layernorm(ln1, st)) return fail("layernorm width %d unsupported", dx);
+        if (node_lin(h, L.linX1, p + "linX1", Xcur, dx, w.t2, c.dim_ffX, M, c.dim_ffX, dx, true, false, mask, w.rows,
+                     w.row_count, st)) return -1;
+        if (node_lin(h, L.linX2, p + "linX2", w.t2, c.dim_ffX, w.t1, dx, M, dx, c.dim_ffX, false, false, mask, w.rows,
+                     w.row_count, st)) return -1;
+        AddLnArgs ln2{Xcur, w.t1, g2->p, b2->p, mask, Xcur, M, dx, w.rows, w.row_count};
+        launch_add_layernorm(ln2, st);
+      }
+      if (signal(ev(l, EV_X), st)) return fail("event record failed");
+    }
     float* t = Ecur; Ecur = Enext; Enext = t;
     if (check_launch("layer")) return -1;
   }
@@ -617,7 +634,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
 
   if (tap) {
     if (signal(ev_join, ax) || await(st, ev_join)) return fail("stream join failed");
-    if (o1) launch_copy_cols(w.Xh, dx, o1, dx, M, dx, st);
+    if (o1) launch_copy_cols(Xcur, dx, o1, dx, M, dx, st);
     if (o2) {
       const long long total = (long long)M * n * de;
       hipLaunchKernelGGL(sym_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ecur, mask, o2, B, n, de);
@@ -628,7 +645,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
 
   // ---- output MLPs (transformer_model.py:371-389): E on the main stream, X and y beside it on the aux stream
   if (c.out_X > 0) {
-    if (gemm(w.Xh, dx, P_(h, "mlp_out_X.0.weight", (int64_t)c.hid_X * dx), P_(h, "mlp_out_X.0.bias", c.hid_X), w.hidX,
+    if (gemm(Xcur, dx, P_(h, "mlp_out_X.0.weight", (int64_t)c.hid_X * dx), P_(h, "mlp_out_X.0.bias", c.hid_X), w.hidX,
              c.hid_X, M, c.hid_X, dx, GEMM_RELU, nullptr, ax)) return -1;
     if (gemm(w.hidX, c.hid_X, P_(h, "mlp_out_X.3.weight", (int64_t)c.out_X * c.hid_X), P_(h, "mlp_out_X.3.bias", c.out_X),
              w.xo, c.out_X, M, c.out_X, c.hid_X, 0, nullptr, ax)) return -1;

@@ -152,6 +152,7 @@ struct NodeLayerArgs {    // fused node part of one layer (node_layer.hip); pack
   int n;
   // the same four weight matrices as three-term bf16 images (launch_pack_linear_x3) for the x3 kernel
   const f32x4_t* W3_xout; const f32x4_t* W3_lin1; const f32x4_t* W3_lin2; const f32x4_t* W3_qkv;
+  float* X_out;           // where the updated residual stream goes (X itself: in place)
 };
 bool node_layer_supported(int dx, int ffx);
 int launch_node_layer(const NodeLayerArgs& a, int dx, int ffx, int M, hipStream_t st);

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(512) void node_layer_kernel(NodeLayerArgs a) {
   }
   __syncthreads();
   // ---- X = normX2(X + ff): global and bufB (every row of the tile is a valid node, so the node mask is 1)
-  tile_add_layernorm<DX, LD>(res, bufA, bufB, a.ln2_g, a.ln2_b, wave, lane, a.X, grow, gok);
+  tile_add_layernorm<DX, LD>(res, bufA, bufB, a.ln2_g, a.ln2_b, wave, lane, a.X_out, grow, gok);
   if (a.W_qkv == nullptr) return;
   __syncthreads();
   // ---- q | k | v of the next layer: bufB -> global
@@ -231,33 +231,48 @@ __device__ __forceinline__ void put_split4(__bf16* planes, int r, int c, const f
 }
 
 struct NFrag3 { nu32x4 h, m, l; };
+constexpr int NWD = 4;                                       // weight chunks in flight per wave
+struct NWRing {
+  NFrag3 f[NWD];
+  const nu32x4* next;                                        // block whose first NWD chunks the ring holds (null: none)
+};
 
-// acc (C layout of the 32x32 MFMA: tile row on lane & 31, 32 output channels of block rb in the registers) += W[rb] . X^T
-// w3: the x3 image (block rb starts at rb * KC * 192 slots); planes: the split operand tile
+// slot pointer of output block rb of an x3 image with KC chunks per block
+__device__ __forceinline__ const nu32x4* w3_block(const f32x4* w3, int rb, int KC, int lane) {
+  return reinterpret_cast<const nu32x4*>(w3) + (size_t)rb * KC * 192 + lane;
+}
+__device__ __forceinline__ void w3_load(NFrag3& f, const nu32x4* w, int kc) {
+  f.h = w[kc * 192];
+  f.m = w[kc * 192 + 64];
+  f.l = w[kc * 192 + 128];
+}
+// start the stream of a block: its first NWD chunks (L2 latency ~1 us: issued ahead of whatever precedes the Linear)
+__device__ __forceinline__ void w3_prime(NWRing& r, const nu32x4* w) {
+#pragma unroll
+  for (int d = 0; d < NWD; ++d) w3_load(r.f[d], w, d);
+  r.next = w;
+}
+
+// acc (C layout of the 32x32 MFMA: tile row on lane & 31, 32 output channels of the block in the registers) += W . X^T
+// w: this wave's block of the x3 image (w3_block); planes: the split operand tile.  The ring holds the block's first
+// NWD chunks on entry when r.next == w (else they are fetched here); on exit it holds those of `wnext` (when not null).
 template <int KC, int KS, int PLANE>
-__device__ __forceinline__ void tile_linear_x3(f32x16& acc, const f32x4* __restrict__ w3, int rb, const __bf16* planes,
-                                               int p, int h, int lane) {
-  constexpr int D = 4;                                       // weight chunks in flight
-  const nu32x4* w = reinterpret_cast<const nu32x4*>(w3) + (size_t)rb * KC * 192 + lane;
+__device__ __forceinline__ void tile_linear_x3(f32x16& acc, NWRing& r, const nu32x4* w, const nu32x4* wnext,
+                                               const __bf16* planes, int p, int h) {
+  static_assert(KC >= NWD, "K too small for the weight ring");
   const __bf16* x = planes + p * KS + 8 * h;
-  NFrag3 wf[D], xf[2];
-  auto wload = [&](NFrag3& f, int kc) {
-    f.h = w[kc * 192];
-    f.m = w[kc * 192 + 64];
-    f.l = w[kc * 192 + 128];
-  };
+  NFrag3 xf[2];
   auto xload = [&](NFrag3& f, int kc) {
     f.h = *reinterpret_cast<const nu32x4*>(x + 16 * kc);
     f.m = *reinterpret_cast<const nu32x4*>(x + 16 * kc + PLANE);
     f.l = *reinterpret_cast<const nu32x4*>(x + 16 * kc + 2 * PLANE);
   };
-#pragma unroll
-  for (int d = 0; d < D && d < KC; ++d) wload(wf[d], d);
+  if (r.next != w) w3_prime(r, w);                           // wave-uniform
   xload(xf[0], 0);
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) {
     if (kc + 1 < KC) xload(xf[(kc + 1) & 1], kc + 1);
-    const NFrag3& a = wf[kc % D];
+    const NFrag3& a = r.f[kc % NWD];
     const NFrag3& b = xf[kc & 1];
     __builtin_amdgcn_sched_barrier(0);
 #define SCGG_NB(v) __builtin_bit_cast(nbf16x8, v)
@@ -269,8 +284,10 @@ __device__ __forceinline__ void tile_linear_x3(f32x16& acc, const f32x4* __restr
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SCGG_NB(a.h), SCGG_NB(b.h), acc, 0, 0, 0);
 #undef SCGG_NB
     __builtin_amdgcn_sched_barrier(0);
-    if (kc + D < KC) wload(wf[kc % D], kc + D);
+    if (kc + NWD < KC) w3_load(r.f[kc % NWD], w, kc + NWD);
+    else if (wnext != nullptr) w3_load(r.f[kc % NWD], wnext, kc + NWD - KC);
   }
+  r.next = wnext;
 }
 
 // as tile_add_layernorm, with the normalised rows written as split planes (the next Linear's operand)
@@ -312,6 +329,16 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
   const int count = *a.row_count;
   const int tile = blockIdx.x;
   if (tile * 32 >= count) return;
+  // this wave's blocks of the four weight images, in order of use; each Linear leaves the ring primed for the next one
+  constexpr int KCX = DX / 16, KCF = FX / 16;
+  const bool has_qkv = a.W3_qkv != nullptr;
+  const nu32x4* w_xout = wave < DXB ? w3_block(a.W3_xout, wave, KCX, lane) : nullptr;
+  const nu32x4* w_lin1 = wave < FXB ? w3_block(a.W3_lin1, wave, KCX, lane) : nullptr;
+  const nu32x4* w_lin2 = wave < DXB ? w3_block(a.W3_lin2, wave, KCF, lane) : nullptr;
+  const nu32x4* w_qkv0 = has_qkv && wave < 3 * DXB ? w3_block(a.W3_qkv, wave, KCX, lane) : nullptr;
+  NWRing ring;
+  ring.next = nullptr;
+  if (w_xout != nullptr) w3_prime(ring, w_xout);
 
   // ---- prologue: this wave's 4 rows: newX_pre from the attention partials of the row's units, residual X
   const int n = a.n, nch = (n + 15) >> 4;
@@ -359,7 +386,7 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
   // ---- x_out: S1 -> F
   for (int rb = wave; rb < DXB; rb += 8) {
     f32x16 acc = load_vec_block(a.b_xout + 32 * rb, h);
-    tile_linear_x3<DX / 16, KS, PLANE>(acc, a.W3_xout, rb, S1, p, h, lane);
+    tile_linear_x3<KCX, KS, PLANE>(acc, ring, w_xout, w_lin1, S1, p, h);
     store_vec_block(F + p * LD + 32 * rb, h, acc);
   }
   __syncthreads();
@@ -369,7 +396,7 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
   // ---- linX1 + relu: S1 -> S2
   for (int rb = wave; rb < FXB; rb += 8) {
     f32x16 acc = load_vec_block(a.b_lin1 + 32 * rb, h);
-    tile_linear_x3<DX / 16, KS, PLANE>(acc, a.W3_lin1, rb, S1, p, h, lane);
+    tile_linear_x3<KCX, KS, PLANE>(acc, ring, w_lin1, w_lin2, S1, p, h);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 t;
@@ -382,12 +409,12 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
   // ---- linX2: S2 -> F
   for (int rb = wave; rb < DXB; rb += 8) {
     f32x16 acc = load_vec_block(a.b_lin2 + 32 * rb, h);
-    tile_linear_x3<FX / 16, KS, PLANE>(acc, a.W3_lin2, rb, S2, p, h, lane);
+    tile_linear_x3<KCF, KS, PLANE>(acc, ring, w_lin2, w_qkv0, S2, p, h);
     store_vec_block(F + p * LD + 32 * rb, h, acc);
   }
   __syncthreads();
   // ---- X = normX2(X + ff): global and S1 (every row of the tile is a valid node, so the node mask is 1)
-  tile_add_layernorm_x3<DX, LD, KS, PLANE>(res, F, S1, a.ln2_g, a.ln2_b, wave, lane, a.X, grow, gok);
+  tile_add_layernorm_x3<DX, LD, KS, PLANE>(res, F, S1, a.ln2_g, a.ln2_b, wave, lane, a.X_out, grow, gok);
   if (a.W3_qkv == nullptr) return;
   __syncthreads();
   // ---- q | k | v of the next layer: S1 -> global
@@ -397,7 +424,8 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
     const long long row = a.rows[ok ? ridx : count - 1];
     for (int rb = wave; rb < 3 * DXB; rb += 8) {
       f32x16 acc = load_vec_block(a.b_qkv + 32 * rb, h);
-      tile_linear_x3<DX / 16, KS, PLANE>(acc, a.W3_qkv, rb, S1, p, h, lane);
+      const nu32x4* wn = rb + 8 < 3 * DXB ? w3_block(a.W3_qkv, rb + 8, KCX, lane) : nullptr;
+      tile_linear_x3<KCX, KS, PLANE>(acc, ring, w3_block(a.W3_qkv, rb, KCX, lane), wn, S1, p, h);
       if (ok) store_vec_block(a.qkv + row * (3 * DX) + 32 * rb, h, acc);
     }
   }
