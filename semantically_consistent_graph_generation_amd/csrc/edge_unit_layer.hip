@@ -1121,101 +1121,95 @@ int launch_attn_finish(const AttnFinishArgs& a, int M, hipStream_t st) {
 // is read once per pass (pair {i,j} = 0.5 (E_ij + E_ji), weight 2); two passes (mean, then centred squares -- the
 // second pass is an L2 read).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void edge_pool_stats_kernel(EdgePoolArgs a) {
-  __shared__ float red[3][256];
-  __shared__ float smean[256];
+constexpr int POOL_T = 512;                                               // threads per graph
+__global__ __launch_bounds__(POOL_T) void edge_pool_stats_kernel(EdgePoolArgs a) {
+  __shared__ f32x4 red[3][POOL_T];
+  __shared__ f32x4 smean[64];
   __shared__ short vidx[512];                                             // the valid nodes, in order
-  __shared__ int wcount[4];
+  __shared__ int wcount[POOL_T / 64];
   const int b = blockIdx.x, n = a.n, DE = a.de, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int S = 256 / DE, c = tid % DE, sl = tid / DE;
+  // thread = (4 channels c4, slice sl of the unordered pairs): one 16-byte load per stored element, 1 KiB per wave
+  const int G4 = DE / 4, S = POOL_T / G4, c4 = tid % G4, sl = tid / G4;
   const uint8_t* m = a.mask + (long long)b * n;
   int nv = 0;
-  for (int i0 = 0; i0 < n; i0 += 256) {                                   // compaction of the mask, 256 nodes a round
+  for (int i0 = 0; i0 < n; i0 += POOL_T) {                                // compaction of the mask
     const int i = i0 + tid;
     const bool v = i < n && m[i] != 0;
     const unsigned long long bal = __ballot(v);
     if (lane == 0) wcount[wave] = __popcll(bal);
     __syncthreads();
-    int off = nv;
-    for (int w = 0; w < wave; ++w) off += wcount[w];
+    int off = nv, tot = 0;
+    for (int w = 0; w < POOL_T / 64; ++w) {
+      if (w < wave) off += wcount[w];
+      tot += wcount[w];
+    }
     if (v) vidx[off + __popcll(bal & ((1ull << lane) - 1ull))] = (short)i;
-    nv += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    nv += tot;
     __syncthreads();
   }
-  const float* E = a.E + (long long)b * n * n * DE + c;
+  const float* E = a.E + (long long)b * n * n * DE + 4 * c4;
   const float cnt = (float)nv * (float)nv;
-  // ---- pass 1: sum, min, max over the unordered pairs ii < jj (slice sl takes rows ii = sl, sl+S, ...)
-  float sum = 0.f, mn = INFINITY, mx = -INFINITY;
-  if (sl < S)
-    for (int ii = sl; ii < nv; ii += S) {
-      const long long i = vidx[ii];
-      int jj = ii + 1;
-      for (; jj + 3 < nv; jj += 4) {
-        float v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const long long j = vidx[jj + u];
-          v[u] = 0.5f * (E[(i * n + j) * DE] + E[(j * n + i) * DE]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { sum += v[u]; mn = fminf(mn, v[u]); mx = fmaxf(mx, v[u]); }
-      }
-      for (; jj < nv; ++jj) {
-        const long long j = vidx[jj];
-        const float v = 0.5f * (E[(i * n + j) * DE] + E[(j * n + i) * DE]);
-        sum += v; mn = fminf(mn, v); mx = fmaxf(mx, v);
-      }
+  // the unordered pairs ii < jj in row-major order; slice sl takes pairs sl, sl + S, ...: (ii, r) walks that sequence,
+  // r = position inside row ii (jj = ii + 1 + r), row ii holds nv - 1 - ii pairs
+  auto walk = [&](auto&& use) {
+    int ii = 0, r = sl;
+    while (true) {
+      while (ii < nv - 1 && r >= nv - 1 - ii) { r -= nv - 1 - ii; ++ii; }
+      if (ii >= nv - 1) break;
+      const long long i = vidx[ii], j = vidx[ii + 1 + r];
+      const f32x4 x = *reinterpret_cast<const f32x4*>(E + (i * n + j) * DE);
+      const f32x4 y = *reinterpret_cast<const f32x4*>(E + (j * n + i) * DE);
+      use(0.5f * (x + y));
+      r += S;
     }
-  if (nv > 0) { mn = fminf(mn, 0.f); mx = fmaxf(mx, 0.f); }             // the diagonal
+  };
+  // ---- pass 1: sum, min, max
+  f32x4 sum = splat4(0.f), mn = splat4(INFINITY), mx = splat4(-INFINITY);
+  walk([&](const f32x4& v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sum[e] += v[e]; mn[e] = fminf(mn[e], v[e]); mx[e] = fmaxf(mx[e], v[e]); }
+  });
+  if (nv > 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { mn[e] = fminf(mn[e], 0.f); mx[e] = fmaxf(mx[e], 0.f); }   // the diagonal
+  }
   red[0][tid] = sum; red[1][tid] = mn; red[2][tid] = mx;
   __syncthreads();
   if (sl == 0) {
     for (int t = 1; t < S; ++t) {
-      sum += red[0][t * DE + c];
-      mn = fminf(mn, red[1][t * DE + c]);
-      mx = fmaxf(mx, red[2][t * DE + c]);
+      const f32x4 s2 = red[0][t * G4 + c4], n2 = red[1][t * G4 + c4], x2 = red[2][t * G4 + c4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { sum[e] += s2[e]; mn[e] = fminf(mn[e], n2[e]); mx[e] = fmaxf(mx[e], x2[e]); }
     }
-    smean[c] = 2.f * sum / cnt;
-    red[1][c] = mn; red[2][c] = mx;
+    smean[c4] = sum * (2.f / cnt);
+    red[1][c4] = mn; red[2][c4] = mx;
   }
   __syncthreads();
   // ---- pass 2: centred squares (L2 reads)
-  const float mean = smean[c];
-  float q = 0.f;
-  if (sl < S)
-    for (int ii = sl; ii < nv; ii += S) {
-      const long long i = vidx[ii];
-      int jj = ii + 1;
-      for (; jj + 3 < nv; jj += 4) {
-        float v[4];
+  const f32x4 mean = smean[c4];
+  f32x4 q = splat4(0.f);
+  walk([&](const f32x4& v) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const long long j = vidx[jj + u];
-          v[u] = 0.5f * (E[(i * n + j) * DE] + E[(j * n + i) * DE]) - mean;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) q += v[u] * v[u];
-      }
-      for (; jj < nv; ++jj) {
-        const long long j = vidx[jj];
-        const float d = 0.5f * (E[(i * n + j) * DE] + E[(j * n + i) * DE]) - mean;
-        q += d * d;
-      }
-    }
+    for (int e = 0; e < 4; ++e) { const float d = v[e] - mean[e]; q[e] += d * d; }
+  });
   __syncthreads();
   red[0][tid] = q;
   __syncthreads();
   if (sl == 0) {
-    for (int t = 1; t < S; ++t) q += red[0][t * DE + c];
-    q = 2.f * q + (float)nv * mean * mean;                                // pairs count twice; nv diagonal zeros
-    float* z = a.z + (long long)b * a.z_stride + a.z_offset;
-    z[c] = mean; z[DE + c] = red[1][c]; z[2 * DE + c] = red[2][c]; z[3 * DE + c] = q / cnt;
+    for (int t = 1; t < S; ++t) q += red[0][t * G4 + c4];
+    float* z = a.z + (long long)b * a.z_stride + a.z_offset + 4 * c4;
+    const f32x4 mnv = red[1][c4], mxv = red[2][c4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float qq = 2.f * q[e] + (float)nv * mean[e] * mean[e];        // pairs count twice; nv diagonal zeros
+      z[e] = mean[e]; z[DE + e] = mnv[e]; z[2 * DE + e] = mxv[e]; z[3 * DE + e] = qq / cnt;
+    }
   }
 }
 
 int launch_edge_pool_stats(const EdgePoolArgs& a, hipStream_t st) {
-  if (a.de > 256 || 256 % a.de != 0 || a.n > 512) return -1;
-  hipLaunchKernelGGL(edge_pool_stats_kernel, dim3(a.B), dim3(256), 0, st, a);
+  if (a.de > 256 || a.de % 4 != 0 || POOL_T % (a.de / 4) != 0 || a.n > 512) return -1;
+  hipLaunchKernelGGL(edge_pool_stats_kernel, dim3(a.B), dim3(POOL_T), 0, st, a);
   return 0;
 }
 

@@ -203,7 +203,7 @@ struct PackArgs {
   int N, K, NB, KB;
 };
 int launch_pack_linear(const PackArgs& a, hipStream_t st);
-// three-term bf16 image of W for node_layer_x3_kernel: [NB][K/16][term][64 lanes] x 16 bytes (Wp holds NB*(K/16)*192 slots)
+// three-term bf16 image of W for node_layer_x3_kernel: [2 NB][K/32][term][64 lanes] x 16 bytes (Wp holds NB*(K/16)*192 slots)
 int launch_pack_linear_x3(const PackArgs& a, hipStream_t st);
 int launch_pad_vec(const float* src, float* dst, int n, int n_pad, float add, hipStream_t st);
 int launch_copy_cols(const float* src, int lds, float* dst, int ldd, int M, int ncols, hipStream_t st);

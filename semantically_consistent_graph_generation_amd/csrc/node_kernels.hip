@@ -308,12 +308,12 @@ __global__ void pack_linear_kernel(PackArgs a) {
   }
 }
 
-// Three-term bf16 image (x = h + m + l by truncation, exact) for v_mfma_f32_32x32x16_bf16 with W as the A operand:
-// slot ((rb * KC + kc) * 3 + term) * 64 + lane holds, for output channel 32 rb + (lane & 31), the 8 input channels
-// 16 kc + 8 (lane >> 5) + 0..7 as packed bf16 pairs.
+// Three-term bf16 image (x = h + m + l by truncation, exact) for v_mfma_f32_16x16x32_bf16 with W as the A operand:
+// slot ((ob * KC + kc) * 3 + term) * 64 + lane holds, for output channel 16 ob + (lane & 15), the 8 input channels
+// 32 kc + 8 (lane >> 4) + 0..7 as packed bf16 pairs (ob < 2 NB: 16-channel blocks, KC = K / 32).
 __global__ void pack_linear_x3_kernel(PackArgs a) {
-  const int KC = a.K / 16;
-  const long long total = (long long)a.NB * KC * 192;
+  const int KC = a.K / 32;
+  const long long total = (long long)2 * a.NB * KC * 192;
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
@@ -321,12 +321,12 @@ __global__ void pack_linear_x3_kernel(PackArgs a) {
     const long long q = idx >> 6;
     const int term = (int)(q % 3);
     const long long rk = q / 3;
-    const int kc = (int)(rk % KC), rb = (int)(rk / KC);
-    const int nn = 32 * rb + (lane & 31);
+    const int kc = (int)(rk % KC), ob = (int)(rk / KC);
+    const int nn = 16 * ob + (lane & 15);
     unsigned hw[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int k = 16 * kc + 8 * (lane >> 5) + i;
+      const int k = 32 * kc + 8 * (lane >> 4) + i;
       float x = (nn < a.N && k < a.K) ? a.W[(long long)nn * a.K + k] : 0.f;
       for (int t = 0; t < term; ++t) x = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
       hw[i] = __float_as_uint(x) >> 16;
@@ -339,7 +339,8 @@ __global__ void pack_linear_x3_kernel(PackArgs a) {
 }
 
 int launch_pack_linear_x3(const PackArgs& a, hipStream_t st) {
-  const long long total = (long long)a.NB * (a.K / 16) * 192;
+  if (a.K % 32 != 0) return -1;
+  const long long total = (long long)2 * a.NB * (a.K / 32) * 192;
   hipLaunchKernelGGL(pack_linear_x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
   return 0;
 }

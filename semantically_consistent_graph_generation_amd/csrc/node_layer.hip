@@ -185,10 +185,15 @@ __global__ __launch_bounds__(512) void node_layer_kernel(NodeLayerArgs a) {
 // =========================================================================================================
 // The same layer on the bf16 matrix pipe with fp32 accuracy ("x3", see edge_unit_layer.hip): every Linear operand is
 // split exactly into three bf16 terms (weights at pack time: launch_pack_linear_x3; activations when they are written
-// to LDS, once per element) and a product is the six leading partial products on v_mfma_f32_32x32x16_bf16 = 6/16 of
-// the fp32 MFMA time.  The tile's operand lives in LDS as three bf16 planes [32][K + 8]; results that feed a LayerNorm
-// go through an fp32 buffer.  Weight blocks (3 x 16 B per lane per 16-channel K chunk) stream from L2 four chunks
-// ahead of their MFMAs.
+// to LDS, once per element) and a product is the six leading partial products on v_mfma_f32_16x16x32_bf16 = 6/16 of
+// the fp32 MFMA time.
+//
+// Tile = 48 valid rows (three 16-row groups): the 10 917 rows of the headline workload are 228 tiles, ONE round on 256
+// CUs (32-row tiles were 342 = two rounds, and a tile's time is mostly its chain of barriers and latencies, not its
+// MFMAs).  The tile's operand lives in LDS as three bf16 planes [48][K + 8]; results that feed a LayerNorm go through
+// an fp32 buffer.  Two LDS regions alternate: planes(R1) -x_out-> fp32(R2) -LN1-> planes(R1) -linX1-> planes(R2)
+// -linX2-> fp32(R1) -LN2-> planes(R2) -qkv-> global.  A wave owns two 16-channel output blocks at a time; their weight
+// blocks (3 x 16 B per lane per 32-channel K chunk) stream from L2 two chunks ahead, across Linear boundaries.
 // =========================================================================================================
 typedef unsigned nu32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned nu32x2 __attribute__((ext_vector_type(2)));
@@ -197,12 +202,14 @@ typedef __bf16 nbf16x8 __attribute__((ext_vector_type(8)));
 template <int DXB, int FXB>
 struct NodeGeomX3 {
   static constexpr int DX = 32 * DXB, FX = 32 * FXB;
+  static constexpr int TR = 48, NRG = TR / 16;              // tile rows, 16-row groups
   static constexpr int KMAX = DX > FX ? DX : FX;
   static constexpr int KS = KMAX + 8;                       // bf16 row stride of a plane: 4 banks (mod 32) per row
-  static constexpr int PLANE = 32 * KS;                     // bf16 elements per term plane
+  static constexpr int PLANE = TR * KS;                     // bf16 elements per term plane
   static constexpr int LD = KMAX + 4;                       // fp32 result buffer stride
-  static constexpr size_t SPLIT_BYTES = (size_t)3 * PLANE * 2;
-  static constexpr size_t LDS_BYTES = 2 * SPLIT_BYTES + (size_t)32 * LD * 4;
+  static constexpr size_t SPLIT_BYTES = (size_t)3 * PLANE * 2, F_BYTES = (size_t)TR * LD * 4;
+  static constexpr size_t REGION = SPLIT_BYTES > F_BYTES ? SPLIT_BYTES : F_BYTES;
+  static constexpr size_t LDS_BYTES = 2 * REGION;
 };
 
 // exact three-way bf16 split of 4 consecutive channels -> 8 bytes per term
@@ -231,74 +238,94 @@ __device__ __forceinline__ void put_split4(__bf16* planes, int r, int c, const f
 }
 
 struct NFrag3 { nu32x4 h, m, l; };
-constexpr int NWD = 4;                                       // weight chunks in flight per wave
+constexpr int NWD = 2;                                       // K chunks of weights in flight per wave
 struct NWRing {
-  NFrag3 f[NWD];
-  const nu32x4* next;                                        // block whose first NWD chunks the ring holds (null: none)
+  NFrag3 f[NWD][2];                                          // [chunk slot][output block of the pair]
+  const nu32x4* next;                                        // block pair whose first NWD chunks the ring holds (null: none)
 };
 
-// slot pointer of output block rb of an x3 image with KC chunks per block
-__device__ __forceinline__ const nu32x4* w3_block(const f32x4* w3, int rb, int KC, int lane) {
-  return reinterpret_cast<const nu32x4*>(w3) + (size_t)rb * KC * 192 + lane;
+// slot pointer of 16-channel output block ob of an x3 image with KC 32-channel chunks per block
+__device__ __forceinline__ const nu32x4* w3_block(const f32x4* w3, int ob, int KC, int lane) {
+  return reinterpret_cast<const nu32x4*>(w3) + (size_t)ob * KC * 192 + lane;
 }
-__device__ __forceinline__ void w3_load(NFrag3& f, const nu32x4* w, int kc) {
-  f.h = w[kc * 192];
-  f.m = w[kc * 192 + 64];
-  f.l = w[kc * 192 + 128];
+template <int KC>
+__device__ __forceinline__ void w3_load(NFrag3 (&f)[2], const nu32x4* w, int kc) {
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    f[blk].h = w[(blk * KC + kc) * 192];
+    f[blk].m = w[(blk * KC + kc) * 192 + 64];
+    f[blk].l = w[(blk * KC + kc) * 192 + 128];
+  }
 }
-// start the stream of a block: its first NWD chunks (L2 latency ~1 us: issued ahead of whatever precedes the Linear)
+// start the stream of a block pair: its first NWD chunks (L2 latency ~1 us: issued ahead of whatever precedes the Linear)
+template <int KC>
 __device__ __forceinline__ void w3_prime(NWRing& r, const nu32x4* w) {
 #pragma unroll
-  for (int d = 0; d < NWD; ++d) w3_load(r.f[d], w, d);
+  for (int d = 0; d < NWD; ++d) w3_load<KC>(r.f[d], w, d);
   r.next = w;
 }
 
-// acc (C layout of the 32x32 MFMA: tile row on lane & 31, 32 output channels of the block in the registers) += W . X^T
-// w: this wave's block of the x3 image (w3_block); planes: the split operand tile.  The ring holds the block's first
-// NWD chunks on entry when r.next == w (else they are fetched here); on exit it holds those of `wnext` (when not null).
-template <int KC, int KS, int PLANE>
-__device__ __forceinline__ void tile_linear_x3(f32x16& acc, NWRing& r, const nu32x4* w, const nu32x4* wnext,
-                                               const __bf16* planes, int p, int h) {
-  static_assert(KC >= NWD, "K too small for the weight ring");
-  const __bf16* x = planes + p * KS + 8 * h;
-  NFrag3 xf[2];
-  auto xload = [&](NFrag3& f, int kc) {
-    f.h = *reinterpret_cast<const nu32x4*>(x + 16 * kc);
-    f.m = *reinterpret_cast<const nu32x4*>(x + 16 * kc + PLANE);
-    f.l = *reinterpret_cast<const nu32x4*>(x + 16 * kc + 2 * PLANE);
+// acc[blk][rg] (C layout of the 16x16 MFMA: tile row 16 rg + (lane & 15) on the lane, output channels 4 (lane >> 4) + r
+// of block blk in the registers) += W . X^T for the pair of 16-channel output blocks at w (consecutive in the image).
+// The ring holds the pair's first NWD chunks on entry when r.next == w (else they are fetched here); on exit it holds
+// those of `wnext` (KCN chunks per block; when not null).
+template <int KC, int KCN, int KS, int PLANE, int NRG>
+__device__ __forceinline__ void tile_linear_x3(f32x4 (&acc)[2][NRG], NWRing& r, const nu32x4* w, const nu32x4* wnext,
+                                               const __bf16* planes, int p, int g) {
+  static_assert(KC >= NWD && KCN >= NWD, "K too small for the weight ring");
+  const __bf16* x = planes + p * KS + 8 * g;
+  NFrag3 xf[2][NRG];
+  auto xload = [&](NFrag3 (&f)[NRG], int kc) {
+#pragma unroll
+    for (int rg = 0; rg < NRG; ++rg) {
+      const __bf16* q = x + rg * 16 * KS + 32 * kc;
+      f[rg].h = *reinterpret_cast<const nu32x4*>(q);
+      f[rg].m = *reinterpret_cast<const nu32x4*>(q + PLANE);
+      f[rg].l = *reinterpret_cast<const nu32x4*>(q + 2 * PLANE);
+    }
   };
-  if (r.next != w) w3_prime(r, w);                           // wave-uniform
+  if (r.next != w) w3_prime<KC>(r, w);                       // wave-uniform
   xload(xf[0], 0);
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) {
     if (kc + 1 < KC) xload(xf[(kc + 1) & 1], kc + 1);
-    const NFrag3& a = r.f[kc % NWD];
-    const NFrag3& b = xf[kc & 1];
     __builtin_amdgcn_sched_barrier(0);
 #define SCGG_NB(v) __builtin_bit_cast(nbf16x8, v)
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SCGG_NB(a.l), SCGG_NB(b.h), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SCGG_NB(a.h), SCGG_NB(b.l), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SCGG_NB(a.m), SCGG_NB(b.m), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SCGG_NB(a.m), SCGG_NB(b.h), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SCGG_NB(a.h), SCGG_NB(b.m), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SCGG_NB(a.h), SCGG_NB(b.h), acc, 0, 0, 0);
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const NFrag3& a = r.f[kc % NWD][blk];
+#pragma unroll
+      for (int rg = 0; rg < NRG; ++rg) {
+        const NFrag3& b = xf[kc & 1][rg];
+        f32x4 c = acc[blk][rg];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_NB(a.l), SCGG_NB(b.h), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_NB(a.h), SCGG_NB(b.l), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_NB(a.m), SCGG_NB(b.m), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_NB(a.m), SCGG_NB(b.h), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_NB(a.h), SCGG_NB(b.m), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_NB(a.h), SCGG_NB(b.h), c, 0, 0, 0);
+        acc[blk][rg] = c;
+      }
+    }
 #undef SCGG_NB
     __builtin_amdgcn_sched_barrier(0);
-    if (kc + NWD < KC) w3_load(r.f[kc % NWD], w, kc + NWD);
-    else if (wnext != nullptr) w3_load(r.f[kc % NWD], wnext, kc + NWD - KC);
+    if (kc + NWD < KC) w3_load<KC>(r.f[kc % NWD], w, kc + NWD);
+    else if (wnext != nullptr) w3_load<KCN>(r.f[kc % NWD], wnext, kc + NWD - KC);
   }
   r.next = wnext;
 }
 
-// as tile_add_layernorm, with the normalised rows written as split planes (the next Linear's operand)
-template <int DX, int LD, int KS, int PLANE>
-__device__ __forceinline__ void tile_add_layernorm_x3(f32x4 (&res)[4], const float* lin, __bf16* planes,
+// rows RPW w .. RPW w + RPW - 1 of the tile: res <- LN(res + lin) * gamma + beta (eps 1e-5, biased variance); the residual
+// stream stays in this wave's registers (lane = 4 channels), the normalised rows are written as split planes (the next
+// Linear's operand) and optionally to global
+template <int DX, int LD, int KS, int PLANE, int RPW>
+__device__ __forceinline__ void tile_add_layernorm_x3(f32x4 (&res)[RPW], const float* lin, __bf16* planes,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       int wave, int lane, float* gout, const long long* grow, const bool* gok) {
   const int c = lane * 4;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int r = wave * 4 + t;
+  for (int t = 0; t < RPW; ++t) {
+    const int r = wave * RPW + t;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (c < DX) v = res[t] + *reinterpret_cast<const f32x4*>(lin + r * LD + c);
     const float mean = wave_sum64(v[0] + v[1] + v[2] + v[3]) * (1.0f / DX);
@@ -319,34 +346,36 @@ __device__ __forceinline__ void tile_add_layernorm_x3(f32x4 (&res)[4], const flo
 template <int DXB, int FXB>
 __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
   using G = NodeGeomX3<DXB, FXB>;
-  constexpr int DX = G::DX, FX = G::FX, LD = G::LD, KS = G::KS, PLANE = G::PLANE;
+  constexpr int DX = G::DX, FX = G::FX, LD = G::LD, KS = G::KS, PLANE = G::PLANE, TR = G::TR, NRG = G::NRG;
+  constexpr int RPW = TR / 8;                                   // rows per wave in the row-wise parts
+  constexpr int KCX = DX / 32, KCF = FX / 32;                   // 32-channel K chunks
+  constexpr int NPX = DX / 32, NPF = FX / 32;                   // pairs of 16-channel output blocks of a Linear
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __bf16* S1 = reinterpret_cast<__bf16*>(smem);                 // split operand tiles
-  __bf16* S2 = S1 + 3 * PLANE;
-  float* F = reinterpret_cast<float*>(S2 + 3 * PLANE);          // fp32 results in front of the LayerNorms
-  f32x4 res[4];                                                 // residual stream X of this wave's 4 rows (lane = 4 channels)
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 31, h = lane >> 5;
+  char* R1 = smem;
+  char* R2 = smem + G::REGION;
+  f32x4 res[RPW];                                               // residual stream X of this wave's rows (lane = 4 channels)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int count = *a.row_count;
   const int tile = blockIdx.x;
-  if (tile * 32 >= count) return;
-  // this wave's blocks of the four weight images, in order of use; each Linear leaves the ring primed for the next one
-  constexpr int KCX = DX / 16, KCF = FX / 16;
+  if (tile * TR >= count) return;
+  // this wave's block pairs of the four weight images, in order of use; each Linear leaves the ring primed for the next
   const bool has_qkv = a.W3_qkv != nullptr;
-  const nu32x4* w_xout = wave < DXB ? w3_block(a.W3_xout, wave, KCX, lane) : nullptr;
-  const nu32x4* w_lin1 = wave < FXB ? w3_block(a.W3_lin1, wave, KCX, lane) : nullptr;
-  const nu32x4* w_lin2 = wave < DXB ? w3_block(a.W3_lin2, wave, KCF, lane) : nullptr;
-  const nu32x4* w_qkv0 = has_qkv && wave < 3 * DXB ? w3_block(a.W3_qkv, wave, KCX, lane) : nullptr;
+  const nu32x4* w_xout = wave < NPX ? w3_block(a.W3_xout, 2 * wave, KCX, lane) : nullptr;
+  const nu32x4* w_lin1 = wave < NPF ? w3_block(a.W3_lin1, 2 * wave, KCX, lane) : nullptr;
+  const nu32x4* w_lin2 = wave < NPX ? w3_block(a.W3_lin2, 2 * wave, KCF, lane) : nullptr;
+  const nu32x4* w_qkv0 = has_qkv && wave < 3 * NPX ? w3_block(a.W3_qkv, 2 * wave, KCX, lane) : nullptr;
   NWRing ring;
   ring.next = nullptr;
-  if (w_xout != nullptr) w3_prime(ring, w_xout);
+  if (w_xout != nullptr) w3_prime<KCX>(ring, w_xout);
 
-  // ---- prologue: this wave's 4 rows: newX_pre from the attention partials of the row's units, residual X
+  // ---- prologue: this wave's rows: newX_pre from the attention partials of the row's units, residual X
   const int n = a.n, nch = (n + 15) >> 4;
-  long long grow[4];
-  bool gok[4];
+  long long grow[RPW];
+  bool gok[RPW];
+  __bf16* S1 = reinterpret_cast<__bf16*>(R1);
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int ridx = tile * 32 + wave * 4 + t;
+  for (int t = 0; t < RPW; ++t) {
+    const int ridx = tile * TR + wave * RPW + t;
     gok[t] = ridx < count;
     const long long row = a.rows[gok[t] ? ridx : count - 1];
     grow[t] = row;
@@ -377,56 +406,92 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = fa[e] + fm[e] * (A[e] / S[e]);
-      put_split4<KS, PLANE>(S1, wave * 4 + t, c, o);
+      put_split4<KS, PLANE>(S1, wave * RPW + t, c, o);
       res[t] = *reinterpret_cast<const f32x4*>(a.X + row * DX + c);
     }
   }
   __syncthreads();
 
-  // ---- x_out: S1 -> F
-  for (int rb = wave; rb < DXB; rb += 8) {
-    f32x16 acc = load_vec_block(a.b_xout + 32 * rb, h);
-    tile_linear_x3<KCX, KS, PLANE>(acc, ring, w_xout, w_lin1, S1, p, h);
-    store_vec_block(F + p * LD + 32 * rb, h, acc);
-  }
-  __syncthreads();
-  // ---- X = normX1(X + newX): registers, and S1 as the next operand
-  tile_add_layernorm_x3<DX, LD, KS, PLANE>(res, F, S1, a.ln1_g, a.ln1_b, wave, lane, nullptr, grow, gok);
-  __syncthreads();
-  // ---- linX1 + relu: S1 -> S2
-  for (int rb = wave; rb < FXB; rb += 8) {
-    f32x16 acc = load_vec_block(a.b_lin1 + 32 * rb, h);
-    tile_linear_x3<KCX, KS, PLANE>(acc, ring, w_lin1, w_lin2, S1, p, h);
+  auto bias_acc = [&](f32x4 (&acc)[2][NRG], const float* bias, int ob0) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 t;
+    for (int blk = 0; blk < 2; ++blk) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 16 * (ob0 + blk) + 4 * g);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) t[e] = fmaxf(acc[4 * g + e], 0.f);
-      put_split4<KS, PLANE>(S2, p, 32 * rb + 8 * g + 4 * h, t);
+      for (int rg = 0; rg < NRG; ++rg) acc[blk][rg] = bv;
     }
+  };
+  // ---- x_out: planes(R1) -> fp32(R2)
+  if (wave < NPX) {
+    float* F = reinterpret_cast<float*>(R2);
+    f32x4 acc[2][NRG];
+    bias_acc(acc, a.b_xout, 2 * wave);
+    tile_linear_x3<KCX, KCX, KS, PLANE, NRG>(acc, ring, w_xout, w_lin1, S1, p, g);
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int rg = 0; rg < NRG; ++rg)
+        *reinterpret_cast<f32x4*>(F + (16 * rg + p) * LD + 16 * (2 * wave + blk) + 4 * g) = acc[blk][rg];
   }
   __syncthreads();
-  // ---- linX2: S2 -> F
-  for (int rb = wave; rb < DXB; rb += 8) {
-    f32x16 acc = load_vec_block(a.b_lin2 + 32 * rb, h);
-    tile_linear_x3<KCF, KS, PLANE>(acc, ring, w_lin2, w_qkv0, S2, p, h);
-    store_vec_block(F + p * LD + 32 * rb, h, acc);
+  // ---- X = normX1(X + newX): registers, and planes(R1) as the next operand
+  tile_add_layernorm_x3<DX, LD, KS, PLANE, RPW>(res, reinterpret_cast<const float*>(R2), S1, a.ln1_g, a.ln1_b, wave, lane,
+                                                nullptr, grow, gok);
+  __syncthreads();
+  // ---- linX1 + relu: planes(R1) -> planes(R2)
+  __bf16* S2 = reinterpret_cast<__bf16*>(R2);
+  if (wave < NPF) {
+    f32x4 acc[2][NRG];
+    bias_acc(acc, a.b_lin1, 2 * wave);
+    tile_linear_x3<KCX, KCF, KS, PLANE, NRG>(acc, ring, w_lin1, w_lin2, S1, p, g);
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int rg = 0; rg < NRG; ++rg) {
+        f32x4 t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = fmaxf(acc[blk][rg][e], 0.f);
+        put_split4<KS, PLANE>(S2, 16 * rg + p, 16 * (2 * wave + blk) + 4 * g, t);
+      }
   }
   __syncthreads();
-  // ---- X = normX2(X + ff): global and S1 (every row of the tile is a valid node, so the node mask is 1)
-  tile_add_layernorm_x3<DX, LD, KS, PLANE>(res, F, S1, a.ln2_g, a.ln2_b, wave, lane, a.X_out, grow, gok);
-  if (a.W3_qkv == nullptr) return;
+  // ---- linX2: planes(R2) -> fp32(R1)
+  if (wave < NPX) {
+    float* F = reinterpret_cast<float*>(R1);
+    f32x4 acc[2][NRG];
+    bias_acc(acc, a.b_lin2, 2 * wave);
+    tile_linear_x3<KCF, KCX, KS, PLANE, NRG>(acc, ring, w_lin2, w_qkv0, S2, p, g);
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int rg = 0; rg < NRG; ++rg)
+        *reinterpret_cast<f32x4*>(F + (16 * rg + p) * LD + 16 * (2 * wave + blk) + 4 * g) = acc[blk][rg];
+  }
   __syncthreads();
-  // ---- q | k | v of the next layer: S1 -> global
+  // ---- X = normX2(X + ff): global and planes(R2) (every row of the tile is a valid node, so the node mask is 1)
+  tile_add_layernorm_x3<DX, LD, KS, PLANE, RPW>(res, reinterpret_cast<const float*>(R1), S2, a.ln2_g, a.ln2_b, wave, lane,
+                                                a.X_out, grow, gok);
+  if (!has_qkv) return;
+  __syncthreads();
+  // ---- q | k | v of the next layer: planes(R2) -> global
   {
-    const int ridx = tile * 32 + p;
-    const bool ok = ridx < count;
-    const long long row = a.rows[ok ? ridx : count - 1];
-    for (int rb = wave; rb < 3 * DXB; rb += 8) {
-      f32x16 acc = load_vec_block(a.b_qkv + 32 * rb, h);
-      const nu32x4* wn = rb + 8 < 3 * DXB ? w3_block(a.W3_qkv, rb + 8, KCX, lane) : nullptr;
-      tile_linear_x3<KCX, KS, PLANE>(acc, ring, w3_block(a.W3_qkv, rb, KCX, lane), wn, S1, p, h);
-      if (ok) store_vec_block(a.qkv + row * (3 * DX) + 32 * rb, h, acc);
+    long long qrow[NRG];
+    bool qok[NRG];
+#pragma unroll
+    for (int rg = 0; rg < NRG; ++rg) {
+      const int ridx = tile * TR + 16 * rg + p;
+      qok[rg] = ridx < count;
+      qrow[rg] = a.rows[qok[rg] ? ridx : count - 1];
+    }
+    for (int pr = wave; pr < 3 * NPX; pr += 8) {
+      f32x4 acc[2][NRG];
+      bias_acc(acc, a.b_qkv, 2 * pr);
+      const nu32x4* wn = pr + 8 < 3 * NPX ? w3_block(a.W3_qkv, 2 * (pr + 8), KCX, lane) : nullptr;
+      tile_linear_x3<KCX, KCX, KS, PLANE, NRG>(acc, ring, w3_block(a.W3_qkv, 2 * pr, KCX, lane), wn, S2, p, g);
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int rg = 0; rg < NRG; ++rg)
+          if (qok[rg]) *reinterpret_cast<f32x4*>(a.qkv + qrow[rg] * (3 * DX) + 16 * (2 * pr + blk) + 4 * g) = acc[blk][rg];
     }
   }
 }
@@ -453,7 +518,8 @@ static int launch_one(const NodeLayerArgs& a, int M, hipStream_t st) {
       return -2;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((M + 31) / 32), dim3(512), lds, st, a);
+  const int rows_per_tile = x3 ? NodeGeomX3<DXB, FXB>::TR : 32;
+  hipLaunchKernelGGL(kern, dim3((M + rows_per_tile - 1) / rows_per_tile), dim3(512), lds, st, a);
   return 0;
 }
 
