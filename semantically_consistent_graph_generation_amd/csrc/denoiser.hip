@@ -431,8 +431,6 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   // ---- work lists (valid rows, 16-key units), then fork
   if (launch_build_lists(mask, B, n, w.goff, w.rows, w.row_count, w.units, w.unit_count, st))
     return fail("n=%d too large for the unit list (max 512)", n);
-  if (signal(ev_fork, st) || await(ax, ev_fork)) return fail("stream fork failed");
-
   // The residual stream X ping-pongs between two buffers when every layer runs the fused node kernel (w.t1 is only
   // used by the unfused path): node kernel l then never overwrites the X whose pooled statistics the y path is taking.
   bool dbl_X = node_layer_supported(dx, c.dim_ffX) && h->in_X2.W != nullptr && c.in_X <= 64 && c.hid_X % 4 == 0;
@@ -442,20 +440,26 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   }
   float* Xcur = w.Xh;
   float* Xalt = w.t1;
+  // valid rows only: the masked rows of the residual stream are zeroed once per forward, nothing writes them afterwards
+  // (on the caller's stream ahead of the fork: the second stream may still be busy with the caller's X / y producers)
+  if (h->in_X2.W != nullptr && c.in_X <= 64 && c.hid_X % 4 == 0) {
+    launch_zero_masked_rows(w.Xh, mask, M, dx, st);
+    if (dbl_X) launch_zero_masked_rows(w.t1, mask, M, dx, st);
+  }
+  if (signal(ev_fork, st) || await(ax, ev_fork)) return fail("stream fork failed");
+
   // ---- input MLPs (transformer_model.py:358-366): E on the main stream, X and y beside it on the aux stream
   {
     const Param* w0 = P_(h, "mlp_in_X.0.weight", (int64_t)c.hid_X * c.in_X); const Param* b0 = P_(h, "mlp_in_X.0.bias", c.hid_X);
     const Param* w3 = P_(h, "mlp_in_X.3.weight", (int64_t)dx * c.hid_X); const Param* b3 = P_(h, "mlp_in_X.3.bias", dx);
     if (!w0 || !b0 || !w3 || !b3) return -1;
     if (h->in_X2.W != nullptr && c.in_X <= 64 && c.hid_X % 4 == 0) {
-      // valid rows only: the masked rows of the residual stream are zeroed once, nothing writes them afterwards
-      launch_zero_masked_rows(w.Xh, mask, M, dx, ax);
-      if (dbl_X) launch_zero_masked_rows(w.t1, mask, M, dx, ax);
       NarrowLinearArgs na{X, w0->p, b0->p, w.hidX, w.rows, w.row_count, c.hid_X, c.in_X, c.in_X, c.hid_X, 1};
       if (launch_narrow_linear(na, M, ax)) return fail("narrow_linear rejected");
       NodeLinearArgs la{w.hidX, h->in_X2.W, h->in_X2.b, w.Xh, w.rows, w.row_count, dx, c.hid_X, (dx + 31) / 32, c.hid_X, dx,
                         (dx + 31) / 32 >= 4 ? 2 : 1, 1};
-      if (launch_node_linear(la, M, ax)) return fail("node_linear(mlp_in_X.3) rejected");
+      if (launch_node_linear_x3(la, h->in_X2.W3, M, ax) != 0 && launch_node_linear(la, M, ax))
+        return fail("node_linear(mlp_in_X.3) rejected");
     } else {
       if (gemm(X, c.in_X, w0, b0, w.hidX, c.hid_X, M, c.hid_X, c.in_X, GEMM_RELU, nullptr, ax)) return -1;
       if (gemm(w.hidX, c.hid_X, w3, b3, w.Xh, dx, M, dx, c.hid_X, GEMM_RELU | GEMM_ROWMASK, mask, ax)) return -1;
@@ -489,7 +493,8 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       } else if (L.qkv.W != nullptr) {
         NodeLinearArgs qa{Xcur, L.qkv.W, L.qkv.b, w.qkv, w.rows, w.row_count, 3 * dx, dx, (3 * dx + 31) / 32, dx, 3 * dx,
                           dx >= 256 ? 8 : (3 * dx + 31) / 32, 0};
-        if (launch_node_linear(qa, M, qs)) return fail("node_linear(qkv) rejected");
+        if (launch_node_linear_x3(qa, L.qkv.W3, M, qs) != 0 && launch_node_linear(qa, M, qs))
+          return fail("node_linear(qkv) rejected");
       } else if (gemm_raw(Xcur, dx, L.Wqkv, L.bqkv, w.qkv, 3 * dx, M, 3 * dx, dx, GEMM_ROWMASK, mask, qs)) return -1;
     }
     // ---- aux: y-FiLM vectors (with the +1 folded in), Xtoy pooled statistics of the layer INPUT (:239-243)

@@ -134,6 +134,8 @@ struct NodeLinearArgs {   // row-list Linear on pre-packed weights (node path)
   int N, K, NB, lda, ldc, rbw, relu;
 };
 int launch_node_linear(const NodeLinearArgs& a, int M, hipStream_t st);
+// the same Linear on the bf16x3 scheme (node_layer.hip; W3 from launch_pack_linear_x3); -1: shape not covered, use the above
+int launch_node_linear_x3(const NodeLinearArgs& a, const f32x4_t* W3, int M, hipStream_t st);
 
 struct NodeLayerArgs {    // fused node part of one layer (node_layer.hip); packed weights as for NodeLinearArgs
   const float* attn_part; // [B*n*nch, 3, dx] per-unit attention partials of this layer's edge kernel

@@ -496,6 +496,81 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Row-list Linear on the same scheme (mlp_in_X.3 and layer 0's q|k|v, the two Linears in front of the first edge kernel):
+// C[row, :N] = act(A[row, :K] . W^T + bias) for the valid rows.  48-row tiles; the operand rows are split into planes once,
+// each wave walks output block pairs w, w + 8, ...
+// ---------------------------------------------------------------------------------------------------------
+template <int KC>
+__global__ __launch_bounds__(512) void node_linear_x3_kernel(NodeLinearArgs a, const f32x4* W3) {
+  constexpr int K = 32 * KC, TR = 48, NRG = 3, KS = K + 8, PLANE = TR * KS, RPW = TR / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* S = reinterpret_cast<__bf16*>(smem);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int count = *a.row_count;
+  const int tile = blockIdx.x;
+  if (tile * TR >= count) return;
+  const int npairs = (a.N + 31) / 32;
+  NWRing ring;
+  ring.next = nullptr;
+  if (wave < npairs) w3_prime<KC>(ring, w3_block(W3, 2 * wave, KC, lane));
+#pragma unroll
+  for (int t = 0; t < RPW; ++t) {
+    const int ridx = tile * TR + wave * RPW + t;
+    const long long row = a.rows[ridx < count ? ridx : count - 1];
+    const int c = lane * 4;
+    if (c < K) put_split4<KS, PLANE>(S, wave * RPW + t, c, *reinterpret_cast<const f32x4*>(a.A + row * a.lda + c));
+  }
+  long long qrow[NRG];
+  bool qok[NRG];
+#pragma unroll
+  for (int rg = 0; rg < NRG; ++rg) {
+    const int ridx = tile * TR + 16 * rg + p;
+    qok[rg] = ridx < count;
+    qrow[rg] = a.rows[qok[rg] ? ridx : count - 1];
+  }
+  __syncthreads();
+  for (int pr = wave; pr < npairs; pr += 8) {
+    f32x4 acc[2][NRG];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + 16 * (2 * pr + blk) + 4 * g);
+#pragma unroll
+      for (int rg = 0; rg < NRG; ++rg) acc[blk][rg] = bv;
+    }
+    const nu32x4* wn = pr + 8 < npairs ? w3_block(W3, 2 * (pr + 8), KC, lane) : nullptr;
+    tile_linear_x3<KC, KC, KS, PLANE, NRG>(acc, ring, w3_block(W3, 2 * pr, KC, lane), wn, S, p, g);
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const int c0 = 16 * (2 * pr + blk) + 4 * g;
+#pragma unroll
+      for (int rg = 0; rg < NRG; ++rg) {
+        f32x4 o = acc[blk][rg];
+        if (a.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        }
+        if (qok[rg] && c0 < a.N) *reinterpret_cast<f32x4*>(a.C + qrow[rg] * a.ldc + c0) = o;
+      }
+    }
+  }
+}
+
+template <int KC>
+static int launch_linear_x3(const NodeLinearArgs& a, const f32x4* W3, int M, hipStream_t st) {
+  constexpr size_t lds = (size_t)3 * 48 * (32 * KC + 8) * 2;
+  static bool attr_set = false;
+  auto kern = node_linear_x3_kernel<KC>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
+      return -2;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((M + 47) / 48), dim3(512), lds, st, a, W3);
+  return 0;
+}
+
 // SCGG_NODE_MODE=f32 selects the plain fp32-MFMA kernel (development A/B switch); default: the x3 kernel
 static bool node_x3() {
   static int mode = -1;
@@ -524,6 +599,14 @@ static int launch_one(const NodeLayerArgs& a, int M, hipStream_t st) {
 }
 
 bool node_layer_supported(int dx, int ffx) { return (dx == 256 && ffx == 256) || (dx == 128 && ffx == 128); }
+
+// row-list Linear through the x3 kernel when the shape allows (K = 128 or 256, N a multiple of 4, padded bias), else -1
+int launch_node_linear_x3(const NodeLinearArgs& a, const f32x4_t* W3, int M, hipStream_t st) {
+  if (!node_x3() || W3 == nullptr || a.lda % 4 != 0 || a.ldc % 4 != 0 || a.N % 4 != 0) return -1;
+  if (a.K == 256) return launch_linear_x3<8>(a, W3, M, st);
+  if (a.K == 128) return launch_linear_x3<4>(a, W3, M, st);
+  return -1;
+}
 
 int launch_node_layer(const NodeLayerArgs& a, int dx, int ffx, int M, hipStream_t st) {
   if (dx == 256 && ffx == 256) return launch_one<8, 8>(a, M, st);
