@@ -1005,11 +1005,7 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
 
     // ================================================================== E <- LN1(E + newE), FFN phases
     // One FFN phase = 64 hidden channels: linE1 + ReLU into 4 register blocks, then their contribution through linE2
-    // accumulated directly onto E (which holds the LN1 output, i.e. the residual).  The next unit's row vectors are fetched
-    // during the first FFN phase and put into this wave's LDS slot at the end of the last (the FiLM reads of this unit
-    // are over); its E tile is fetched during the last FFN phase.
-    f32x4 nvr[NV], nx0[IBE], nx1[IBE];
-    const int nj = nx.j0 + p, njj = nj < n ? nj : 0;
+    // accumulated directly onto E (which holds the LN1 output, i.e. the residual).
 #pragma unroll
     for (int f = 0; f < G::NFF; ++f) {
       __syncthreads();
@@ -1019,8 +1015,6 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
         stage_phase_unit<G::CB_F4, NW>(a.phase_img, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
       const float* bias = reinterpret_cast<const float*>(wbuf + cur * G::PH_F4);
       const f32x4* W = wbuf + cur * G::PH_F4 + G::BIAS_F4;
-      if (f == 0 && nx.active) vec_load(nx, nvr);
-      if (f == G::NFF - 1 && nx.active) tile_load(nx, njj, nx0, nx1);
       if (active) {
         load_frag3(fa, W, lane);
         if (f == 0) {
@@ -1048,7 +1042,6 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
           mfma_x3(e[t % IBE], w, hh, hm, hl);
         });
       }
-      if (f == G::NFF - 1 && nx.active) vec_store(nvr);
       cur ^= 1;
     }
     if (active) {
@@ -1059,7 +1052,15 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
         for (int eb = 0; eb < IBE; ++eb) *reinterpret_cast<f32x4*>(dst + 16 * eb) = live ? e[eb] : splat4(0.f);
       }
     }
+    // the next unit's row vectors and E tile.  Not prefetched under the FFN phases: the 44 registers that took are what
+    // kept a third wave per SIMD from fitting (149 VGPRs now), and three waves hide this latency better than the prefetch
+    // did with two (probe: 331 us against 354)
     if (nx.active) {
+      f32x4 nvr[NV], nx0[IBE], nx1[IBE];
+      const int nj = nx.j0 + p, njj = nj < n ? nj : 0;
+      vec_load(nx, nvr);
+      tile_load(nx, njj, nx0, nx1);
+      vec_store(nvr);
       const bool nlive = nmk != 0 && nj != nx.i;
 #pragma unroll
       for (int eb = 0; eb < IBE; ++eb) e[eb] = nlive ? 0.5f * (nx0[eb] + nx1[eb]) : splat4(0.f);
@@ -1251,23 +1252,38 @@ int launch_edge_unit_pack(const EdgeUnitPackArgs& a, int dx, int de, int ffe, hi
 }
 
 #ifndef SCGG_UNIT_WAVES
-#define SCGG_UNIT_WAVES 8
+#define SCGG_UNIT_WAVES 8      // fp32 kernel: 2 waves per SIMD (up to 256 VGPRs)
+#endif
+#ifndef SCGG_X3_WAVES
+#define SCGG_X3_WAVES 12       // x3 kernel: 3 waves per SIMD (168 VGPRs; 149 used, no scratch)
 #endif
 
 template <int NXB, int NEB, int NFB>
 static int launch_one(const EdgeLayerArgs& a, int n_cu, hipStream_t st) {
-  constexpr int NW = SCGG_UNIT_WAVES;
   static bool attr_set = false;
-  const bool x3 = edge_x3();
-  auto kern = x3 ? edge_unit_layer_x3_kernel<NXB, NEB, NFB, NW> : edge_unit_layer_kernel<NXB, NEB, NFB, NW>;
-  const size_t lds = x3 ? UnitGeomX3<NXB, NEB, NFB>::lds_bytes(NW) : UnitGeom<NXB, NEB, NFB>::lds_bytes(NW);
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess)
-      return -2;
-    attr_set = true;
+  if (edge_x3()) {
+    constexpr int NW = SCGG_X3_WAVES;
+    auto kern = edge_unit_layer_x3_kernel<NXB, NEB, NFB, NW>;
+    const size_t lds = UnitGeomX3<NXB, NEB, NFB>::lds_bytes(NW);
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+          hipSuccess)
+        return -2;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_cu), dim3(NW * 64), lds, st, a);        // one persistent workgroup per CU
+  } else {
+    constexpr int NW = SCGG_UNIT_WAVES;
+    auto kern = edge_unit_layer_kernel<NXB, NEB, NFB, NW>;
+    const size_t lds = UnitGeom<NXB, NEB, NFB>::lds_bytes(NW);
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+          hipSuccess)
+        return -2;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_cu * (16 / NW)), dim3(NW * 64), lds, st, a);
   }
-  hipLaunchKernelGGL(kern, dim3(n_cu * (16 / NW)), dim3(NW * 64), lds, st, a);
   return 0;
 }
 

@@ -18,7 +18,7 @@
 
 namespace scgg {
 
-constexpr int YG = 2;          // graphs per workgroup
+constexpr int YG = 1;          // graphs per workgroup
 constexpr int YT = 256;        // threads per workgroup
 constexpr int YW = 256;        // max width of the y vectors (dy); the FFN hidden width dim_ffy has its own buffer
 
