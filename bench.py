@@ -183,7 +183,7 @@ def main():
                          "algorithmic_over_f32_mfma_peak": algorithmic / PEAK_F32_MFMA_TFLOPS,
                          "traffic": measured_traffic() if a.batch == 512 else None,
                          "algorithmic_bytes_per_launch": 3 * valid_pairs * hd["de"] * 4,
-                         "kernel": "scgg::edge_unit_layer_x3_kernel<8,2,4,8> (fused XEy layer, edge path; fp32 results from 6 bf16 "
+                         "kernel": "scgg::edge_unit_layer_x3_kernel<8,2,4,12> (fused XEy layer, edge path; fp32 results from 6 bf16 "
                                    "MFMA 16x16x32 partial products per product, fp32 accumulate)",
                          "avg_launch_ms": kernel_ms, "launches_timed": n_launch,
                          "algorithmic_flops_per_launch": flops_per_launch,
