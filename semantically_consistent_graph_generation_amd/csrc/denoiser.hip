@@ -513,7 +513,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       if (!fused_y) launch_copy_cols(w.y, dy, w.ycat, kcat, B, dy, ax);
       if (l > 0 && await(ax, ev(l - 1, EV_X))) return fail("stream wait failed");
       NodeStatsArgs ns{Xcur, mask, w.ycat, B, n, dx, kcat, dy};
-      launch_node_stats(ns, ax);
+      if (launch_node_stats(ns, ax)) return fail("node_stats: unsupported dx=%d or n=%d", dx, n);
     }
     if (signal(ev(l, EV_NS), ax)) return fail("event record failed");
     // Etoy of the layer INPUT E(l) (:239-243).  Fused y path: E(0) here, E(l+1) at the end of round l (beside the node

@@ -1122,7 +1122,7 @@ int launch_attn_finish(const AttnFinishArgs& a, int M, hipStream_t st) {
 // is read once per pass (pair {i,j} = 0.5 (E_ij + E_ji), weight 2); two passes (mean, then centred squares -- the
 // second pass is an L2 read).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int POOL_T = 512;                                               // threads per graph
+constexpr int POOL_T = 256;   // threads per graph; 13 KB of LDS: fits on a CU beside a 12-wave edge workgroup (23 KB free)
 __global__ __launch_bounds__(POOL_T) void edge_pool_stats_kernel(EdgePoolArgs a) {
   __shared__ f32x4 red[3][POOL_T];
   __shared__ f32x4 smean[64];

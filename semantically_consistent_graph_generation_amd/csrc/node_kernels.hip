@@ -257,32 +257,81 @@ int launch_add_layernorm(const AddLnArgs& a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // Xtoy pooling (layers.py:11-19): [mean|min|max|biased variance] over the valid nodes of each graph
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void node_stats_kernel(NodeStatsArgs a) {
-  const int b = blockIdx.x;
-  const uint8_t* m = a.mask + b * a.n;
-  for (int c = threadIdx.x; c < a.dx; c += 256) {
-    const float* X = a.X + (long long)b * a.n * a.dx + c;
-    float s = 0.f, mn = INFINITY, mx = -INFINITY;
-    int cnt = 0;
-    for (int i = 0; i < a.n; ++i) {
-      if (!m[i]) continue;
-      const float v = X[(long long)i * a.dx];
-      s += v; mn = fminf(mn, v); mx = fmaxf(mx, v); ++cnt;
+// One workgroup per graph; thread = (4 channels, slice of the rows): float4 loads, the rows of a slice are independent
+// loads in flight together (the kernel runs beside the edge kernel's start and sits in front of the y round, so its
+// latency chain matters, not its bytes).  dx % 4 == 0, dx / 4 divides NS_T; the valid nodes come first in a list in LDS.
+constexpr int NS_T = 256;      // 14 KB of LDS: has to fit on a CU beside a 12-wave edge workgroup (23 KB free)
+__global__ __launch_bounds__(NS_T) void node_stats_kernel(NodeStatsArgs a) {
+  __builtin_amdgcn_s_setprio(3);   // runs beside the edge kernel and in front of the y round: issue first
+  __shared__ f32x4_t red[3][NS_T];
+  __shared__ f32x4_t smean[128];
+  __shared__ short vidx[512];
+  __shared__ int nvs;
+  const int b = blockIdx.x, n = a.n, dx = a.dx, tid = threadIdx.x;
+  const int G4 = dx / 4, S = NS_T / G4, c4 = tid % G4, sl = tid / G4;
+  const uint8_t* m = a.mask + (long long)b * n;
+  if (tid < 64) {                                    // wave 0 compacts the mask (n <= 512: 8 rounds of 64)
+    int nv = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int i = i0 + tid;
+      const bool v = i < n && m[i] != 0;
+      const unsigned long long bal = __ballot(v);
+      if (v) vidx[nv + __popcll(bal & ((1ull << tid) - 1ull))] = (short)i;
+      nv += __popcll(bal);
     }
-    const float mean = s / (float)cnt;
-    float q = 0.f;
-    for (int i = 0; i < a.n; ++i) {
-      if (!m[i]) continue;
-      const float d = X[(long long)i * a.dx] - mean;
-      q += d * d;
+    if (tid == 0) nvs = nv;
+  }
+  __syncthreads();
+  const int nv = nvs;
+  const float* X = a.X + (long long)b * n * dx + 4 * c4;
+  f32x4_t s = {0.f, 0.f, 0.f, 0.f}, mn = {INFINITY, INFINITY, INFINITY, INFINITY}, mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  if (sl < S) {
+#pragma unroll 4
+    for (int k = sl; k < nv; k += S) {
+      const f32x4_t v = *reinterpret_cast<const f32x4_t*>(X + (long long)vidx[k] * dx);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[e] += v[e]; mn[e] = fminf(mn[e], v[e]); mx[e] = fmaxf(mx[e], v[e]); }
     }
-    float* z = a.z + (long long)b * a.z_stride + a.z_offset;
-    z[c] = mean; z[a.dx + c] = mn; z[2 * a.dx + c] = mx; z[3 * a.dx + c] = q / (float)cnt;
+  }
+  red[0][tid] = s; red[1][tid] = mn; red[2][tid] = mx;
+  __syncthreads();
+  if (sl == 0) {
+    for (int t = 1; t < S; ++t) {
+      const f32x4_t s2 = red[0][t * G4 + c4], n2 = red[1][t * G4 + c4], x2 = red[2][t * G4 + c4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[e] += s2[e]; mn[e] = fminf(mn[e], n2[e]); mx[e] = fmaxf(mx[e], x2[e]); }
+    }
+    smean[c4] = s / (float)nv;
+    red[1][c4] = mn; red[2][c4] = mx;
+  }
+  __syncthreads();
+  const f32x4_t mean = smean[c4];
+  f32x4_t q = {0.f, 0.f, 0.f, 0.f};
+  if (sl < S) {
+#pragma unroll 4
+    for (int k = sl; k < nv; k += S) {
+      const f32x4_t v = *reinterpret_cast<const f32x4_t*>(X + (long long)vidx[k] * dx);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[e] - mean[e]; q[e] += d * d; }
+    }
+  }
+  __syncthreads();
+  red[0][tid] = q;
+  __syncthreads();
+  if (sl == 0) {
+    for (int t = 1; t < S; ++t) q += red[0][t * G4 + c4];
+    float* z = a.z + (long long)b * a.z_stride + a.z_offset + 4 * c4;
+    const f32x4_t mnv = red[1][c4], mxv = red[2][c4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      z[e] = mean[e]; z[dx + e] = mnv[e]; z[2 * dx + e] = mxv[e]; z[3 * dx + e] = q[e] / (float)nv;
+    }
   }
 }
 
 int launch_node_stats(const NodeStatsArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(node_stats_kernel, dim3(a.B), dim3(256), 0, st, a);
+  if (a.dx % 4 != 0 || a.dx > 512 || NS_T % (a.dx / 4) != 0 || a.n > 512) return -1;
+  hipLaunchKernelGGL(node_stats_kernel, dim3(a.B), dim3(NS_T), 0, st, a);
   return 0;
 }
 

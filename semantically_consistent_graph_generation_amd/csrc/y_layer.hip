@@ -114,6 +114,7 @@ __device__ __forceinline__ void y_add_layernorm(float* y, const float* t, int ld
 }
 
 __global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
+  __builtin_amdgcn_s_setprio(3);   // a short latency chain beside the edge kernel's waves on the same SIMDs: issue first
   extern __shared__ __attribute__((aligned(16))) float ysm[];
   const int tid = threadIdx.x;
   const int dy = a.dy, kcat = a.kcat;
