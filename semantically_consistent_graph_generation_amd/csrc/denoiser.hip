@@ -650,11 +650,24 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
 
   // ---- output MLPs (transformer_model.py:371-389): E on the main stream, X and y beside it on the aux stream
   if (c.out_X > 0) {
-    if (gemm(Xcur, dx, P_(h, "mlp_out_X.0.weight", (int64_t)c.hid_X * dx), P_(h, "mlp_out_X.0.bias", c.hid_X), w.hidX,
-             c.hid_X, M, c.hid_X, dx, GEMM_RELU, nullptr, ax)) return -1;
-    if (gemm(w.hidX, c.hid_X, P_(h, "mlp_out_X.3.weight", (int64_t)c.out_X * c.hid_X), P_(h, "mlp_out_X.3.bias", c.out_X),
-             w.xo, c.out_X, M, c.out_X, c.hid_X, 0, nullptr, ax)) return -1;
-    launch_x_out_residual(w.xo, X, c.in_X, mask, o1, M, c.out_X, ax);
+    // valid rows only when the shapes allow: x3 row-list Linear + a one-wave-per-row head with the residual fused
+    // (masked rows of the output are zero: utils.py:154); else the dense GEMMs
+    const Param* w3 = P_(h, "mlp_out_X.3.weight", (int64_t)c.out_X * c.hid_X); const Param* b3 = P_(h, "mlp_out_X.3.bias", c.out_X);
+    if (!w3 || !b3) return -1;
+    NodeLinearArgs la{Xcur, h->out_X1.W, h->out_X1.b, w.hidX, w.rows, w.row_count, c.hid_X, dx, (c.hid_X + 31) / 32, dx, c.hid_X,
+                      1, 1};
+    bool rows_only = h->out_X1.W3 != nullptr && c.out_X <= 16 && c.hid_X % 4 == 0 &&
+                     launch_node_linear_x3(la, h->out_X1.W3, M, ax) == 0;
+    if (rows_only) {
+      if (hipMemsetAsync(o1, 0, (size_t)M * c.out_X * sizeof(float), ax) != hipSuccess) return fail("memset failed");
+      if (launch_row_head(w.hidX, c.hid_X, w3->p, b3->p, X, c.in_X, w.rows, w.row_count, o1, M, c.out_X, c.hid_X, ax))
+        return fail("row_head rejected");
+    } else {
+      if (gemm(Xcur, dx, P_(h, "mlp_out_X.0.weight", (int64_t)c.hid_X * dx), P_(h, "mlp_out_X.0.bias", c.hid_X), w.hidX,
+               c.hid_X, M, c.hid_X, dx, GEMM_RELU, nullptr, ax)) return -1;
+      if (gemm(w.hidX, c.hid_X, w3, b3, w.xo, c.out_X, M, c.out_X, c.hid_X, 0, nullptr, ax)) return -1;
+      launch_x_out_residual(w.xo, X, c.in_X, mask, o1, M, c.out_X, ax);
+    }
   }
   if (c.out_y > 0) {
     if (!o3) return fail("out_y requested by the config but out_y pointer is NULL");

@@ -210,6 +210,8 @@ int launch_pack_linear_x3(const PackArgs& a, hipStream_t st);
 int launch_pad_vec(const float* src, float* dst, int n, int n_pad, float add, hipStream_t st);
 int launch_copy_cols(const float* src, int lds, float* dst, int ldd, int M, int ncols, hipStream_t st);
 int launch_transpose(const float* src, float* dst, int rows, int cols, hipStream_t st);   // dst[c][r] = src[r][c]
+int launch_row_head(const float* hid, int ldh, const float* W, const float* b, const float* X_in, int dX_in, const int* rows,
+                    const int* row_count, float* out, int M, int N, int K, hipStream_t st);   // -1: shape not covered
 int launch_x_out_residual(const float* mlp, const float* X_in, int dX_in, const uint8_t* mask, float* out,
                           int M, int nout, hipStream_t st);
 

@@ -498,6 +498,35 @@ __global__ void x_out_residual_kernel(const float* mlp, const float* X_in, int d
   out[idx] = keep ? mlp[idx] + X_in[(long long)m * dX_in + c] : 0.f;
 }
 
+// Narrow output head on the valid rows (mlp_out_X.3 + residual, transformer_model.py:374, :387): one wave per row,
+// out[row, c] = W[c, :] . hid[row, :] + b[c] + X_in[row, c] for c < N (N small); masked rows are zero-filled by the caller.
+__global__ __launch_bounds__(256) void row_head_kernel(const float* hid, int ldh, const float* W, const float* b,
+                                                       const float* X_in, int dX_in, const int* rows, const int* row_count,
+                                                       float* out, int N, int K) {
+  const int ridx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (ridx >= *row_count) return;
+  const long long row = rows[ridx];
+  const float* hrow = hid + row * ldh;
+  for (int c = 0; c < N; ++c) {
+    float acc = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+      const f32x4_t hv = *reinterpret_cast<const f32x4_t*>(hrow + k), wv = *reinterpret_cast<const f32x4_t*>(W + (long long)c * K + k);
+      acc += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
+    }
+#pragma unroll
+    for (int mm = 1; mm < 64; mm <<= 1) acc += __shfl_xor(acc, mm);
+    if (lane == 0) out[row * N + c] = acc + b[c] + X_in[row * dX_in + c];
+  }
+}
+
+int launch_row_head(const float* hid, int ldh, const float* W, const float* b, const float* X_in, int dX_in, const int* rows,
+                    const int* row_count, float* out, int M, int N, int K, hipStream_t st) {
+  if (K % 4 != 0 || ldh % 4 != 0 || N > 16) return -1;
+  hipLaunchKernelGGL(row_head_kernel, dim3((M + 3) / 4), dim3(256), 0, st, hid, ldh, W, b, X_in, dX_in, rows, row_count, out,
+                     N, K);
+  return 0;
+}
+
 int launch_x_out_residual(const float* mlp, const float* X_in, int dX_in, const uint8_t* mask, float* out, int M,
                           int nout, hipStream_t st) {
   const long long total = (long long)M * nout;
