@@ -12,6 +12,8 @@
 // the launcher (logits).
 #include "mfma_chain.h"
 #include "kernels.h"
+#include "x3_mfma.h"
+#include <stdlib.h>
 
 namespace scgg {
 
@@ -184,6 +186,173 @@ __global__ __launch_bounds__(512) void edge_mlp_unit_kernel(EdgeMlpUnitArgs a) {
   }
 }
 
+// =========================================================================================================
+// The same MLPs on the bf16 matrix pipe with fp32 accuracy (x3_mfma.h), for even IB (input width a multiple of 32).
+// img = [ layer-1 blocks (ob, q) | layer-2 blocks (q, ob) | b1 padded | b2 padded ]; a block = three bf16 terms x 64 lanes
+// x 16 bytes of W[16 ob + (l & 15)][32 q + {4g..4g+3, 16+4g..16+4g+3}] (g = l >> 4), zero outside the matrix.  Layer-2
+// blocks are chunk-major so that a hidden chunk is split once and used for every output block.
+// =========================================================================================================
+template <int IB, int HB, int OB>
+struct MlpGeomX3 {
+  static constexpr int Q1 = IB / 2, Q2 = HB / 2;
+  static constexpr int B1 = HB * Q1, B2 = OB * Q2;                      // blocks of the two layers
+  static constexpr int IMG_F4 = (B1 + B2) * 192 + HB * 4 + OB * 4;
+};
+
+template <int IB, int HB, int OB>
+__global__ __launch_bounds__(256) void edge_mlp_pack_x3_kernel(EdgeMlpPackArgs a) {
+  using G = MlpGeomX3<IB, HB, OB>;
+  u32x4* img = reinterpret_cast<u32x4*>(a.img);
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < G::IMG_F4; idx += gridDim.x * 256) {
+    u32x4 out = {0u, 0u, 0u, 0u};
+    if (idx < (G::B1 + G::B2) * 192) {
+      const int t = idx / 192, term = (idx % 192) >> 6, l = idx & 63, g = l >> 4;
+      const bool second = t >= G::B1;
+      const int tt = second ? t - G::B1 : t;
+      const int ob = second ? tt % OB : tt / G::Q1, q = second ? tt / OB : tt % G::Q1;
+      const float* W = second ? a.W2 : a.W1;
+      const int N = second ? a.N2 : a.N1, K = second ? a.N1 : a.K1;
+      const int row = 16 * ob + (l & 15);
+      unsigned hw[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int col = 32 * q + (i < 4 ? 4 * g + i : 16 + 4 * g + i - 4);
+        float x = (row < N && col < K) ? W[(size_t)row * K + col] : 0.f;
+        for (int k = 0; k < term; ++k) x = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+        hw[i] = __float_as_uint(x) >> 16;
+      }
+#pragma unroll
+      for (int d = 0; d < 4; ++d) out[d] = hw[2 * d] | (hw[2 * d + 1] << 16);
+    } else {
+      const int fo = (idx - (G::B1 + G::B2) * 192) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = fo + e;
+        float v = 0.f;
+        if (c < HB * 16) v = c < a.N1 ? a.b1[c] : 0.f;
+        else if (c - HB * 16 < a.N2) v = a.b2[c - HB * 16];
+        out[e] = __float_as_uint(v);
+      }
+    }
+    img[idx] = out;
+  }
+}
+
+template <int IB, int HB, int OB, bool OUT>
+__global__ __launch_bounds__(512) void edge_mlp_unit_x3_kernel(EdgeMlpUnitArgs a) {
+  using G = MlpGeomX3<IB, HB, OB>;
+  constexpr int Q1 = G::Q1, Q2 = G::Q2;
+  static_assert(IB % 2 == 0 && (HB * Q1) % 2 == 0, "x3 MLP: even block counts");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* img = reinterpret_cast<f32x4*>(smem);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  for (int idx = tid; idx < G::IMG_F4; idx += 512) img[idx] = a.img[idx];
+  __syncthreads();
+  const f32x4* W1 = img;
+  const f32x4* W2 = img + G::B1 * 192;
+  const float* b1 = reinterpret_cast<const float*>(img + (G::B1 + G::B2) * 192);
+  const float* b2 = b1 + HB * 16;
+  const int n = a.n, nch = (n + 15) >> 4;
+  const int count = *a.unit_count;
+  constexpr int DO = 16 * OB;
+
+  for (int uidx = blockIdx.x * 8 + wave; uidx < count; uidx += gridDim.x * 8) {
+    const int u = a.units[uidx];
+    const int row = u / nch, jc = u - row * nch;
+    const int b = row / n, i = row - b * n;
+    const int j = jc * 16 + p;
+    const bool inb = j < n;
+    const int jj = inb ? j : 0;
+    const bool live = inb && a.mask[b * n + jj] != 0 && j != i;
+    const long long pij = (long long)row * n + jj;
+    const long long pji = ((long long)b * n + jj) * n + i;
+
+    Frag3 fa, fb;
+    load_frag3(fa, W1, lane);
+    f32x4 x[IB];
+    if (OUT) {   // symmetrised hidden E (16 IB channels)
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) {
+        x[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (live) x[ib] = 0.5f * (ldg4(a.src + pij * (16 * IB) + 16 * ib + 4 * g) + ldg4(a.src + pji * (16 * IB) + 16 * ib + 4 * g));
+      }
+    } else {     // raw input features, row width dE_in (not 16-byte aligned)
+      const float* src = a.src + pij * a.dE_in;
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * ib + 4 * g + r;
+          x[ib][r] = (live && c < a.dE_in) ? src[c] : 0.f;
+        }
+    }
+    u32x4 xh[Q1], xm[Q1], xl[Q1];
+#pragma unroll
+    for (int q = 0; q < Q1; ++q) split3(x[2 * q], x[2 * q + 1], xh[q], xm[q], xl[q]);
+    // ---- layer 1 + relu
+    f32x4 hid[HB];
+#pragma unroll
+    for (int ob = 0; ob < HB; ++ob) hid[ob] = *reinterpret_cast<const f32x4*>(b1 + 16 * ob + 4 * g);
+    block_pipeline<HB * Q1, 0>(W1, W2, fa, fb, lane, [&](int t, const Frag3& w) {
+      mfma_x3(hid[t / Q1], w, xh[t % Q1], xm[t % Q1], xl[t % Q1]);
+    });
+#pragma unroll
+    for (int ob = 0; ob < HB; ++ob)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hid[ob][r] = fmaxf(hid[ob][r], 0.f);
+    // ---- layer 2 (chunk-major blocks: a hidden chunk is split once)
+    f32x4 o[OB];
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) o[ob] = *reinterpret_cast<const f32x4*>(b2 + 16 * ob + 4 * g);
+    {
+      u32x4 hh, hm, hl;
+      block_pipeline<OB * Q2, 0>(W2, nullptr, fa, fb, lane, [&](int t, const Frag3& w) {
+        if (t % OB == 0) split3(hid[2 * (t / OB)], hid[2 * (t / OB) + 1], hh, hm, hl);
+        mfma_x3(o[t % OB], w, hh, hm, hl);
+      });
+    }
+    if (OUT) {
+      // (mlp + E_in[ij]) and (mlp + E_in[ji]) averaged: the hidden E is symmetric after the sym-load, so the MLP
+      // term is bit-identical for (i,j) and (j,i); only the residual needs both orientations.
+      if (inb) {
+        float* dst = a.dst + pij * a.C;
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = 16 * ob + 4 * g + r;
+            if (c < a.C) {
+              float val = 0.f;
+              if (live) val = 0.5f * ((o[ob][r] + a.E_in[pij * a.dE_in + c]) + (o[ob][r] + a.E_in[pji * a.dE_in + c]));
+              dst[c] = val;
+            }
+          }
+      }
+    } else if (inb) {
+      float* dst = a.dst + pij * DO + 4 * g;
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(o[ob][r], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(dst + 16 * ob) = v;
+      }
+    }
+  }
+}
+
+// SCGG_EDGE_MODE=f32 keeps the fp32-MFMA kernels (development A/B switch, as in edge_unit_layer.hip); odd IB always does
+static bool mlp_x3(int ib) {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("SCGG_EDGE_MODE");
+    mode = (e != nullptr && e[0] == 'f') ? 0 : 1;
+  }
+  return mode == 1 && ib % 2 == 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 #define SCGG_MLP_IN_CASES CASE(1, 8, 4) CASE(2, 8, 4) CASE(3, 8, 4) CASE(4, 8, 4) CASE(1, 2, 2) CASE(2, 2, 2)   /* (ceil(in_E/16), hid_E/16, de/16) */
 #define SCGG_MLP_OUT_CASES CASE(4, 8, 1) CASE(4, 8, 2) CASE(2, 2, 1)   /* (de/16, hid_E/16, ceil(C/16)) */
@@ -202,6 +371,7 @@ static int n_cu_cached() {
 long long edge_mlp_img_f4(int K1, int N1, int N2) {
   const int ib = (K1 + 15) / 16, hb = N1 / 16, ob = (N2 + 15) / 16;
   if (N1 % 32 != 0) return -1;
+  if (mlp_x3(ib)) return (long long)(hb * (ib / 2) + ob * (hb / 2)) * 192 + hb * 4 + ob * 4;
   return (long long)hb * ib * 64 + (long long)ob * hb * 64 + hb * 4 + ob * 4;
 }
 
@@ -209,6 +379,12 @@ int launch_edge_mlp_pack(const EdgeMlpPackArgs& a, hipStream_t st) {
   const int ib = (a.K1 + 15) / 16, hb = a.N1 / 16, ob = (a.N2 + 15) / 16;
 #define CASE(IB, HB, OB)                                                                             \
   if (ib == IB && hb == HB && ob == OB) {                                                            \
+    if constexpr (IB % 2 == 0) {                                                                     \
+      if (mlp_x3(IB)) {                                                                              \
+        hipLaunchKernelGGL((edge_mlp_pack_x3_kernel<IB, HB, OB>), dim3(64), dim3(256), 0, st, a);    \
+        return 0;                                                                                    \
+      }                                                                                              \
+    }                                                                                                \
     hipLaunchKernelGGL((edge_mlp_pack_kernel<IB, HB, OB>), dim3(64), dim3(256), 0, st, a);           \
     return 0;                                                                                        \
   }
@@ -219,12 +395,17 @@ int launch_edge_mlp_pack(const EdgeMlpPackArgs& a, hipStream_t st) {
 
 template <int IB, int HB, int OB, bool OUT>
 static int launch_mlp(const EdgeMlpUnitArgs& a, hipStream_t st) {
-  using G = MlpGeom<IB, HB, OB>;
   const int n_cu = n_cu_cached();
   if (n_cu <= 0) return -2;
   static bool attr_set = false;
-  auto kern = edge_mlp_unit_kernel<IB, HB, OB, OUT>;
-  const size_t lds = (size_t)G::IMG_F4 * 16;
+  void (*kern)(EdgeMlpUnitArgs) = edge_mlp_unit_kernel<IB, HB, OB, OUT>;
+  size_t lds = (size_t)MlpGeom<IB, HB, OB>::IMG_F4 * 16;
+  if constexpr (IB % 2 == 0) {
+    if (mlp_x3(IB)) {
+      kern = edge_mlp_unit_x3_kernel<IB, HB, OB, OUT>;
+      lds = (size_t)MlpGeomX3<IB, HB, OB>::IMG_F4 * 16;
+    }
+  }
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess)
