@@ -469,9 +469,17 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
            c.hid_y, B, c.hid_y, c.in_y, GEMM_RELU, nullptr, ax)) return -1;
   if (gemm(w.hidy, c.hid_y, P_(h, "mlp_in_y.3.weight", (int64_t)dy * c.hid_y), P_(h, "mlp_in_y.3.bias", dy), w.y, dy, B,
            dy, c.hid_y, GEMM_RELU, nullptr, ax)) return -1;
+  bool pooled_e0 = false;
   {
     EdgeMlpUnitArgs a{E, nullptr, mask, h->in_E_img, w.E0, w.units, w.unit_count, B, n, c.in_E, c.out_E};
     if (launch_edge_mlp_in(a, c.in_E, c.hid_E, de, st)) return fail("edge_mlp_in: unsupported dims");
+    // Etoy of E(0) for the fused y path: on the caller's stream, which idles from here until the FiLM vectors of layer 0
+    // are ready (the second stream is still busy with the X / y prologue)
+    pooled_e0 = y_layer_supported(dy, c.dim_ffy, kcat) && n_run_layers > 0 && h->layers[0].predicts_y;
+    if (pooled_e0) {
+      EdgePoolArgs ep{w.E0, mask, w.epool, B, n, de, 4 * de, 0};
+      if (launch_edge_pool_stats(ep, st)) return fail("edge_pool_stats: unsupported de=%d or n=%d", de, n);
+    }
     if (signal(ev_e0, st)) return fail("event record failed");
   }
   float* Ecur = w.E0;
@@ -518,8 +526,8 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     if (signal(ev(l, EV_NS), ax)) return fail("event record failed");
     // Etoy of the layer INPUT E(l) (:239-243).  Fused y path: E(0) here, E(l+1) at the end of round l (beside the node
     // kernel); unfused: every layer here, straight into the ycat row.
-    if (L.predicts_y && (l == 0 || !fused_y)) {
-      if (l == 0 && await(ax, ev_e0)) return fail("stream wait failed");
+    if (l == 0 && await(ax, ev_e0)) return fail("stream wait failed");
+    if (L.predicts_y && (l == 0 || !fused_y) && !(l == 0 && pooled_e0)) {
       EdgePoolArgs ep{Ecur, mask, fused_y ? w.epool : w.ycat, B, n, de, fused_y ? 4 * de : kcat, fused_y ? 0 : dy + 4 * dx};
       if (launch_edge_pool_stats(ep, ax)) return fail("edge_pool_stats: unsupported de=%d or n=%d", de, n);
     }
