@@ -397,7 +397,7 @@ int ensure_streams(scgg_denoiser* h) {
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   if (hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, prio_hi) != hipSuccess)
     return fail("aux stream creation failed");
-  h->sync_ev.resize((size_t)(h->c.n_layers + 1) * 4);
+  h->sync_ev.resize((size_t)(h->c.n_layers + 1) * 4 + 1);   // [0..3]: join, fork, E0, second stream caught up; 4 per layer; [last]: y0
   for (hipEvent_t& e : h->sync_ev)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail("event creation failed");
   return 0;
@@ -426,7 +426,8 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   auto ev = [&](int l, int k) { return h->sync_ev[(size_t)(l + 1) * EV_PER_LAYER + k]; };
   auto signal = [&](hipEvent_t e, hipStream_t s) { return hipEventRecord(e, s) != hipSuccess; };
   auto await = [&](hipStream_t s, hipEvent_t e) { return hipStreamWaitEvent(s, e, 0) != hipSuccess; };
-  hipEvent_t ev_join = h->sync_ev[0], ev_fork = h->sync_ev[1], ev_e0 = h->sync_ev[2];
+  hipEvent_t ev_join = h->sync_ev[0], ev_fork = h->sync_ev[1], ev_e0 = h->sync_ev[2], ev_pro = h->sync_ev[3];
+  hipEvent_t ev_y0 = h->sync_ev.back();
 
   // ---- work lists (valid rows, 16-key units), then fork
   if (launch_build_lists(mask, B, n, w.goff, w.rows, w.row_count, w.units, w.unit_count, st))
@@ -447,6 +448,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     if (dbl_X) launch_zero_masked_rows(w.t1, mask, M, dx, st);
   }
   if (signal(ev_fork, st) || await(ax, ev_fork)) return fail("stream fork failed");
+  if (signal(ev_pro, ax)) return fail("event record failed");
 
   // ---- input MLPs (transformer_model.py:358-366): E on the main stream, X and y beside it on the aux stream
   {
@@ -465,10 +467,10 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       if (gemm(w.hidX, c.hid_X, w3, b3, w.Xh, dx, M, dx, c.hid_X, GEMM_RELU | GEMM_ROWMASK, mask, ax)) return -1;
     }
   }
-  if (gemm(y, c.in_y, P_(h, "mlp_in_y.0.weight", (int64_t)c.hid_y * c.in_y), P_(h, "mlp_in_y.0.bias", c.hid_y), w.hidy,
-           c.hid_y, B, c.hid_y, c.in_y, GEMM_RELU, nullptr, ax)) return -1;
-  if (gemm(w.hidy, c.hid_y, P_(h, "mlp_in_y.3.weight", (int64_t)dy * c.hid_y), P_(h, "mlp_in_y.3.bias", dy), w.y, dy, B,
-           dy, c.hid_y, GEMM_RELU, nullptr, ax)) return -1;
+  // The y input MLP and the FiLM vectors of layer 0 (fused y path): on the caller's stream, which idles after the edge
+  // input MLP, beside the X chain on the second stream.  The caller's stream first waits until the second stream has
+  // caught up with whatever the caller queued there (the producers of y, scgg_denoiser_side_stream).
+  const bool y_on_main = y_layer_supported(dy, c.dim_ffy, dy + 4 * dx + 4 * de) && n_run_layers > 0;
   bool pooled_e0 = false;
   {
     EdgeMlpUnitArgs a{E, nullptr, mask, h->in_E_img, w.E0, w.units, w.unit_count, B, n, c.in_E, c.out_E};
@@ -481,6 +483,14 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       if (launch_edge_pool_stats(ep, st)) return fail("edge_pool_stats: unsupported de=%d or n=%d", de, n);
     }
     if (signal(ev_e0, st)) return fail("event record failed");
+  }
+  {
+    hipStream_t ys = y_on_main ? st : ax;
+    if (y_on_main && await(st, ev_pro)) return fail("stream wait failed");
+    if (gemm(y, c.in_y, P_(h, "mlp_in_y.0.weight", (int64_t)c.hid_y * c.in_y), P_(h, "mlp_in_y.0.bias", c.hid_y), w.hidy,
+             c.hid_y, B, c.hid_y, c.in_y, GEMM_RELU, nullptr, ys)) return -1;
+    if (gemm(w.hidy, c.hid_y, P_(h, "mlp_in_y.3.weight", (int64_t)dy * c.hid_y), P_(h, "mlp_in_y.3.bias", dy), w.y, dy, B,
+             dy, c.hid_y, GEMM_RELU, nullptr, ys)) return -1;
   }
   float* Ecur = w.E0;
   float* Enext = w.E1;
@@ -512,7 +522,9 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
         YLayerArgs ya{};
         ya.y = w.y; ya.Wt_film = L.Wt_film; ya.b_film = L.bfilm; ya.film = film;
         ya.B = B; ya.dy = dy; ya.ffy = c.dim_ffy; ya.kcat = kcat; ya.dx = dx; ya.update = 0;
-        if (launch_y_layer(ya, ax)) return fail("y_layer launch failed");
+        if (launch_y_layer(ya, y_on_main ? st : ax)) return fail("y_layer launch failed");
+        // y(0) is complete on the caller's stream: the second stream's y round of layer 0 waits for it
+        if (y_on_main && (signal(ev_y0, st) || await(ax, ev_y0))) return fail("stream sync failed");
       } else if (gemm_raw(w.y, dy, L.Wfilm, L.bfilm, film, 4 * dx, B, 4 * dx, dy, GEMM_ADD_ONE_COLS, nullptr, ax, dx,
                           2 * dx, 3 * dx, 4 * dx)) return -1;
       if (signal(ev(l, EV_FILM), ax)) return fail("event record failed");
