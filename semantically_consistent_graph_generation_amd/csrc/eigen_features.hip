@@ -46,10 +46,12 @@ __device__ __forceinline__ void jacobi_pair(int r, int k, int nve, const int* ac
 }
 
 __global__ __launch_bounds__(ETHREADS) void eigen_features_kernel(EigArgs a) {
-  __shared__ float A[EN * ELD];
-  __shared__ float V[EN * ELD];
-  __shared__ float cs[16][2];
-  __shared__ int pq[16][2];
+  // A and V ping-pong between two buffers: a round reads one and rewrites every entry of the active submatrix into the
+  // other, so a round needs ONE barrier (each thread recomputes the two rotation angles it needs instead of waiting for a
+  // separate angle phase); the round-robin schedule is tabulated once
+  __shared__ float Abuf[2][EN * ELD];
+  __shared__ float Vbuf[2][EN * ELD];
+  __shared__ unsigned char ptab[(EN - 1) * 16][2];
   __shared__ float w[EN];
   __shared__ int order[EN];      // order[r] = index of the r-th smallest eigenvalue
   __shared__ int act[EN];        // the nodes that take part in rotations: the valid ones (+ one idle node if odd)
@@ -60,6 +62,8 @@ __global__ __launch_bounds__(ETHREADS) void eigen_features_kernel(EigArgs a) {
   const uint8_t* m = a.mask + b * n;
   const float* L = a.lap + (long long)b * n * n;
 
+  float* A = Abuf[0];
+  float* V = Vbuf[0];
   float fro = 0.f;
   for (int idx = lane; idx < EN * EN; idx += ETHREADS) {
     const int i = idx >> 5, j = idx & 31;
@@ -68,6 +72,8 @@ __global__ __launch_bounds__(ETHREADS) void eigen_features_kernel(EigArgs a) {
     else if (i == j) v = 4.0f * n + i;          // beyond n: decoupled, sorts last
     A[i * ELD + j] = v;
     V[i * ELD + j] = i == j ? 1.f : 0.f;
+    Abuf[1][i * ELD + j] = v;                   // entries outside the active submatrix never change
+    Vbuf[1][i * ELD + j] = i == j ? 1.f : 0.f;
     if (i < n && j < n) fro += v * v;
   }
 #pragma unroll
@@ -90,61 +96,78 @@ __global__ __launch_bounds__(ETHREADS) void eigen_features_kernel(EigArgs a) {
   const float thresh = 2e-7f * sqrtf(fro);
   const int nve = s_nve, npairs = nve >> 1;
 
+  for (int idx = lane; idx < (nve - 1) * npairs; idx += ETHREADS) {
+    const int r = idx / npairs, k = idx - r * npairs;
+    int p, q;
+    jacobi_pair(r, k, nve, act, p, q);
+    ptab[r * 16 + k][0] = (unsigned char)p;
+    ptab[r * 16 + k][1] = (unsigned char)q;
+  }
+  // thread = (pair k, pair l): the 2x2 block rows {p_k, q_k} x columns {p_l, q_l} of A, and rows act[l], act[l + 16] of V
+  // for the columns {p_k, q_k}
+  const int tk = lane >> 4, tl = lane & 15;
+  const bool blk_on = tk < npairs && tl < npairs;
+  int cur = 0;
   for (int sweep = 0; sweep < MAX_SWEEPS && nve > 0; ++sweep) {
     if (lane == 0) flag = 0;
     __syncthreads();
     for (int r = 0; r < nve - 1; ++r) {
-      // ---- the disjoint pairs of this round and their rotation angles
-      if (lane < npairs) {
-        int p, q;
-        jacobi_pair(r, lane, nve, act, p, q);
-        const float apq = A[p * ELD + q];
-        float c = 1.f, s = 0.f;
+      const float* Ac = Abuf[cur];
+      const float* Vc = Vbuf[cur];
+      float* An = Abuf[cur ^ 1];
+      float* Vn = Vbuf[cur ^ 1];
+      // the rotation of pair (p, q): angle from the current A (every thread that needs it computes the same numbers)
+      auto rot = [&](int p, int q, float& c, float& s) {
+        const float apq = Ac[p * ELD + q];
+        c = 1.f; s = 0.f;
         if (fabsf(apq) > thresh) {
-          const float tau = (A[q * ELD + q] - A[p * ELD + p]) / (2.f * apq);
-          const float t = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
-          c = 1.0f / sqrtf(1.f + t * t);
+          // hardware reciprocal / square root (1 ulp) instead of the correctly rounded sequences: the rotation only has
+          // to be orthogonal to fp32 round-off (c from t by one rsq), the iteration corrects everything else, and these
+          // four operations are the latency chain of a round
+          const float tau = (Ac[q * ELD + q] - Ac[p * ELD + p]) * __builtin_amdgcn_rcpf(2.f * apq);
+          const float t = (tau >= 0.f ? 1.f : -1.f) * __builtin_amdgcn_rcpf(fabsf(tau) + __builtin_amdgcn_sqrtf(1.f + tau * tau));
+          c = __builtin_amdgcn_rsqf(1.f + t * t);
           s = t * c;
-          flag = 1;
         }
-        cs[lane][0] = c;
-        cs[lane][1] = s;
-        pq[lane][0] = p;
-        pq[lane][1] = q;
-      }
-      __syncthreads();
-      // ---- A <- J^T A J in one pass: item (k, l) owns the 2x2 block rows {p_k, q_k} x columns {p_l, q_l};
-      //      V <- V J: item (k, active row i).  Blocks are disjoint, so there is no barrier between the two sides.
-      const int nblk = npairs * npairs;
-      for (int item = lane; item < nblk + npairs * nve; item += ETHREADS) {
-        if (item < nblk) {
-          const int k = item / npairs, l = item - k * npairs;
-          const int pk = pq[k][0], qk = pq[k][1], pl = pq[l][0], ql = pq[l][1];
-          const float ck = cs[k][0], sk = cs[k][1], cl = cs[l][0], sl = cs[l][1];
-          const float a00 = A[pk * ELD + pl], a01 = A[pk * ELD + ql], a10 = A[qk * ELD + pl], a11 = A[qk * ELD + ql];
+      };
+      if (tk < npairs) {
+        const int pk = ptab[r * 16 + tk][0], qk = ptab[r * 16 + tk][1];
+        float ck, sk;
+        rot(pk, qk, ck, sk);
+        if (blk_on) {
+          const int pl = ptab[r * 16 + tl][0], ql = ptab[r * 16 + tl][1];
+          float cl = ck, sl = sk;
+          if (tl != tk) rot(pl, ql, cl, sl);
+          else if (sk != 0.f) flag = 1;
+          const float a00 = Ac[pk * ELD + pl], a01 = Ac[pk * ELD + ql], a10 = Ac[qk * ELD + pl], a11 = Ac[qk * ELD + ql];
           // columns first (A J), then rows (J^T .): same operation order as two separate passes
           const float b00 = cl * a00 - sl * a01, b01 = sl * a00 + cl * a01;
           const float b10 = cl * a10 - sl * a11, b11 = sl * a10 + cl * a11;
           float r00 = ck * b00 - sk * b10, r01 = ck * b01 - sk * b11;
           float r10 = sk * b00 + ck * b10, r11 = sk * b01 + ck * b11;
-          if (k == l && sk != 0.f) { r01 = 0.f; r10 = 0.f; }          // the rotated pair is annihilated exactly
-          A[pk * ELD + pl] = r00; A[pk * ELD + ql] = r01;
-          A[qk * ELD + pl] = r10; A[qk * ELD + ql] = r11;
-        } else {
-          const int it2 = item - nblk;
-          const int k = it2 / nve, i = act[it2 - k * nve];
-          const int p = pq[k][0], q = pq[k][1];
-          const float c = cs[k][0], s = cs[k][1];
-          const float vip = V[i * ELD + p], viq = V[i * ELD + q];
-          V[i * ELD + p] = c * vip - s * viq;
-          V[i * ELD + q] = s * vip + c * viq;
+          if (tk == tl && sk != 0.f) { r01 = 0.f; r10 = 0.f; }        // the rotated pair is annihilated exactly
+          An[pk * ELD + pl] = r00; An[pk * ELD + ql] = r01;
+          An[qk * ELD + pl] = r10; An[qk * ELD + ql] = r11;
+        }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int iv = tl + 16 * hh;
+          if (iv < nve) {
+            const int i = act[iv];
+            const float vip = Vc[i * ELD + pk], viq = Vc[i * ELD + qk];
+            Vn[i * ELD + pk] = ck * vip - sk * viq;
+            Vn[i * ELD + qk] = sk * vip + ck * viq;
+          }
         }
       }
       __syncthreads();
+      cur ^= 1;
     }
     if (flag == 0) break;            // a whole sweep without a rotation: converged (uniform: flag is shared)
     __syncthreads();
   }
+  A = Abuf[cur];
+  V = Vbuf[cur];
 
   // ---- sort ascending (stable rank), scale, features.  Wave 0 only from here (the mask as a bit set, no global reads
   //      inside the loops).
