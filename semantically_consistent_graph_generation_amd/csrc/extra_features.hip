@@ -29,6 +29,8 @@ struct AdjArgs {
   float* onehot_out;       // optional: one-hot of the labels into the same destination rows, channels [0,C)
   float* lap_out;          // [B,n,n] or null
   int B, n, C, Cx, num_degree, max_degree, cycle_features, e_ld, e_off, x_ld, x_off, y_ld, y_off;
+  int packed;              // the kernel owns whole pair rows [one-hot | max_degree+1 features]: rows are assembled in LDS
+                           // and written as contiguous runs instead of 25 scalar stores per pair
 };
 
 __device__ __forceinline__ float clamp05(float v) { return fminf(fmaxf(v, 0.f), 5.f) * 0.2f; }
@@ -51,6 +53,7 @@ __global__ __launch_bounds__(256) void adjacency_features_kernel(AdjArgs a) {
   __shared__ float gsq[NT];              // Adamic-Adar weight of a common neighbour
   __shared__ float red[4];
   __shared__ float hist[64];
+  extern __shared__ float stage[];       // packed mode: [256 pairs][e_ld]
   const int b = blockIdx.x, n = a.n, tid = threadIdx.x;
   const int8_t* lab = a.labels + (long long)b * n * n;
   const uint8_t* m = a.mask + b * n;
@@ -83,11 +86,11 @@ __global__ __launch_bounds__(256) void adjacency_features_kernel(AdjArgs a) {
   for (int idx = tid; idx < n * n; idx += 256) {
     const int i = idx / n, j = idx - i * n;
     float* e = a.e_out + ((long long)b * n * n + idx) * a.e_ld + a.e_off;
-    e[0] = a.cycle_features ? (A[i * LDT + j] != 0.f ? 0.2f : 0.f) : 0.f;
+    if (!a.packed) e[0] = a.cycle_features ? (A[i * LDT + j] != 0.f ? 0.2f : 0.f) : 0.f;
     const bool live = i != j && m[i] && m[j];
     const int l = lab[idx];
     if (live && l >= 0 && l < 64) atomicAdd(&hist[l], 1.0f);
-    if (a.onehot_out != nullptr) {
+    if (a.onehot_out != nullptr && !a.packed) {
       float* oh = a.onehot_out + ((long long)b * n * n + idx) * a.e_ld;
       for (int c = 0; c < a.C; ++c) oh[c] = (live && c == l) ? 1.f : 0.f;
     }
@@ -98,14 +101,17 @@ __global__ __launch_bounds__(256) void adjacency_features_kernel(AdjArgs a) {
       a.lap_out[(long long)b * n * n + idx] = v;
     }
     // Adamic-Adar-like index: S_ij = sum_k A_ik A_jk g_k^2, zero diagonal, * log(n_b)/n_b   (:335-356)
-    float s = 0.f;
-    if (i != j)
-      for (int k = 0; k < NT; ++k) s += (A[i * LDT + k] * gsq[k]) * (A[j * LDT + k] * gsq[k]);
-    e[K] = clamp05(s * (logf(nvf) / nvf));
+    if (!a.packed) {
+      float s = 0.f;
+      if (i != j)
+        for (int k = 0; k < NT; ++k) s += (A[i * LDT + k] * gsq[k]) * (A[j * LDT + k] * gsq[k]);
+      e[K] = clamp05(s * (logf(nvf) / nvf));
+    }
   }
 
   // ---- powers A^2..A^K; keep diagonals of A^2..A^6, sum(A^3) and sum(A o (A^2)^2) for the cycle formulas
   float sumA3 = 0.f, sumA_A2sq = 0.f;
+  unsigned reach[4] = {0u, 0u, 0u, 0u};   // packed mode: bit k-1 = (A^k)_ij != 0 for this thread's four pairs
   int cur = 0;
   for (int k = 2; k <= K; ++k) {
     float acc[4];
@@ -124,7 +130,9 @@ __global__ __launch_bounds__(256) void adjacency_features_kernel(AdjArgs a) {
       if (i == j && k <= 6) dg[k - 1][i] = acc[t];
       if (k == 2) sumA_A2sq += A[i * LDT + j] * acc[t] * acc[t];
       if (k == 3) sumA3 += acc[t];
-      if (i < n && j < n) {
+      if (a.packed) {
+        reach[t] |= acc[t] != 0.f ? (1u << (k - 1)) : 0u;
+      } else if (i < n && j < n) {
         float* e = a.e_out + ((long long)b * n * n + i * n + j) * a.e_ld + a.e_off;
         e[k - 1] = a.cycle_features ? (acc[t] != 0.f ? 0.2f : 0.f) : 0.f;
       }
@@ -134,6 +142,38 @@ __global__ __launch_bounds__(256) void adjacency_features_kernel(AdjArgs a) {
   }
   sumA3 = block_sum(sumA3, red);
   sumA_A2sq = block_sum(sumA_A2sq, red);
+
+  // ---- packed mode: the pair rows [one-hot | reachability k = 1..K | Adamic-Adar], eight tile rows (<= 256 pairs) at a
+  //      time through LDS, written as one contiguous run of 8 n e_ld floats
+  if (a.packed) {
+    const float aa_scale = logf(nvf) / nvf;
+    const float on = a.cycle_features ? 0.2f : 0.f;
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {
+      const int idx = tid + 256 * t, i = idx >> 5, j = idx & 31;
+      if (i < n && j < n) {
+        float* row = stage + ((i & 7) * n + j) * a.e_ld;
+        const bool live = i != j && m[i] && m[j];
+        const int l = lab[i * n + j];
+        for (int c = 0; c < a.C; ++c) row[c] = (live && c == l) ? 1.f : 0.f;
+        float* e = row + a.e_off;
+        e[0] = A[i * LDT + j] != 0.f ? on : 0.f;
+        for (int k = 2; k <= K; ++k) e[k - 1] = ((reach[t] >> (k - 1)) & 1u) ? on : 0.f;
+        float sAA = 0.f;
+        if (i != j)
+          for (int k = 0; k < NT; ++k) sAA += (A[i * LDT + k] * gsq[k]) * (A[j * LDT + k] * gsq[k]);
+        e[K] = clamp05(sAA * aa_scale);
+      }
+      __syncthreads();
+      const int i0 = 8 * t, rows = min(8, n - i0);
+      if (rows > 0) {
+        float* dst = a.e_out + ((long long)b * n * n + (long long)i0 * n) * a.e_ld;
+        const int total = rows * n * a.e_ld;
+        for (int q = tid; q < total; q += 256) dst[q] = stage[q];
+      }
+      __syncthreads();
+    }
+  }
 
   // ---- per-node cycle counts and the graph-level sums (one wave)
   const int ny = 4 + a.num_degree + 2 + a.Cx + a.C;
@@ -221,9 +261,11 @@ extern "C" int scgg_adjacency_features(const int8_t* labels, const int8_t* node_
   if (e_ld < e_off + max_degree + 1 || (onehot_out && e_off < C) || x_ld < x_off + 3 ||
       y_ld < y_off + 4 + num_degree + 2 + Cx + C)
     return fail("adjacency_features: bad destination stride");
+  const int packed = (onehot_out == e_out && e_off == C && e_ld == C + max_degree + 1 && e_ld <= 48) ? 1 : 0;
   AdjArgs a{labels, node_mask, node_labels, x_out, y_out, e_out, onehot_out, lap_out,
-            B, n, C, Cx, num_degree, max_degree, cycle_features, e_ld, e_off, x_ld, x_off, y_ld, y_off};
-  hipLaunchKernelGGL(adjacency_features_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+            B, n, C, Cx, num_degree, max_degree, cycle_features, e_ld, e_off, x_ld, x_off, y_ld, y_off, packed};
+  hipLaunchKernelGGL(adjacency_features_kernel, dim3(B), dim3(256), packed ? (size_t)256 * e_ld * sizeof(float) : 0,
+                     static_cast<hipStream_t>(stream), a);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail("adjacency_features: %s", hipGetErrorString(e));
   return 0;
