@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <map>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -472,6 +473,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   // caught up with whatever the caller queued there (the producers of y, scgg_denoiser_side_stream).
   const bool y_on_main = y_layer_supported(dy, c.dim_ffy, dy + 4 * dx + 4 * de) && n_run_layers > 0;
   bool pooled_e0 = false;
+  bool head_fused = false;   // the last node kernel also ran mlp_out_X.0
   {
     EdgeMlpUnitArgs a{E, nullptr, mask, h->in_E_img, w.E0, w.units, w.unit_count, B, n, c.in_E, c.out_E};
     if (launch_edge_mlp_in(a, c.in_E, c.hid_E, de, st)) return fail("edge_mlp_in: unsupported dims");
@@ -634,7 +636,15 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
                          L.linX1.W, L.linX1.b, L.linX2.W, L.linX2.b, g2->p, b2->p,
                          next ? h->layers[l + 1].qkv.W : nullptr, next ? h->layers[l + 1].qkv.b : nullptr, w.qkv, n,
                          L.x_out.W3, L.linX1.W3, L.linX2.W3, next ? h->layers[l + 1].qkv.W3 : nullptr,
-                         dbl_X ? Xalt : Xcur};
+                         dbl_X ? Xalt : Xcur, 0, 0, 0};
+        // after the last layer the trailing Linear is mlp_out_X.0 (+ ReLU) into the hidden buffer of the X output head
+        head_fused = false;
+        if (!next && !tap && l + 1 == c.n_layers && c.out_X > 0 && c.out_X <= 16 && h->out_X1.W3 != nullptr &&
+            c.hid_X % 32 == 0 && node_layer_x3_enabled()) {
+          na.W_qkv = h->out_X1.W; na.b_qkv = h->out_X1.b; na.W3_qkv = h->out_X1.W3; na.qkv = w.hidX;
+          na.tail_pairs = c.hid_X / 32; na.tail_ld = c.hid_X; na.tail_relu = 1;
+          head_fused = true;
+        }
         if (launch_node_layer(na, dx, c.dim_ffX, M, st)) return fail("node_layer launch failed");
         if (dbl_X) { float* tx = Xcur; Xcur = Xalt; Xalt = tx; }
       } else {
@@ -676,8 +686,8 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     if (!w3 || !b3) return -1;
     NodeLinearArgs la{Xcur, h->out_X1.W, h->out_X1.b, w.hidX, w.rows, w.row_count, c.hid_X, dx, (c.hid_X + 31) / 32, dx, c.hid_X,
                       1, 1};
-    bool rows_only = h->out_X1.W3 != nullptr && c.out_X <= 16 && c.hid_X % 4 == 0 &&
-                     launch_node_linear_x3(la, h->out_X1.W3, M, ax) == 0;
+    bool rows_only = head_fused || (h->out_X1.W3 != nullptr && c.out_X <= 16 && c.hid_X % 4 == 0 &&
+                                    launch_node_linear_x3(la, h->out_X1.W3, M, ax) == 0);
     if (rows_only) {
       if (hipMemsetAsync(o1, 0, (size_t)M * c.out_X * sizeof(float), ax) != hipSuccess) return fail("memset failed");
       if (launch_row_head(w.hidX, c.hid_X, w3->p, b3->p, X, c.in_X, w.rows, w.row_count, o1, M, c.out_X, c.hid_X, ax))

@@ -155,8 +155,13 @@ struct NodeLayerArgs {    // fused node part of one layer (node_layer.hip); pack
   // the same four weight matrices as three-term bf16 images (launch_pack_linear_x3) for the x3 kernel
   const f32x4_t* W3_xout; const f32x4_t* W3_lin1; const f32x4_t* W3_lin2; const f32x4_t* W3_qkv;
   float* X_out;           // where the updated residual stream goes (X itself: in place)
+  // x3 kernel: shape of the trailing Linear on the new X (W3_qkv / b_qkv / qkv): pairs of 16-channel output blocks, row
+  // stride of the destination, ReLU.  0 pairs = the next layer's q|k|v (3 dx wide, no activation); the last layer passes
+  // mlp_out_X.0 here (transformer_model.py:371), so that the output head needs no separate launch over X.
+  int tail_pairs, tail_ld, tail_relu;
 };
 bool node_layer_supported(int dx, int ffx);
+bool node_layer_x3_enabled();   // the x3 kernels are selected (SCGG_NODE_MODE is not f32)
 int launch_node_layer(const NodeLayerArgs& a, int dx, int ffx, int M, hipStream_t st);
 
 struct YLayerArgs {       // fused global-feature part of one layer (y_layer.hip); weights TRANSPOSED to [K][N]

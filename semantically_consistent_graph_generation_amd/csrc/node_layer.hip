@@ -363,7 +363,9 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
   const nu32x4* w_xout = wave < NPX ? w3_block(a.W3_xout, 2 * wave, KCX, lane) : nullptr;
   const nu32x4* w_lin1 = wave < NPF ? w3_block(a.W3_lin1, 2 * wave, KCX, lane) : nullptr;
   const nu32x4* w_lin2 = wave < NPX ? w3_block(a.W3_lin2, 2 * wave, KCF, lane) : nullptr;
-  const nu32x4* w_qkv0 = has_qkv && wave < 3 * NPX ? w3_block(a.W3_qkv, 2 * wave, KCX, lane) : nullptr;
+  const int tail_pairs = a.tail_pairs > 0 ? a.tail_pairs : 3 * NPX;
+  const int tail_ld = a.tail_pairs > 0 ? a.tail_ld : 3 * DX;
+  const nu32x4* w_qkv0 = has_qkv && wave < tail_pairs ? w3_block(a.W3_qkv, 2 * wave, KCX, lane) : nullptr;
   NWRing ring;
   ring.next = nullptr;
   if (w_xout != nullptr) w3_prime<KCX>(ring, w_xout);
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
                                                 a.X_out, grow, gok);
   if (!has_qkv) return;
   __syncthreads();
-  // ---- q | k | v of the next layer: planes(R2) -> global
+  // ---- trailing Linear on the new X (q | k | v of the next layer, or mlp_out_X.0 + ReLU after the last): planes(R2) -> global
   {
     long long qrow[NRG];
     bool qok[NRG];
@@ -482,16 +484,23 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
       qok[rg] = ridx < count;
       qrow[rg] = a.rows[qok[rg] ? ridx : count - 1];
     }
-    for (int pr = wave; pr < 3 * NPX; pr += 8) {
+    for (int pr = wave; pr < tail_pairs; pr += 8) {
       f32x4 acc[2][NRG];
       bias_acc(acc, a.b_qkv, 2 * pr);
-      const nu32x4* wn = pr + 8 < 3 * NPX ? w3_block(a.W3_qkv, 2 * (pr + 8), KCX, lane) : nullptr;
+      const nu32x4* wn = pr + 8 < tail_pairs ? w3_block(a.W3_qkv, 2 * (pr + 8), KCX, lane) : nullptr;
       tile_linear_x3<KCX, KCX, KS, PLANE, NRG>(acc, ring, w3_block(a.W3_qkv, 2 * pr, KCX, lane), wn, S2, p, g);
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
         for (int rg = 0; rg < NRG; ++rg)
-          if (qok[rg]) *reinterpret_cast<f32x4*>(a.qkv + qrow[rg] * (3 * DX) + 16 * (2 * pr + blk) + 4 * g) = acc[blk][rg];
+          if (qok[rg]) {
+            f32x4 o = acc[blk][rg];
+            if (a.tail_relu) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(a.qkv + qrow[rg] * tail_ld + 16 * (2 * pr + blk) + 4 * g) = o;
+          }
     }
   }
 }
@@ -597,6 +606,8 @@ static int launch_one(const NodeLayerArgs& a, int M, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3((M + rows_per_tile - 1) / rows_per_tile), dim3(512), lds, st, a);
   return 0;
 }
+
+bool node_layer_x3_enabled() { return node_x3(); }
 
 bool node_layer_supported(int dx, int ffx) { return (dx == 256 && ffx == 256) || (dx == 128 && ffx == 128); }
 
