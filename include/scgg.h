@@ -148,6 +148,12 @@ int scgg_adjacency_features(const int8_t* labels, const int8_t* node_labels, con
                             int32_t y_ld, int32_t y_off, float* e_out, int32_t e_ld, int32_t e_off, float* onehot_out,
                             float* lap_out, void* stream);
 
+/* The padded combinatorial Laplacian alone: replaces EigenFeatures.compute_laplacian
+ * (src/ConStruct/diffusion/extra_features.py:121-127 with the padding of :88-94), bit-identical to the lap_out of
+ * scgg_adjacency_features.  Separate so that scgg_eigen_features can start (on another stream) while the remaining
+ * structural features are computed.  labels int8 [B,n,n] (> 0 = edge), lap_out [B,n,n].  n <= 32 in this round. */
+int scgg_laplacian(const int8_t* labels, const uint8_t* node_mask, int32_t B, int32_t n, float* lap_out, void* stream);
+
 /* EigenFeatures.compute_features after the Laplacian (extra_features.py:96-112, :138-195), including the
  * eigendecomposition the reference delegates to torch.linalg.eigh (:96): batched Jacobi, one wave per graph.
  *   eval_feat: graph b gets [#connected components | first num_eigenvalues non-zero eigenvalues / n_valid (padded

@@ -45,6 +45,7 @@ SIGNATURES = {
     "scgg_onehot_to_labels": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "scgg_adjacency_features": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp,
                                           _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "scgg_laplacian": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "scgg_eigen_features": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
 }
 

@@ -244,9 +244,51 @@ __global__ __launch_bounds__(256) void adjacency_features_kernel(AdjArgs a) {
   }
 }
 
+// The padded combinatorial Laplacian alone (EigenFeatures.compute_features :88-94, compute_laplacian :121-127), the same
+// numbers as adjacency_features_kernel's lap_out: handed out separately so that the eigensolver can start while the
+// rest of the structural features are still being computed.  One workgroup per graph, n <= 32.
+__global__ __launch_bounds__(256) void laplacian_kernel(const int8_t* labels, const uint8_t* mask, int n, float* lap_out) {
+  __shared__ float A[NT * LDT];
+  __shared__ float deg[NT];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int8_t* lab = labels + (long long)b * n * n;
+  const uint8_t* m = mask + b * n;
+  for (int idx = tid; idx < NT * NT; idx += 256) {
+    const int i = idx >> 5, j = idx & 31;
+    float v = 0.f;
+    if (i < n && j < n && i != j && m[i] && m[j]) v = lab[i * n + j] > 0 ? 1.f : 0.f;
+    A[i * LDT + j] = v;
+  }
+  __syncthreads();
+  if (tid < NT) {
+    float d = 0.f;
+    for (int j = 0; j < NT; ++j) d += A[tid * LDT + j];
+    deg[tid] = d;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < n * n; idx += 256) {
+    const int i = idx / n, j = idx - i * n;
+    float v;
+    if (m[i] && m[j]) v = (i == j ? deg[i] : 0.f) - A[i * LDT + j];
+    else v = (i == j && !m[i]) ? 2.0f * n : 0.f;
+    lap_out[(long long)b * n * n + idx] = v;
+  }
+}
+
 }  // namespace scgg
 
 using namespace scgg;
+
+extern "C" int scgg_laplacian(const int8_t* labels, const uint8_t* node_mask, int32_t B, int32_t n, float* lap_out,
+                              void* stream) {
+  if (!labels || !node_mask || !lap_out) return fail("laplacian: null argument");
+  if (B <= 0 || n <= 0) return fail("laplacian: bad shape");
+  if (n > NT) return fail("laplacian: n=%d > 32 is not built yet (LDS-tile kernel only)", n);
+  hipLaunchKernelGGL(laplacian_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), labels, node_mask, n, lap_out);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail("laplacian: %s", hipGetErrorString(e));
+  return 0;
+}
 
 extern "C" int scgg_adjacency_features(const int8_t* labels, const int8_t* node_labels, const uint8_t* node_mask,
                                        int32_t B, int32_t n, int32_t C, int32_t Cx, int32_t num_degree,

@@ -79,6 +79,15 @@ class ExtraFeatures:
             _lib.stream_ptr()), "adjacency_features")
         return x_dst, y_dst, e_dst, lap
 
+    def laplacian(self, labels, node_mask):
+        """The padded combinatorial Laplacian alone (reference compute_laplacian :121-127, padding :88-94), the same
+        numbers as ``adjacency_features(..., want_lap=True)`` returns: lets the eigensolver start first."""
+        B, n = node_mask.shape
+        lap = torch.empty(B, n, n, device=node_mask.device)
+        _lib.check(_lib.lib().scgg_laplacian(_lib.ptr(labels), _lib.ptr(node_mask.view(torch.uint8)), B, n, _lib.ptr(lap),
+                                             _lib.stream_ptr()), "laplacian")
+        return lap
+
     def eigen_features(self, lap, node_mask, evl_dst=None, evl_off=0, evc_dst=None, evc_off=0, want_raw=False):
         """EigenFeatures.compute_features after the Laplacian (reference :96-112, :138-195) on the device: batched
         Jacobi eigensolver + feature extraction in one kernel.  -> (evalue_feat, evector_feat[, w, V])."""

@@ -76,14 +76,15 @@ class DiscreteSampler:
             # X_in = [node one-hot | 3 cycle feats | LCC flag + eigenvectors], y_in = [n/n_max | graph feats |
             # eigenvalue feats | t], E_in = [edge one-hot | reachability + Adamic-Adar]: two kernels, no copies
             ky = 4 + ef.num_degree + 2 + 1 + C_e
-            _, _, _, lap = ef.adjacency_features(labels, node_mask, C_e, e_dst=st["E_in"], e_off=C_e, want_onehot=True,
-                                                 x_dst=st["X_in"], x_off=1, y_dst=st["y_in"], y_off=1)
-            st["y_in"][:, -1] = t / self.T
-            # The eigen features feed only X and y (extra_features.py:41-60): they run on the denoiser's second stream,
-            # ahead of its consumers of X / y and beside its edge input MLP (scgg_denoiser_side_stream).
+            # The eigen features feed only X and y (extra_features.py:41-60): Laplacian first, then the eigensolver on the
+            # denoiser's second stream (ahead of its consumers of X / y: scgg_denoiser_side_stream) while the caller's
+            # stream computes the rest of the structural features and the denoiser's edge input MLP.
             if os.environ.get("SCGG_NO_SIDE_STREAM"):   # development A/B switch
+                _, _, _, lap = ef.adjacency_features(labels, node_mask, C_e, e_dst=st["E_in"], e_off=C_e, want_onehot=True,
+                                                     x_dst=st["X_in"], x_off=1, y_dst=st["y_in"], y_off=1)
                 ef.eigen_features(lap, node_mask, evl_dst=st["y_in"], evl_off=1 + ky, evc_dst=st["X_in"], evc_off=4)
             else:
+                lap = ef.laplacian(labels, node_mask)
                 side = st.get("side_stream")
                 if side is None:
                     side = st["side_stream"] = self.model.side_stream(node_mask.device)
@@ -91,6 +92,9 @@ class DiscreteSampler:
                 with torch.cuda.stream(side):
                     lap.record_stream(side)
                     ef.eigen_features(lap, node_mask, evl_dst=st["y_in"], evl_off=1 + ky, evc_dst=st["X_in"], evc_off=4)
+                ef.adjacency_features(labels, node_mask, C_e, e_dst=st["E_in"], e_off=C_e, want_onehot=True, want_lap=False,
+                                      x_dst=st["X_in"], x_off=1, y_dst=st["y_in"], y_off=1)
+            st["y_in"][:, -1] = t / self.T
         else:
             _lib.check(_lib.lib().scgg_labels_to_onehot(_lib.ptr(labels), None, B * n * n, C_e, 0, _lib.ptr(st["E_in"]), None,
                                                         _lib.stream_ptr()), "labels_to_onehot")

@@ -41,6 +41,8 @@ def test_adjacency_features_match_reference(name, maxn):
     np.testing.assert_allclose(e.cpu().numpy(), g["adj_e"], rtol=1e-5, atol=1e-6)
     L = XF.laplacian_for_eigh(torch.from_numpy(g["E"]), torch.from_numpy(g["node_mask"]))
     np.testing.assert_array_equal(lap.cpu().numpy(), L.numpy())
+    # the stand-alone Laplacian entry point (scgg_laplacian) gives the same matrix
+    np.testing.assert_array_equal(ef.laplacian(labels, d.node_mask).cpu().numpy(), L.numpy())
 
 
 def test_onehot_and_features_written_into_strided_input():
