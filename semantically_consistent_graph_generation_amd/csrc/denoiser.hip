@@ -486,6 +486,14 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     }
     if (signal(ev_e0, st)) return fail("event record failed");
   }
+  // the output tensors are zero outside the valid rows / live pairs (utils.py:154) and only their valid part is written
+  // at the end: zero-filled now, while the caller's stream waits for the prologue of the second stream anyway
+  bool out_zeroed = false;
+  if (!tap && y_on_main) {
+    if (c.out_X > 0 && o1 && hipMemsetAsync(o1, 0, (size_t)M * c.out_X * sizeof(float), st) != hipSuccess) return fail("memset failed");
+    if (hipMemsetAsync(o2, 0, (size_t)M * n * c.out_E * sizeof(float), st) != hipSuccess) return fail("memset failed");
+    out_zeroed = true;
+  }
   {
     hipStream_t ys = y_on_main ? st : ax;
     if (y_on_main && await(st, ev_pro)) return fail("stream wait failed");
@@ -689,7 +697,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     bool rows_only = head_fused || (h->out_X1.W3 != nullptr && c.out_X <= 16 && c.hid_X % 4 == 0 &&
                                     launch_node_linear_x3(la, h->out_X1.W3, M, ax) == 0);
     if (rows_only) {
-      if (hipMemsetAsync(o1, 0, (size_t)M * c.out_X * sizeof(float), ax) != hipSuccess) return fail("memset failed");
+      if (!out_zeroed && hipMemsetAsync(o1, 0, (size_t)M * c.out_X * sizeof(float), ax) != hipSuccess) return fail("memset failed");
       if (launch_row_head(w.hidX, c.hid_X, w3->p, b3->p, X, c.in_X, w.rows, w.row_count, o1, M, c.out_X, c.hid_X, ax))
         return fail("row_head rejected");
     } else {
@@ -709,7 +717,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   }
   {
     // logits are zero outside the live pairs (utils.py:154); the unit kernel writes the chunks that hold valid keys
-    if (hipMemsetAsync(o2, 0, (size_t)M * n * c.out_E * sizeof(float), st) != hipSuccess) return fail("memset failed");
+    if (!out_zeroed && hipMemsetAsync(o2, 0, (size_t)M * n * c.out_E * sizeof(float), st) != hipSuccess) return fail("memset failed");
     EdgeMlpUnitArgs a{Ecur, E, mask, h->out_E_img, o2, w.units, w.unit_count, B, n, c.in_E, c.out_E};
     if (launch_edge_mlp_out(a, de, c.hid_E, c.out_E, st)) return fail("edge_mlp_out: unsupported dims");
   }
