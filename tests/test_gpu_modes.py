@@ -1,0 +1,47 @@
+"""The bf16x3 ("x3") kernels against the plain fp32-MFMA kernels they replaced (SCGG_EDGE_MODE / SCGG_NODE_MODE = f32,
+read once per process, hence the subprocesses): same network, same inputs, the two results must agree to fp32
+round-off, which is what "fp32 accuracy on the bf16 matrix pipe"  promises.  Both also stay
+within the oracle tolerance through the ordinary parity tests; this one pins the two HIP paths to each other."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from oracle import fixtures as fx
+from semantically_consistent_graph_generation_amd.transformer_model import GraphTransformer, model_input
+torch.manual_seed(5)
+dims = fx.CONSTRUCT_DIMS
+ind, od, B, n = (10, 25, 13), (1, 14, 0), 6, 32
+model = GraphTransformer(3, fx.dims_ns(*ind), dims["hidden_mlp_dims"], dims["hidden_dims"], fx.dims_ns(*od)).eval().cuda()
+X = torch.randn(B, n, ind[0]); E = torch.randn(B, n, n, ind[1]); E = 0.5 * (E + E.transpose(1, 2)); y = torch.randn(B, ind[2])
+mask = fx.ragged_mask(torch.tensor([32, 12, 27, 16, 5, 21]), n)
+out = model(model_input(X.cuda(), E.cuda(), y.cuda(), mask.cuda()))
+torch.cuda.synchronize()
+np.savez(sys.argv[1], X=out.X.cpu().numpy(), E=out.E.cpu().numpy())
+"""
+
+
+def _run(tmp_path, tag, env_extra):
+    out = tmp_path / f"{tag}.npz"
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, "-c", SCRIPT.format(root=ROOT), str(out)], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(out)
+
+
+@pytest.mark.gpu
+def test_x3_kernels_agree_with_fp32_mfma_kernels(tmp_path):
+    a = _run(tmp_path, "x3", {})
+    b = _run(tmp_path, "f32", {"SCGG_EDGE_MODE": "f32", "SCGG_NODE_MODE": "f32"})
+    for k in ("X", "E"):
+        scale = float(np.abs(b[k]).max())
+        err = float(np.abs(a[k] - b[k]).max()) / scale
+        assert err < 2e-5, f"{k}: x3 vs fp32 MFMA differ by {err:.2e} of the output scale"   # fp32 round-off over 3 layers
