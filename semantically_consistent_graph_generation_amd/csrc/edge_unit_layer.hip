@@ -720,8 +720,19 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
   const int n = a.n;
   const int nch = (n + 15) >> 4;
   const int count = *a.unit_count;
+  // Rounds: in a full round workgroup b takes the NW consecutive units of its slot.  The units left over for the last,
+  // partial round are spread over ALL workgroups (q consecutive units each) instead of filling the first ones: a round's
+  // duration grows with the number of active waves on the CU (it is latency-bound), so half-filled workgroups everywhere
+  // finish sooner than full ones on half of the CUs.
   const int per_iter = NW * gridDim.x;
-  const int iters = (count + per_iter - 1) / per_iter;
+  const int full = count / per_iter, rest = count - full * per_iter;
+  const int iters = full + (rest > 0 ? 1 : 0);
+  const int q_last = (rest + (int)gridDim.x - 1) / (int)gridDim.x;
+  auto slot = [&](int it) -> int {                                     // unit-list index of this wave in round `it`
+    if (it < full) return (it * (int)gridDim.x + (int)blockIdx.x) * NW + wave;
+    const int r = (int)blockIdx.x * q_last + wave;
+    return (it == full && wave < q_last && r < rest) ? full * per_iter + r : count;
+  };
   constexpr float LOG2E = 1.4426950408889634f;
   typedef const char* cptr;
   auto ldo = [](cptr base, unsigned off) { return *reinterpret_cast<const f32x4*>(base + off); };   // scalar base + lane offset
@@ -780,7 +791,7 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
     }
   };
 
-  Unit un = unit_of(blockIdx.x * NW + wave);
+  Unit un = unit_of(slot(0));
   int mk = mask_byte(un);
   f32x4 e[IBE];
   if (un.active) {
@@ -800,7 +811,7 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
     const bool inb = j < n, vj = mk != 0, live = vj && j != un.i;
     const int jj = inb ? j : 0;
     // the next unit: scalars now, the mask byte of the lane's key in flight until the FFN phases
-    const Unit nx = unit_of(((it + 1) * gridDim.x + blockIdx.x) * NW + wave);
+    const Unit nx = unit_of(slot(it + 1));
     const int nmk = mask_byte(nx);
 
     const cptr kbase = reinterpret_cast<cptr>(a.K + (long long)un.b * n * a.ldqkv);
