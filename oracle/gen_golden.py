@@ -405,8 +405,66 @@ def gen_placeholder(R):
     save("f11_placeholder", X=X, E=E, pos=pos, node_mask=mask, mX=ph.X, mE=ph.E, mpos=ph.pos, cX=col.X, cE=col.E)
 
 
+def gen_projector(R):
+    """F12: the host-side validity projectors (projector_3d_utils.py) driven over a synthetic absorbing-style
+    trajectory: at step s every still-empty pair takes the step's proposal, the REAL projector edits z_s in place,
+    and the edited state is the next z_t.  Stored: proposals, candidates, the projected labels per step, the
+    blocked-edge table and (CoW) the correction counter.  np.random is seeded once before the constructor."""
+    import contextlib
+    import io
+    from src.ConStruct.projector import projector_3d_utils as PJ
+    cases = (("cow", "CoWProjector", 14, [10, 7, 12, 3, 1, 9]), ("cow_vanilla", "CoWVanillaProjector", 14, [10, 7, 12, 3, 1, 9]),
+             ("atm", "ATMTreeProjector", 5, [10, 7, 12, 3, 1, 9]), ("atm_vanilla", "ATMVanillaTreeProjector", 5, [10, 7, 12, 3, 1, 9]),
+             ("tree", "TreeProjector", 5, [10, 7, 12, 3, 1, 9]))
+    S, k = 12, 4
+    for ci, (name, cls, C, n_nodes) in enumerate(cases):
+        rs = np.random.RandomState(900 + ci)
+        mask = fx.ragged_mask(n_nodes)
+        B, n = mask.shape
+        valid = (mask[:, :, None] & mask[:, None, :]).numpy() & ~np.eye(n, dtype=bool)[None]
+        props = np.zeros((S, B, n, n), dtype=np.int8)
+        cands = np.zeros((S, B, n, n, k), dtype=np.int8)
+        for s in range(S):
+            lab = np.where(rs.rand(B, n, n) < 0.5, rs.randint(1, min(C, 4), (B, n, n)), rs.randint(1, C, (B, n, n)))
+            on = rs.rand(B, n, n) < (0.10 if s % 4 else 0.03)
+            lab = np.triu(lab * on, 1)
+            props[s] = (lab + lab.transpose(0, 2, 1)) * valid
+            cd = np.argsort(rs.rand(B, n, n, C), axis=-1)[..., :k]          # k distinct classes, 0 included
+            iu = np.triu(np.ones((n, n), dtype=bool), 1)[None, :, :, None]
+            cands[s] = np.where(iu, cd, cd.transpose(0, 2, 1, 3))
+        seed = 4000 + ci
+        np.random.seed(seed)
+        z = torch.zeros(B, n, n, dtype=torch.long)
+        def holder(lab, cd):
+            return R.U.PlaceHolder(X=mask[..., None].float(), E=fx.one_hot_edges(lab, mask, C), y=torch.zeros(B, 0),
+                                   node_mask=mask, pos=torch.zeros(B, n, 3), extra_info=cd)
+        sink = io.StringIO()
+        with contextlib.redirect_stdout(sink):
+            z_T = holder(z, None)
+            proj = getattr(PJ, cls)(z_T) if cls == "TreeProjector" else getattr(PJ, cls)(z_T, torch.device("cpu"))
+            outs = np.zeros((S, B, n, n), dtype=np.int8)
+            for s in range(S):
+                raw = torch.where(z == 0, torch.from_numpy(props[s]).long(), z)
+                z_s = holder(raw, torch.from_numpy(cands[s]).long())
+                proj.project(z_s)
+                z = torch.argmax(z_s.E, dim=3) * (z_s.E.sum(-1) > 0)
+                outs[s] = z.numpy()
+        blocked = np.zeros((B, n, n), dtype=bool)
+        for b, d in proj.blocked_edges.items():
+            for (i, j), v in d.items():
+                blocked[b, i, j] = v
+        counter = getattr(getattr(proj, "top_cow_validity_check_and_fix_obj", None), "counter", 0)
+        n_del = int(sum(((np.where(outs[s] == 0, 1, 0) * (props[s] != 0))).sum() for s in range(S)))
+        print(f"{name}: kept {int((outs[-1] != 0).sum()) // 2} edges, blocked {int(blocked.sum())}, counter {counter}, "
+              f"relabelled {int(((outs[-1] != 0) & (sum(props.astype(np.int64)) != 0) & (outs[-1] != np.where(outs[-1] != 0, outs[-1], 0))).sum())}")
+        save(f"f12_projector_{name}", node_mask=mask, C=C, top_k=k, seed=seed, props=props, cands=cands, out_labels=outs,
+             blocked=blocked, counter=counter)
+
+
 def main():
     R = import_reference()
+    if sys.argv[1:] == ["projector"]:
+        return gen_projector(R)
     gen_block_and_layer(R)
     gen_graph_transformer(R)
     gen_pooling(R)
@@ -415,6 +473,7 @@ def main():
     gen_reverse_step(R)
     gen_sample_discrete(R)
     gen_placeholder(R)
+    gen_projector(R)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,490 @@
+"""Host-side validity projectors of the reverse loop.
+
+Mirrors /root/reference/src/ConStruct/projector/projector_3d_utils.py: ``CoWProjector`` (:213-387),
+``CoWVanillaProjector`` (:464-598), ``ATMTreeProjector`` (:662-840), ``ATMVanillaTreeProjector`` (:917-1052),
+``TreeProjector`` (:157-164 over ``AbstractProjector`` :16-147) and ``BaseValidProjector`` (:168-183): same
+constructor arguments, same ``project(z_s)`` (in-place edit of ``z_s.E``), same ``blocked_edges`` /
+``nx_graphs_list`` / ``counter`` attributes, same use of the GLOBAL ``np.random`` stream (one
+``np.random.shuffle`` of an ``[m, 2]`` array per graph that falls back to one-by-one insertion), so a run under
+``np.random.seed(k)`` gives the reference's result bit for bit (tests/golden/f12_projector_*.npz).
+
+What is different is the machinery:
+  * no networkx: every sample is a ``LabelGraph`` (adjacency dict + per-node label multiset) and the reference's
+    line-graph test (``is_line_graph_valid`` :431-461: every two edges that share a node must carry classes that
+    are equal or adjacent in the 13x13 / 4x4 table) is a bitmask test per node;
+  * ``project_labels(labels, cands)``: the state route of ``sampling.Sampler`` keeps the graph state as int8 labels
+    on the device, so the projector takes that tensor directly: the new edges (label differs from the stored
+    z_t, upper triangle, row-major = the order of ``Tensor.nonzero`` in the reference) are compacted on the
+    device, one small copy brings (b, i, j, label, candidates) to the host, and the host's edits go back as one
+    scatter.  The one-hot E and the int64 extra_info are never built.
+
+The reference's behaviour is kept where it is surprising (each is covered by the golden trajectories):
+  * one-by-one insertion shuffles the edges but not their labels / candidates (:330-331), so an edge can enter the
+    graph with another new edge's label;
+  * the all-at-once attempt is evaluated twice (:318 and again in the condition :327), the second time re-adding
+    every edge with its original label on top of the first pass's fixes;
+  * the vanilla variants do not write the graph's label back, so graph and tensor labels can differ;
+  * a candidate label stays on the edge when no candidate repairs it and later edges of the same attempt are
+    judged with it present (:412-426).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+
+# projector_3d_utils.py:193-205 (TopCoW segment classes 1..13) and :645-648 (ATM generations 1..4)
+COW_ADJACENCY = (
+    (0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0),
+    (1, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0),
+    (1, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0),
+    (0, 0, 0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0),
+    (0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 1, 0, 0),
+    (0, 0, 0, 0, 0, 0, 1, 0, 1, 0, 0, 1, 0),
+    (0, 0, 0, 0, 0, 1, 0, 0, 1, 0, 0, 1, 0),
+    (0, 1, 0, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0),
+    (0, 0, 1, 0, 0, 1, 1, 0, 0, 0, 0, 1, 0),
+    (0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1),
+    (0, 0, 0, 1, 1, 0, 0, 1, 0, 1, 0, 1, 1),
+    (0, 0, 0, 0, 0, 1, 1, 0, 1, 1, 1, 0, 1),
+    (0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 0),
+)
+ATM_ADJACENCY = ((0, 1, 0, 0), (1, 0, 1, 0), (0, 1, 0, 1), (0, 0, 1, 0))
+
+
+def _allowed_masks(table):
+    """allowed[c] = bit set of the classes that may sit beside class c at a node (c itself included: the reference
+    clears the diagonal, :457).  Bit c <-> class c, classes are 1-based, bit 0 unused."""
+    rows = [0]
+    for a, row in enumerate(table):
+        assert all(row[b] == table[b][a] for b in range(len(table))), "Not symmetric"        # check_symmetric :207
+        rows.append((1 << (a + 1)) | sum(1 << (b + 1) for b, v in enumerate(row) if v))
+    return tuple(rows)
+
+
+class LabelGraph:
+    """One sample's graph on the host: adj[u][v] = class of edge {u,v}; cnt[u][c] = edges of class c at node u."""
+
+    __slots__ = ("n", "adj", "cnt", "n_edges", "pending")
+
+    def __init__(self, n: int):
+        self.n = n
+        self.adj = [dict() for _ in range(n)]
+        self.cnt = [dict() for _ in range(n)]
+        self.n_edges = 0
+        self.pending = None            # the reference's nx_graph.graph['all_possible_new_edges_to_add']
+
+    def copy(self) -> "LabelGraph":
+        g = LabelGraph.__new__(LabelGraph)
+        g.n, g.n_edges, g.pending = self.n, self.n_edges, self.pending
+        g.adj = [d.copy() for d in self.adj]
+        g.cnt = [d.copy() for d in self.cnt]
+        return g
+
+    def _count(self, u, c, d):
+        k = self.cnt[u].get(c, 0) + d
+        if k:
+            self.cnt[u][c] = k
+        else:
+            del self.cnt[u][c]
+
+    def add_edge(self, u: int, v: int, label=None):
+        """nx.Graph.add_edge: an existing edge keeps its place and takes the new label."""
+        old = self.adj[u].get(v, self)
+        if old is self:
+            self.n_edges += 1
+        else:
+            self._count(u, old, -1)
+            self._count(v, old, -1)
+        self.adj[u][v] = label
+        self.adj[v][u] = label
+        self._count(u, label, 1)
+        self._count(v, label, 1)
+
+    def remove_edge(self, u: int, v: int):
+        c = self.adj[u].pop(v)
+        del self.adj[v][u]
+        self._count(u, c, -1)
+        self._count(v, c, -1)
+        self.n_edges -= 1
+
+    def label(self, u: int, v: int):
+        return self.adj[u][v]
+
+    def number_of_nodes(self) -> int:
+        return self.n
+
+    def number_of_edges(self) -> int:
+        return self.n_edges
+
+    def edges(self):
+        return [(u, v, c) for u in range(self.n) for v, c in self.adj[u].items() if u < v]
+
+    def to_numpy_array(self) -> np.ndarray:
+        a = np.zeros((self.n, self.n))
+        for u, v, _ in self.edges():
+            a[u, v] = a[v, u] = 1.0
+        return a
+
+
+def line_graph_valid(g: LabelGraph, allowed) -> bool:
+    """is_line_graph_valid (:431-461, :881-912) / is_valid_graph (:605-637, :1060-1092): the line graph joins two
+    edges iff they share a node, so the set of class pairs it marks is the union over nodes of the pairs of
+    classes present at that node; invalid iff some pair of different classes is not in the table."""
+    n_cls = len(allowed)
+    for cnt in g.cnt:
+        if len(cnt) < 2:
+            continue
+        present = 0
+        for c in cnt:
+            if not 0 < c < n_cls:          # the reference indexes table[c-1, ...] here and fails the same way
+                raise IndexError(f"edge class {c} outside the validity table (1..{n_cls - 1})")
+            present |= 1 << c
+        for c in cnt:
+            if present & ~allowed[c]:
+                return False
+    return True
+
+
+def has_no_cycles(g: LabelGraph) -> bool:
+    """has_no_cycles (:150-154): fewer edges than nodes and nx.is_forest."""
+    if g.n_edges >= g.n:
+        return False
+    parent = list(range(g.n))
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    for u, v, _ in g.edges():
+        ru, rv = find(u), find(v)
+        if ru == rv:
+            return False
+        parent[ru] = rv
+    return True
+
+
+class _Fixer:
+    """check_validity_and_fix_if_needed (:395-428 with the rebuttal counter, :847-879 without)."""
+
+    def __init__(self, table, counted: bool):
+        self.allowed = _allowed_masks(table)
+        self.valid_adjacency = torch.as_tensor(table)
+        self.counted = counted
+        self.counter = 0
+
+    def is_line_graph_valid(self, g: LabelGraph) -> bool:
+        return line_graph_valid(g, self.allowed)
+
+    is_valid_graph = is_line_graph_valid
+
+    def check_validity_and_fix_if_needed(self, g: LabelGraph) -> bool:
+        if g.pending is None and g.n_edges == 0:
+            return True
+        all_ok = True
+        for (u, v), label, cx in g.pending:
+            g.add_edge(u, v, label)
+            ok = True
+            if not line_graph_valid(g, self.allowed):
+                ok = False
+                if self.counted:
+                    self.counter -= 1
+                for cand in cx:
+                    if self.counted:
+                        self.counter += 1
+                    cand = int(cand)
+                    if cand == 0:          # class 0 would delete the edge
+                        continue
+                    g.remove_edge(u, v)
+                    g.add_edge(u, v, cand)
+                    if line_graph_valid(g, self.allowed):
+                        ok = True
+                        break
+            all_ok = all_ok and ok
+        return all_ok
+
+
+def _adj_of(z, binary: bool) -> torch.Tensor:
+    """get_multi_class_adj_matrix (:185-187) / get_adj_matrix (:10-13)."""
+    a = torch.argmax(z.E, dim=3)
+    return (a != 0).long() if binary else a
+
+
+class _Projector:
+    """Shared driver: device-side diff and write-back around the per-graph host routine of the subclass."""
+
+    binary = False           # TreeProjector compares 0/1 adjacency (:59-62), the others the class labels
+    uses_cands = False
+    can_block_edges = True
+
+    def __init__(self, z_t, device=None):
+        self.batch_size = z_t.X.shape[0]
+        self.device = torch.device(device) if device is not None else z_t.X.device
+        if getattr(z_t, "E", None) is not None:
+            self.z_t_adj = _adj_of(z_t, self.binary)
+        else:                                  # our sampler's z_T without the one-hot: int8 labels, -1 = zero row
+            self.z_t_adj = z_t._labels.clone()
+        assert bool((self.z_t_adj <= 0).all()), "the limit distribution has no edges"            # :234 / :37
+        n_nodes = z_t.node_mask.sum(dim=1).tolist()
+        self.nx_graphs_list = [LabelGraph(int(k)) for k in n_nodes]
+        for g in self.nx_graphs_list:
+            assert self._valid_empty(g)
+        self.blocked_edges = {b: {(i, j): False for i in range(int(k)) for j in range(i + 1, int(k))}
+                              for b, k in enumerate(n_nodes)}
+
+    # ---- per-class pieces -----------------------------------------------------------------------------------
+    def _valid_empty(self, g) -> bool:
+        return True
+
+    def _project_graph(self, b, edges, attrs, cands, edits):
+        raise NotImplementedError
+
+    # ---- reference interface --------------------------------------------------------------------------------
+    def project(self, z_s):
+        """project(z_s) of the reference: one-hot ``z_s.E`` (and int ``z_s.extra_info``) in, ``z_s.E`` edited in place."""
+        z_s_adj = _adj_of(z_s, self.binary)
+        diff = z_s_adj - self.z_t_adj.clamp(min=0).to(z_s_adj.dtype)
+        assert bool((diff >= 0).all()), "Once unmasked, the edges cannot be removed."
+        new = diff.nonzero(as_tuple=False)
+        new = new[new[:, 1] < new[:, 2]]
+        attrs = z_s_adj[new[:, 0], new[:, 1], new[:, 2]]
+        cands = None
+        if self.uses_cands:
+            cands = z_s.extra_info[new[:, 0], new[:, 1], new[:, 2]].cpu().numpy()
+        edits = self._run(new.cpu().numpy(), attrs.cpu().numpy(), cands)
+        if edits:
+            C = z_s.E.shape[-1]
+            e = torch.as_tensor(edits, dtype=torch.long, device=z_s.E.device)
+            rows = torch.nn.functional.one_hot(e[:, 3], C).to(z_s.E.dtype)
+            z_s.E[e[:, 0], e[:, 1], e[:, 2]] = rows
+            z_s.E[e[:, 0], e[:, 2], e[:, 1]] = rows
+        self.z_t_adj = _adj_of(z_s, self.binary)
+
+    # ---- state route ----------------------------------------------------------------------------------------
+    def project_labels(self, labels: torch.Tensor, cands: torch.Tensor = None):
+        """Same step on the int8 state of ``Sampler.sample_batch``: labels [B,n,n] (padding/diagonal 0 or -1 are never
+        new edges), cands [B,n,n,k] int8.  Edits ``labels`` in place; returns the number of edited pairs."""
+        if self.uses_cands and cands is None:
+            raise _lib.ScggError(f"{type(self).__name__}.project_labels needs the top-k candidates")
+        prev = self.z_t_adj if self.z_t_adj.dtype == labels.dtype else self.z_t_adj.to(labels.dtype)
+        if self.binary:
+            changed = (labels > 0) & ~(prev > 0)
+            assert not bool(((prev > 0) & ~(labels > 0)).any()), "Once unmasked, the edges cannot be removed."
+        else:
+            changed = labels > prev
+            assert not bool((labels < prev).any()), "Once unmasked, the edges cannot be removed."
+        new = changed.triu(1).nonzero(as_tuple=False)
+        attrs = labels[new[:, 0], new[:, 1], new[:, 2]].long()
+        rec = [new, attrs[:, None]]
+        if self.uses_cands:
+            rec.append(cands[new[:, 0], new[:, 1], new[:, 2]].long())
+        rec = torch.cat(rec, dim=1).cpu().numpy()                 # the one device -> host copy of the step
+        edits = self._run(rec[:, :3], rec[:, 3], rec[:, 4:] if self.uses_cands else None)
+        if edits:
+            e = torch.as_tensor(edits, dtype=torch.long, device=labels.device)
+            v = e[:, 3].to(labels.dtype)
+            labels[e[:, 0], e[:, 1], e[:, 2]] = v
+            labels[e[:, 0], e[:, 2], e[:, 1]] = v
+        self.z_t_adj = labels.clone()
+        return len(edits)
+
+    # ---- host part ------------------------------------------------------------------------------------------
+    def _run(self, new, attrs, cands):
+        """new [m,3] (b,i,j) in row-major order with i<j.  Returns the edits [(b,i,j,label)], last write per pair."""
+        edits = []
+        if len(new):
+            starts = np.searchsorted(new[:, 0], np.arange(self.batch_size + 1))
+        for b in range(self.batch_size):
+            lo, hi = (starts[b], starts[b + 1]) if len(new) else (0, 0)
+            if hi > lo:
+                self._project_graph(b, new[lo:hi, 1:], attrs[lo:hi], cands[lo:hi] if cands is not None else None, edits)
+        last = {}
+        for b, u, v, c in edits:
+            last[(int(b), int(u), int(v))] = int(c)
+        return [(b, u, v, c) for (b, u, v), c in last.items()]
+
+    def _drop_blocked(self, b, edges, edits):
+        """:282-301: an edge blocked in an earlier step is deleted again at once; returns the indices kept."""
+        blocked = self.blocked_edges[b]
+        keep = []
+        for idx, (u, v) in enumerate(edges):
+            if blocked[(int(u), int(v))]:
+                edits.append((b, u, v, 0))
+            else:
+                keep.append(idx)
+        return keep
+
+
+class _FixingProjector(_Projector):
+    """project() of CoWProjector (:256-377) and ATMTreeProjector (:697-825)."""
+
+    uses_cands = True
+
+    def _try(self, g) -> bool:
+        raise NotImplementedError
+
+    def _valid_empty(self, g):
+        return self._try(g)
+
+    def try_fix_and_validate_fn(self, g) -> bool:
+        return self._try(g)
+
+    def _project_graph(self, b, edges, attrs, cands, edits):
+        g = self.nx_graphs_list[b]
+        old = g.copy()
+        keep = self._drop_blocked(b, edges, edits)
+        if not keep:
+            return
+        edges, attrs, cands = np.array(edges[keep]), attrs[keep], cands[keep]
+        if len(edges) > 1:
+            g.pending = [((int(u), int(v)), int(label), cx) for (u, v), label, cx in zip(edges, attrs, cands)]
+            if self._try(g):
+                for u, v in edges:
+                    edits.append((b, u, v, g.label(int(u), int(v))))
+        if len(edges) == 1 or not self._try(g):
+            g = old
+            self._shuffle(edges)                   # edges only: labels and candidates keep their order (:330-331)
+            for (u, v), label, cx in zip(edges, attrs, cands):
+                u, v = int(u), int(v)
+                old = g.copy()
+                g.pending = [((u, v), int(label), cx)]
+                if not self._try(g):
+                    g = old
+                    edits.append((b, u, v, 0))
+                    self.blocked_edges[b][(u, v)] = True
+                else:
+                    edits.append((b, u, v, g.label(u, v)))
+            self.nx_graphs_list[b] = g
+
+    @staticmethod
+    def _shuffle(edges):
+        np.random.shuffle(edges)
+
+
+class _VanillaProjector(_Projector):
+    """project() of CoWVanillaProjector (:499-590), ATMVanillaTreeProjector (:952-1043) and AbstractProjector (:57-147)."""
+
+    def valid_graph_fn(self, g) -> bool:
+        raise NotImplementedError
+
+    def _valid_empty(self, g):
+        return self.valid_graph_fn(g)
+
+    def _project_graph(self, b, edges, attrs, cands, edits):
+        g = self.nx_graphs_list[b]
+        old = g.copy()
+        keep = self._drop_blocked(b, edges, edits)
+        if not keep:
+            return
+        edges, attrs = np.array(edges[keep]), attrs[keep]
+        if len(edges) > 1:
+            for (u, v), label in zip(edges, attrs):
+                g.add_edge(int(u), int(v), self._label(label))
+        if not self.valid_graph_fn(g) or len(edges) == 1:
+            g = old
+            np.random.shuffle(edges)
+            for (u, v), label in zip(edges, attrs):
+                u, v = int(u), int(v)
+                old = g.copy()
+                g.add_edge(u, v, self._label(label))
+                if not self.valid_graph_fn(g):
+                    g = old
+                    edits.append((b, u, v, 0))
+                    self.blocked_edges[b][(u, v)] = True
+            self.nx_graphs_list[b] = g
+
+    @staticmethod
+    def _label(label):
+        return int(label)
+
+
+class CoWProjector(_FixingProjector):
+    """:213-387 -- TopCoW class adjacency with repair from the top-k candidates."""
+
+    def __init__(self, z_t, device=None):
+        self.top_cow_validity_check_and_fix_obj = _Fixer(COW_ADJACENCY, counted=True)
+        super().__init__(z_t, device)
+
+    def _try(self, g):
+        return self.top_cow_validity_check_and_fix_obj.check_validity_and_fix_if_needed(g)
+
+
+class ATMTreeProjector(_FixingProjector):
+    """:662-840 -- ATM generation adjacency with repair, and no cycles."""
+
+    def __init__(self, z_t, device=None):
+        self.atm_validity_check_and_fix_obj = _Fixer(ATM_ADJACENCY, counted=False)
+        super().__init__(z_t, device)
+
+    def _try(self, g):
+        return self.atm_validity_check_and_fix_obj.check_validity_and_fix_if_needed(g) and has_no_cycles(g)
+
+    def valid_graph_fn_lite(self, g) -> bool:
+        return g.pending is None and self.atm_validity_check_and_fix_obj.is_line_graph_valid(g)
+
+
+class CoWVanillaProjector(_VanillaProjector):
+    """:464-598 -- TopCoW class adjacency, violating edges deleted."""
+
+    def __init__(self, z_t, device=None):
+        self.top_cow_validity_check = _Fixer(COW_ADJACENCY, counted=False)
+        super().__init__(z_t, device)
+
+    def valid_graph_fn(self, g):
+        return self.top_cow_validity_check.is_valid_graph(g)
+
+
+class ATMVanillaTreeProjector(_VanillaProjector):
+    """:917-1052 -- ATM generation adjacency and no cycles, violating edges deleted."""
+
+    def __init__(self, z_t, device=None):
+        self.atm_validity_check = _Fixer(ATM_ADJACENCY, counted=False)
+        super().__init__(z_t, device)
+
+    def valid_graph_fn(self, g):
+        return self.atm_validity_check.is_valid_graph(g) and has_no_cycles(g)
+
+
+class TreeProjector(_VanillaProjector):
+    """:157-164 over AbstractProjector :16-147 -- unlabelled forest constraint on the 0/1 adjacency."""
+
+    binary = True
+
+    def __init__(self, z_t, device=None):
+        super().__init__(z_t, device)
+
+    def valid_graph_fn(self, g):
+        return has_no_cycles(g)
+
+    @staticmethod
+    def _label(label):
+        return None
+
+
+class BaseValidProjector:
+    """:168-183 -- checks only that no edge disappeared; stateless (its z_t_adj is never advanced in the reference
+    either, so the check is against the empty limit graph)."""
+
+    can_block_edges = True
+
+    def __init__(self, z_t, device=None):
+        self.batch_size = z_t.X.shape[0]
+
+    def project(self, z_s):
+        pass
+
+    def project_labels(self, labels, cands=None):
+        return 0
+
+    def valid_graph_fn(self, g) -> bool:
+        return True
+
+
+def projector_for(rev_proj):
+    """cfg.model.rev_proj -> class (diffusion_model_discrete_3d.py:636-650); falsy -> None (the loop skips it, :660)."""
+    if not rev_proj:
+        return None
+    return {"cow_proj": CoWProjector, "cow_proj_vanilla": CoWVanillaProjector, "atm_proj": ATMTreeProjector,
+            "atm_proj_vanilla": ATMVanillaTreeProjector}.get(rev_proj, BaseValidProjector)

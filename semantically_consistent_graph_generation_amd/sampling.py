@@ -117,7 +117,8 @@ class DiscreteSampler:
         node_mask = (torch.arange(n, device=dev)[None, :] < n_nodes[:, None]).contiguous()
         nm = self.noise_model
         gen = torch.Generator(device=dev).manual_seed(seed)
-        z_T = nm.sample_limit_dist(node_mask, generator=gen, with_onehot=projector is not None)
+        on_state = hasattr(projector, "project_labels")      # our projector.py classes take the int8 state directly
+        z_T = nm.sample_limit_dist(node_mask, generator=gen, with_onehot=projector is not None and not on_state)
         st = self._alloc_state(node_mask)
         cur = 0
         st["labels"][0].copy_(z_T._labels)
@@ -135,7 +136,9 @@ class DiscreteSampler:
             nm.reverse_step_state(pred.E, labels_t, node_mask, st["t_all"][t], st["t_all"][s], rng,
                                   labels_out=st["labels"][cur ^ 1], cands_out=st["cands"][cur ^ 1])
             cur ^= 1
-            if proj is not None:   # host-side validity projector: reference types in, in-place edit of z_s.E
+            if proj is not None and on_state:      # projector.py: compacted new edges to the host, edits scattered back
+                proj.project_labels(st["labels"][cur], st["cands"][cur])
+            elif proj is not None:   # any other host-side projector: reference types in, in-place edit of z_s.E
                 s_int = torch.full((B, 1), s, dtype=torch.long, device=dev)
                 z_s = nm._to_placeholder(st["labels"][cur], st["cands"][cur], node_mask, s_int, pos, B)
                 proj.project(z_s)

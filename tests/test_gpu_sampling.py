@@ -121,3 +121,47 @@ def test_absorbing_chain_never_removes_an_edge():
             assert torch.equal(lab[had], prev[had])
         prev = lab
     assert int((prev > 0).sum()) > 0
+
+
+def test_projector_state_route_equals_placeholder_route_in_the_loop():
+    """Row a9 inside the loop: projector.py on the int8 device state (project_labels) gives the chain that the same
+    projector gives through the reference-typed route (one-hot z_s.E + int64 extra_info, project()), same np.random
+    seed; the ATM projector's result is a forest."""
+    from semantically_consistent_graph_generation_amd import projector as PJ
+    sampler, nm = make_cow_sampler(T=10)
+    n_nodes = [14, 6, 11, 1]
+    for cls in (PJ.CoWProjector, PJ.CoWVanillaProjector):
+        made = []
+
+        def via_state(z_T, dev):
+            made.append(cls(z_T, dev))
+            return made[-1]
+        via_state.project_labels = True          # the sampler keys the route on this attribute
+
+        def via_placeholder(z_T, dev):
+            made.append(cls(z_T, dev))
+            return SimpleNamespace(project=made[-1].project)
+        np.random.seed(5)
+        a, _, mask, _ = sampler.sample_batch(n_nodes, seed=4, projector=via_state, return_state=True)
+        np.random.seed(5)
+        b, _, _, _ = sampler.sample_batch(n_nodes, seed=4, projector=via_placeholder, return_state=True)
+        free, _, _, _ = sampler.sample_batch(n_nodes, seed=4, return_state=True)
+        assert torch.equal(a, b)
+        assert made[0].blocked_edges == made[1].blocked_edges
+        assert int((a > 0).sum()) > 0 and not torch.equal(a, free)       # the projector did intervene
+        L = a.cpu()
+        assert torch.equal(L, L.transpose(1, 2))
+        for bi, g in enumerate(made[0].nx_graphs_list):                  # stored graph == adjacency of the state
+            k = g.number_of_nodes()
+            assert np.array_equal((L[bi, :k, :k] > 0).numpy(), g.to_numpy_array() != 0)
+    # ATM setting: 5 classes, forest constraint
+    from semantically_consistent_graph_generation_amd.sampling import DiscreteSampler
+    model, _ = tiny_model(5, 5, 1, 1)
+    smp = DiscreteSampler(model, make_noise_model("absorbing_edges", 5, T=10, top_k=4))
+    np.random.seed(6)
+    lab, _, _, _ = smp.sample_batch(n_nodes, seed=8, projector=PJ.ATMTreeProjector, return_state=True)
+    for bi, k in enumerate(n_nodes):
+        g = PJ.LabelGraph(k)
+        for i, j in (lab[bi, :k, :k].cpu().triu(1) > 0).nonzero().tolist():
+            g.add_edge(i, j, 1)
+        assert PJ.has_no_cycles(g)

@@ -1,0 +1,102 @@
+"""Host-side validity projectors against trajectories recorded from the REAL reference
+(oracle/gen_golden.py gen_projector -> tests/golden/f12_projector_*.npz): same proposals, same candidates, same
+np.random seed -> the same projected labels at every step, the same blocked-edge table and correction counter."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures as fx
+from semantically_consistent_graph_generation_amd import projector as PJ
+from semantically_consistent_graph_generation_amd.placeholder import PlaceHolder
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASES = [("cow", PJ.CoWProjector), ("cow_vanilla", PJ.CoWVanillaProjector), ("atm", PJ.ATMTreeProjector),
+         ("atm_vanilla", PJ.ATMVanillaTreeProjector), ("tree", PJ.TreeProjector)]
+
+
+def _holder(lab, cd, mask, C):
+    B, n = mask.shape
+    return PlaceHolder(X=mask[..., None].float(), E=fx.one_hot_edges(lab, mask, C), y=torch.zeros(B, 0), node_mask=mask,
+                       pos=torch.zeros(B, n, 3), extra_info=cd)
+
+
+def _blocked(proj, shape):
+    out = np.zeros(shape, dtype=bool)
+    for b, d in proj.blocked_edges.items():
+        for (i, j), v in d.items():
+            out[b, i, j] = v
+    return out
+
+
+@pytest.mark.parametrize("name,cls", CASES)
+def test_projector_matches_reference_trajectory(name, cls):
+    g = np.load(os.path.join(GOLD, f"f12_projector_{name}.npz"))
+    mask, C = torch.from_numpy(g["node_mask"]), int(g["C"])
+    props, cands, want = g["props"], g["cands"], g["out_labels"]
+    B, n = mask.shape
+    np.random.seed(int(g["seed"]))
+    z = torch.zeros(B, n, n, dtype=torch.long)
+    proj = cls(_holder(z, None, mask, C), torch.device("cpu"))
+    for s in range(props.shape[0]):
+        raw = torch.where(z == 0, torch.from_numpy(props[s]).long(), z)
+        z_s = _holder(raw, torch.from_numpy(cands[s]).long(), mask, C)
+        proj.project(z_s)
+        z = torch.argmax(z_s.E, dim=3) * (z_s.E.sum(-1) > 0)
+        assert np.array_equal(z.numpy(), want[s]), f"{name}: step {s} differs"
+        # the reference's own consistency checks (:361-372): stored graph == 0/1 adjacency of z_s
+        for b, gr in enumerate(proj.nx_graphs_list):
+            k = gr.number_of_nodes()
+            assert np.array_equal((z[b, :k, :k] != 0).numpy(), gr.to_numpy_array() != 0)
+    assert np.array_equal(_blocked(proj, g["blocked"].shape), g["blocked"])
+    fixer = getattr(proj, "top_cow_validity_check_and_fix_obj", None)
+    if fixer is not None:
+        assert fixer.counter == int(g["counter"])
+
+
+@pytest.mark.parametrize("name,cls", CASES)
+def test_state_route_equals_placeholder_route(name, cls):
+    """project_labels (int8 state, -1 on padding and diagonal) == project (one-hot) on the same trajectory (CPU tensors)."""
+    g = np.load(os.path.join(GOLD, f"f12_projector_{name}.npz"))
+    mask = torch.from_numpy(g["node_mask"])
+    props, cands, want = g["props"], g["cands"], g["out_labels"]
+    B, n = mask.shape
+    pair = (mask[:, :, None] & mask[:, None, :]) & ~torch.eye(n, dtype=torch.bool)[None]
+    np.random.seed(int(g["seed"]))
+    lab = torch.where(pair, 0, -1).to(torch.int8)
+    z_T = PlaceHolder(X=mask[..., None].float(), E=None, y=torch.zeros(B, 0), node_mask=mask, pos=torch.zeros(B, n, 3))
+    z_T._labels = lab
+    proj = cls(z_T, torch.device("cpu"))
+    for s in range(props.shape[0]):
+        lab = torch.where(lab == 0, torch.from_numpy(props[s]), lab)
+        proj.project_labels(lab, torch.from_numpy(cands[s]))
+        assert np.array_equal(lab.clamp(min=0).numpy(), want[s]), f"{name}: step {s} differs"
+        assert bool((lab[~pair] == -1).all())
+
+
+def test_line_graph_rule_and_forest_rule():
+    allowed = PJ._allowed_masks(PJ.COW_ADJACENCY)
+    g = PJ.LabelGraph(5)
+    g.add_edge(0, 1, 1)
+    g.add_edge(1, 2, 2)           # 1-2 adjacent in the table
+    assert PJ.line_graph_valid(g, allowed)
+    g.add_edge(1, 3, 1)           # same class twice at a node: the diagonal is cleared (:457)
+    assert PJ.line_graph_valid(g, allowed)
+    g.add_edge(2, 4, 13)          # 2-13 not in the table
+    assert not PJ.line_graph_valid(g, allowed)
+    g.add_edge(2, 4, 8)           # relabel in place: 2-8 allowed
+    assert PJ.line_graph_valid(g, allowed) and g.number_of_edges() == 4
+    assert PJ.has_no_cycles(g)
+    g.add_edge(0, 2, 3)
+    assert not PJ.has_no_cycles(g)           # triangle 0-1-2
+    h = g.copy()
+    h.remove_edge(0, 2)
+    assert PJ.has_no_cycles(h) and not PJ.has_no_cycles(g)
+
+
+def test_projector_for_names():
+    assert PJ.projector_for(None) is None and PJ.projector_for("") is None
+    assert PJ.projector_for("cow_proj") is PJ.CoWProjector
+    assert PJ.projector_for("atm_proj_vanilla") is PJ.ATMVanillaTreeProjector
+    assert PJ.projector_for("planar") is PJ.BaseValidProjector
