@@ -167,6 +167,53 @@ int scgg_eigen_features(const float* laplacian, const uint8_t* node_mask, int32_
                         int32_t off_ev, float* evec_feat, int32_t ld_vec, int32_t off_vec, float* w_out, float* v_out,
                         void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Validity projector of the reverse loop (src/ConStruct/projector/projector_3d_utils.py; created at
+ * diffusion_model_discrete_3d.py:636-650 and called once per reverse step at :661).
+ *
+ * Device half.  scgg_new_edges replaces the reference's `(argmax(z_s.E) - z_t_adj).nonzero()` and its per-graph
+ * full-tensor copies to the host (projector_3d_utils.py:259-279): labels_s / labels_t are the int8 states [B,n,n]
+ * (-1 on padding and diagonal), cands int8 [B,n,n,top_k] (NULL with top_k = 0).  An edge is new where
+ * labels_s > labels_t (binary != 0: where it is > 0 and labels_t is not), upper triangle only.  offsets [B+1] int32
+ * receives the exclusive prefix of the per-graph counts (offsets[B] = total m); rec receives m records of
+ * 4 + top_k int32 (graph, i, j, label, candidates...) in (graph, i, j) order -- the order of Tensor.nonzero() --
+ * at most `cap` records are written; status[0] (caller-zeroed) gets bit 0 set when an edge of labels_t is missing
+ * or lowered in labels_s (the reference asserts on that, :261).
+ * scgg_apply_edge_edits writes the host's decisions back: edits int32 [n_edits,4] = (graph, i, j, class), both
+ * (i,j) and (j,i) are set (the reference's in-place z_s.E[...] = one_hot writes, :288-293, :323-324, :340-355). */
+int scgg_new_edges(const int8_t* labels_s, const int8_t* labels_t, const int8_t* cands, int32_t B, int32_t n, int32_t top_k,
+                   int32_t binary, int32_t* offsets, int32_t* rec, int64_t cap, int32_t* status, void* stream);
+int scgg_apply_edge_edits(int8_t* labels, const int32_t* edits, int64_t n_edits, int32_t B, int32_t n, void* stream);
+
+/* Host half (all pointers are HOST pointers; no GPU work).  One object per batch, as the reference's projector
+ * objects: it owns every sample's graph and its blocked-edge table.
+ *   kind: SCGG_PROJ_COW = CoWProjector (:213-387), SCGG_PROJ_COW_VANILLA = CoWVanillaProjector (:464-598),
+ *         SCGG_PROJ_ATM = ATMTreeProjector (:662-840), SCGG_PROJ_ATM_VANILLA = ATMVanillaTreeProjector (:917-1052),
+ *         SCGG_PROJ_TREE = TreeProjector (:157-164 over AbstractProjector :16-147).
+ * A reverse step is begin + finish because the reference shuffles the new edges of every graph that falls back to
+ * one-by-one insertion with np.random.shuffle (:330, :555, :112), i.e. from a random stream the CALLER owns:
+ *   scgg_projector_begin   rec = the m records of scgg_new_edges (copied to the host).  Deletes edges blocked in
+ *                          earlier steps, tries all new edges of a graph at once, and lists in fb_graph / fb_count
+ *                          (capacity B each) the graphs that need the fallback and how many edges each has;
+ *   scgg_projector_finish  perm = for each listed graph, in order, a permutation of 0..fb_count-1 (what
+ *                          np.random.shuffle(arange(fb_count)) gives; position k takes edge perm[k] but keeps the
+ *                          k-th label and candidates, as the reference does), n_perm = sum of fb_count.  Writes the
+ *                          step's edits (graph, i, j, class; class 0 = edge deleted; one entry per pair, the last
+ *                          write of the reference's sequence) to edits_out (capacity edits_cap rows; m is enough).
+ * scgg_projector_export copies graph b's class matrix [n_b,n_b] (the reference's nx_graphs_list[b]) and its
+ * blocked table [n_b,n_b] (blocked_edges[b], upper triangle); scgg_projector_counter is
+ * top_cow_validity_check_and_fix_obj.counter (:411-413). */
+typedef struct scgg_projector scgg_projector;
+enum { SCGG_PROJ_COW = 0, SCGG_PROJ_COW_VANILLA = 1, SCGG_PROJ_ATM = 2, SCGG_PROJ_ATM_VANILLA = 3, SCGG_PROJ_TREE = 4 };
+int scgg_projector_create(int32_t kind, int32_t B, const int32_t* n_nodes_host, scgg_projector** out);
+void scgg_projector_destroy(scgg_projector* p);
+int scgg_projector_begin(scgg_projector* p, int64_t m, const int32_t* rec_host, int32_t top_k, int32_t* fb_graph_host,
+                         int32_t* fb_count_host, int32_t* n_fb_host);
+int scgg_projector_finish(scgg_projector* p, const int32_t* perm_host, int64_t n_perm, int32_t* edits_out_host,
+                          int64_t edits_cap, int64_t* n_edits_host);
+int scgg_projector_export(const scgg_projector* p, int32_t b, int8_t* graph_labels_host, uint8_t* blocked_host);
+int64_t scgg_projector_counter(const scgg_projector* p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,14 @@ SIGNATURES = {
     "scgg_onehot_to_labels": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "scgg_adjacency_features": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp,
                                           _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "scgg_new_edges": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
+    "scgg_apply_edge_edits": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "scgg_projector_create": (C.c_int, [_i32, _i32, _vp, C.POINTER(_vp)]),
+    "scgg_projector_destroy": (None, [_vp]),
+    "scgg_projector_begin": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, C.POINTER(_i32)]),
+    "scgg_projector_finish": (C.c_int, [_vp, _vp, _i64, _vp, _i64, C.POINTER(_i64)]),
+    "scgg_projector_export": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "scgg_projector_counter": (_i64, [_vp]),
     "scgg_laplacian": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "scgg_eigen_features": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
 }

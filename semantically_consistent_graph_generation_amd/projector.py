@@ -29,6 +29,8 @@ The reference's behaviour is kept where it is surprising (each is covered by the
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -173,7 +175,18 @@ class _Fixer:
         self.allowed = _allowed_masks(table)
         self.valid_adjacency = torch.as_tensor(table)
         self.counted = counted
-        self.counter = 0
+        self._count = 0
+        self._owner = None             # set by a projector whose engine is native: the count lives in libscgg.so
+
+    @property
+    def counter(self):
+        if self._owner is not None and self._owner._native is not None:
+            return int(_lib.lib().scgg_projector_counter(self._owner._native))
+        return self._count
+
+    @counter.setter
+    def counter(self, v):
+        self._count = v
 
     def is_line_graph_valid(self, g: LabelGraph) -> bool:
         return line_graph_valid(g, self.allowed)
@@ -213,13 +226,20 @@ def _adj_of(z, binary: bool) -> torch.Tensor:
 
 
 class _Projector:
-    """Shared driver: device-side diff and write-back around the per-graph host routine of the subclass."""
+    """Shared driver.  ``engine="native"`` (default): the per-graph work runs in libscgg.so (csrc/projector_host.hip,
+    scgg_projector_*), the new edges of a device state are compacted by scgg_new_edges and the edits go back through
+    scgg_apply_edge_edits.  ``engine="python"``: the same algorithm on the ``LabelGraph`` classes of this module (the
+    readable restatement the tests hold the native engine against)."""
 
     binary = False           # TreeProjector compares 0/1 adjacency (:59-62), the others the class labels
     uses_cands = False
     can_block_edges = True
+    kind = None              # SCGG_PROJ_* of include/scgg.h
 
-    def __init__(self, z_t, device=None):
+    def __init__(self, z_t, device=None, engine="native"):
+        if engine not in ("native", "python"):
+            raise ValueError(f"engine {engine!r}")
+        self.engine = engine
         self.batch_size = z_t.X.shape[0]
         self.device = torch.device(device) if device is not None else z_t.X.device
         if getattr(z_t, "E", None) is not None:
@@ -227,14 +247,61 @@ class _Projector:
         else:                                  # our sampler's z_T without the one-hot: int8 labels, -1 = zero row
             self.z_t_adj = z_t._labels.clone()
         assert bool((self.z_t_adj <= 0).all()), "the limit distribution has no edges"            # :234 / :37
-        n_nodes = z_t.node_mask.sum(dim=1).tolist()
-        self.nx_graphs_list = [LabelGraph(int(k)) for k in n_nodes]
-        for g in self.nx_graphs_list:
-            assert self._valid_empty(g)
-        self.blocked_edges = {b: {(i, j): False for i in range(int(k)) for j in range(i + 1, int(k))}
-                              for b, k in enumerate(n_nodes)}
+        self._n_nodes = [int(k) for k in z_t.node_mask.sum(dim=1).tolist()]
+        self._native = None
+        self._dev_buf = None
+        if engine == "native":
+            L = _lib.lib()
+            nn_ = np.asarray(self._n_nodes, dtype=np.int32)
+            h = C.c_void_p()
+            _lib.check(L.scgg_projector_create(self.kind, self.batch_size, nn_.ctypes.data, C.byref(h)), "projector_create")
+            self._native = h
+            self._fb_graph = np.empty(max(self.batch_size, 1), dtype=np.int32)
+            self._fb_count = np.empty(max(self.batch_size, 1), dtype=np.int32)
+        else:
+            self._graphs = [LabelGraph(k) for k in self._n_nodes]
+            for g in self._graphs:
+                assert self._valid_empty(g)
+            self._blocked = {b: {(i, j): False for i in range(k) for j in range(i + 1, k)}
+                             for b, k in enumerate(self._n_nodes)}
 
-    # ---- per-class pieces -----------------------------------------------------------------------------------
+    def __del__(self):
+        h, self._native = getattr(self, "_native", None), None
+        if h:
+            _lib.lib().scgg_projector_destroy(h)
+
+    # ---- the reference's attributes ---------------------------------------------------------------------------
+    def _export(self, b):
+        k = self._n_nodes[b]
+        lab, blk = np.zeros((k, k), dtype=np.int8), np.zeros((k, k), dtype=np.uint8)
+        _lib.check(_lib.lib().scgg_projector_export(self._native, b, lab.ctypes.data, blk.ctypes.data), "projector_export")
+        return lab, blk
+
+    @property
+    def nx_graphs_list(self):
+        """The stored graph of every sample (the reference keeps nx.Graph objects; here ``LabelGraph``)."""
+        if self._native is None:
+            return self._graphs
+        out = []
+        for b, k in enumerate(self._n_nodes):
+            lab, _ = self._export(b)
+            g = LabelGraph(k)
+            for i, j in zip(*np.nonzero(np.triu(lab, 1))):
+                g.add_edge(int(i), int(j), None if self.binary else int(lab[i, j]))
+            out.append(g)
+        return out
+
+    @property
+    def blocked_edges(self):
+        if self._native is None:
+            return self._blocked
+        out = {}
+        for b, k in enumerate(self._n_nodes):
+            _, blk = self._export(b)
+            out[b] = {(i, j): bool(blk[i, j]) for i in range(k) for j in range(i + 1, k)}
+        return out
+
+    # ---- per-class pieces (python engine) -----------------------------------------------------------------------
     def _valid_empty(self, g) -> bool:
         return True
 
@@ -249,65 +316,119 @@ class _Projector:
         assert bool((diff >= 0).all()), "Once unmasked, the edges cannot be removed."
         new = diff.nonzero(as_tuple=False)
         new = new[new[:, 1] < new[:, 2]]
-        attrs = z_s_adj[new[:, 0], new[:, 1], new[:, 2]]
-        cands = None
+        rec = [new, z_s_adj[new[:, 0], new[:, 1], new[:, 2]][:, None]]
         if self.uses_cands:
-            cands = z_s.extra_info[new[:, 0], new[:, 1], new[:, 2]].cpu().numpy()
-        edits = self._run(new.cpu().numpy(), attrs.cpu().numpy(), cands)
-        if edits:
-            C = z_s.E.shape[-1]
-            e = torch.as_tensor(edits, dtype=torch.long, device=z_s.E.device)
-            rows = torch.nn.functional.one_hot(e[:, 3], C).to(z_s.E.dtype)
+            rec.append(z_s.extra_info[new[:, 0], new[:, 1], new[:, 2]].long())
+        edits = self._run(torch.cat(rec, dim=1).to(torch.int32).cpu().numpy())
+        if len(edits):
+            e = torch.from_numpy(edits).long().to(z_s.E.device)
+            rows = torch.nn.functional.one_hot(e[:, 3], z_s.E.shape[-1]).to(z_s.E.dtype)
             z_s.E[e[:, 0], e[:, 1], e[:, 2]] = rows
             z_s.E[e[:, 0], e[:, 2], e[:, 1]] = rows
         self.z_t_adj = _adj_of(z_s, self.binary)
 
     # ---- state route ----------------------------------------------------------------------------------------
     def project_labels(self, labels: torch.Tensor, cands: torch.Tensor = None):
-        """Same step on the int8 state of ``Sampler.sample_batch``: labels [B,n,n] (padding/diagonal 0 or -1 are never
-        new edges), cands [B,n,n,k] int8.  Edits ``labels`` in place; returns the number of edited pairs."""
+        """Same step on the int8 state of ``Sampler.sample_batch``: labels [B,n,n] (-1 on padding and diagonal; never a
+        new edge), cands [B,n,n,k] int8.  Edits ``labels`` in place; returns the number of edited pairs."""
         if self.uses_cands and cands is None:
             raise _lib.ScggError(f"{type(self).__name__}.project_labels needs the top-k candidates")
-        prev = self.z_t_adj if self.z_t_adj.dtype == labels.dtype else self.z_t_adj.to(labels.dtype)
+        if labels.dtype != torch.int8 or labels.dim() != 3 or not labels.is_contiguous():
+            raise _lib.ScggError("project_labels: labels must be a contiguous int8 [B,n,n] tensor")
+        if labels.is_cuda:
+            return self._project_labels_device(labels, cands if self.uses_cands else None)
+        prev = self.z_t_adj.to(labels.dtype)                     # host tensors: same step with torch ops
         if self.binary:
-            changed = (labels > 0) & ~(prev > 0)
-            assert not bool(((prev > 0) & ~(labels > 0)).any()), "Once unmasked, the edges cannot be removed."
+            changed, lost = (labels > 0) & ~(prev > 0), (prev > 0) & ~(labels > 0)
         else:
-            changed = labels > prev
-            assert not bool((labels < prev).any()), "Once unmasked, the edges cannot be removed."
+            changed, lost = labels > prev, labels < prev
+        assert not bool(lost.any()), "Once unmasked, the edges cannot be removed."
         new = changed.triu(1).nonzero(as_tuple=False)
-        attrs = labels[new[:, 0], new[:, 1], new[:, 2]].long()
-        rec = [new, attrs[:, None]]
+        rec = [new, labels[new[:, 0], new[:, 1], new[:, 2]].long()[:, None]]
         if self.uses_cands:
             rec.append(cands[new[:, 0], new[:, 1], new[:, 2]].long())
-        rec = torch.cat(rec, dim=1).cpu().numpy()                 # the one device -> host copy of the step
-        edits = self._run(rec[:, :3], rec[:, 3], rec[:, 4:] if self.uses_cands else None)
-        if edits:
-            e = torch.as_tensor(edits, dtype=torch.long, device=labels.device)
+        edits = self._run(torch.cat(rec, dim=1).to(torch.int32).numpy())
+        if len(edits):
+            e = torch.from_numpy(edits).long()
             v = e[:, 3].to(labels.dtype)
             labels[e[:, 0], e[:, 1], e[:, 2]] = v
             labels[e[:, 0], e[:, 2], e[:, 1]] = v
         self.z_t_adj = labels.clone()
         return len(edits)
 
+    def _project_labels_device(self, labels, cands):
+        L = _lib.lib()
+        B, n, _ = labels.shape
+        k = cands.shape[-1] if cands is not None else 0
+        if cands is not None and (cands.dtype != torch.int8 or not cands.is_contiguous() or cands.shape[:3] != labels.shape):
+            raise _lib.ScggError("project_labels: cands must be a contiguous int8 [B,n,n,k] tensor")
+        buf = self._dev_buf
+        if buf is None or buf["key"] != (B, n, k, labels.device):
+            cap = B * (n * (n - 1) // 2)                         # every pair of every graph new at once
+            buf = self._dev_buf = dict(key=(B, n, k, labels.device), cap=cap,
+                                       meta=torch.zeros(B + 2, dtype=torch.int32, device=labels.device),
+                                       rec=torch.empty(max(cap, 1), 4 + k, dtype=torch.int32, device=labels.device),
+                                       prev=self.z_t_adj.to(device=labels.device, dtype=torch.int8).contiguous())
+        meta, rec, prev = buf["meta"], buf["rec"], buf["prev"]
+        meta[B + 1] = 0
+        st = _lib.stream_ptr()
+        status_ptr = C.c_void_p(meta.data_ptr() + 4 * (B + 1))
+        _lib.check(L.scgg_new_edges(_lib.ptr(labels), _lib.ptr(prev), _lib.ptr(cands), B, n, k, int(self.binary),
+                                    _lib.ptr(meta), _lib.ptr(rec), buf["cap"], status_ptr, st), "new_edges")
+        m, status = meta[B:].tolist()                            # sync 1: how many records
+        assert status == 0, "Once unmasked, the edges cannot be removed."
+        edits = self._run(rec[:m].cpu().numpy() if m else np.zeros((0, 4 + k), dtype=np.int32))      # sync 2: the records
+        if len(edits):
+            e = torch.from_numpy(edits).to(labels.device)
+            _lib.check(L.scgg_apply_edge_edits(_lib.ptr(labels), _lib.ptr(e), len(edits), B, n, st), "apply_edge_edits")
+            e.record_stream(torch.cuda.current_stream())
+        prev.copy_(labels)
+        self.z_t_adj = prev
+        return len(edits)
+
     # ---- host part ------------------------------------------------------------------------------------------
-    def _run(self, new, attrs, cands):
-        """new [m,3] (b,i,j) in row-major order with i<j.  Returns the edits [(b,i,j,label)], last write per pair."""
+    def _run(self, rec: np.ndarray) -> np.ndarray:
+        """rec int32 [m, 4+k]: (graph, i, j, label, candidates...) sorted by (graph, i, j), i < j.
+        Returns the step's edits int32 [e, 4] = (graph, i, j, class), one per pair (the reference's last write)."""
+        rec = np.ascontiguousarray(rec, dtype=np.int32)
+        m, k = rec.shape[0], rec.shape[1] - 4
+        if self._native is not None:
+            L = _lib.lib()
+            n_fb = C.c_int32(0)
+            _lib.check(L.scgg_projector_begin(self._native, m, rec.ctypes.data, k, self._fb_graph.ctypes.data,
+                                              self._fb_count.ctypes.data, C.byref(n_fb)), "projector_begin")
+            counts = self._fb_count[:n_fb.value]
+            perm = np.empty(int(counts.sum()), dtype=np.int32)
+            off = 0
+            for c in counts.tolist():                # np.random.shuffle of the reference, in graph order (:330)
+                perm[off:off + c] = np.arange(c, dtype=np.int32)
+                if c > 1:                            # a 1-element shuffle draws nothing from the stream
+                    self._shuffle(perm[off:off + c])
+                off += c
+            out = np.empty((max(m, 1), 4), dtype=np.int32)
+            ne = C.c_int64(0)
+            _lib.check(L.scgg_projector_finish(self._native, perm.ctypes.data, perm.size, out.ctypes.data, out.shape[0],
+                                               C.byref(ne)), "projector_finish")
+            return out[:ne.value]
         edits = []
-        if len(new):
-            starts = np.searchsorted(new[:, 0], np.arange(self.batch_size + 1))
-        for b in range(self.batch_size):
-            lo, hi = (starts[b], starts[b + 1]) if len(new) else (0, 0)
-            if hi > lo:
-                self._project_graph(b, new[lo:hi, 1:], attrs[lo:hi], cands[lo:hi] if cands is not None else None, edits)
+        if m:
+            starts = np.searchsorted(rec[:, 0], np.arange(self.batch_size + 1))
+            for b in range(self.batch_size):
+                lo, hi = starts[b], starts[b + 1]
+                if hi > lo:
+                    self._project_graph(b, rec[lo:hi, 1:3], rec[lo:hi, 3], rec[lo:hi, 4:] if k else None, edits)
         last = {}
         for b, u, v, c in edits:
             last[(int(b), int(u), int(v))] = int(c)
-        return [(b, u, v, c) for (b, u, v), c in last.items()]
+        return np.asarray([(b, u, v, c) for (b, u, v), c in last.items()], dtype=np.int32).reshape(-1, 4)
+
+    @staticmethod
+    def _shuffle(x):
+        np.random.shuffle(x)
 
     def _drop_blocked(self, b, edges, edits):
         """:282-301: an edge blocked in an earlier step is deleted again at once; returns the indices kept."""
-        blocked = self.blocked_edges[b]
+        blocked = self._blocked[b]
         keep = []
         for idx, (u, v) in enumerate(edges):
             if blocked[(int(u), int(v))]:
@@ -332,7 +453,7 @@ class _FixingProjector(_Projector):
         return self._try(g)
 
     def _project_graph(self, b, edges, attrs, cands, edits):
-        g = self.nx_graphs_list[b]
+        g = self._graphs[b]
         old = g.copy()
         keep = self._drop_blocked(b, edges, edits)
         if not keep:
@@ -353,14 +474,11 @@ class _FixingProjector(_Projector):
                 if not self._try(g):
                     g = old
                     edits.append((b, u, v, 0))
-                    self.blocked_edges[b][(u, v)] = True
+                    self._blocked[b][(u, v)] = True
                 else:
                     edits.append((b, u, v, g.label(u, v)))
-            self.nx_graphs_list[b] = g
+            self._graphs[b] = g
 
-    @staticmethod
-    def _shuffle(edges):
-        np.random.shuffle(edges)
 
 
 class _VanillaProjector(_Projector):
@@ -373,7 +491,7 @@ class _VanillaProjector(_Projector):
         return self.valid_graph_fn(g)
 
     def _project_graph(self, b, edges, attrs, cands, edits):
-        g = self.nx_graphs_list[b]
+        g = self._graphs[b]
         old = g.copy()
         keep = self._drop_blocked(b, edges, edits)
         if not keep:
@@ -384,7 +502,7 @@ class _VanillaProjector(_Projector):
                 g.add_edge(int(u), int(v), self._label(label))
         if not self.valid_graph_fn(g) or len(edges) == 1:
             g = old
-            np.random.shuffle(edges)
+            self._shuffle(edges)
             for (u, v), label in zip(edges, attrs):
                 u, v = int(u), int(v)
                 old = g.copy()
@@ -392,8 +510,8 @@ class _VanillaProjector(_Projector):
                 if not self.valid_graph_fn(g):
                     g = old
                     edits.append((b, u, v, 0))
-                    self.blocked_edges[b][(u, v)] = True
-            self.nx_graphs_list[b] = g
+                    self._blocked[b][(u, v)] = True
+            self._graphs[b] = g
 
     @staticmethod
     def _label(label):
@@ -403,9 +521,12 @@ class _VanillaProjector(_Projector):
 class CoWProjector(_FixingProjector):
     """:213-387 -- TopCoW class adjacency with repair from the top-k candidates."""
 
-    def __init__(self, z_t, device=None):
+    kind = 0
+
+    def __init__(self, z_t, device=None, engine="native"):
         self.top_cow_validity_check_and_fix_obj = _Fixer(COW_ADJACENCY, counted=True)
-        super().__init__(z_t, device)
+        self.top_cow_validity_check_and_fix_obj._owner = self
+        super().__init__(z_t, device, engine)
 
     def _try(self, g):
         return self.top_cow_validity_check_and_fix_obj.check_validity_and_fix_if_needed(g)
@@ -414,9 +535,12 @@ class CoWProjector(_FixingProjector):
 class ATMTreeProjector(_FixingProjector):
     """:662-840 -- ATM generation adjacency with repair, and no cycles."""
 
-    def __init__(self, z_t, device=None):
+    kind = 2
+
+    def __init__(self, z_t, device=None, engine="native"):
         self.atm_validity_check_and_fix_obj = _Fixer(ATM_ADJACENCY, counted=False)
-        super().__init__(z_t, device)
+        self.atm_validity_check_and_fix_obj._owner = self
+        super().__init__(z_t, device, engine)
 
     def _try(self, g):
         return self.atm_validity_check_and_fix_obj.check_validity_and_fix_if_needed(g) and has_no_cycles(g)
@@ -428,9 +552,12 @@ class ATMTreeProjector(_FixingProjector):
 class CoWVanillaProjector(_VanillaProjector):
     """:464-598 -- TopCoW class adjacency, violating edges deleted."""
 
-    def __init__(self, z_t, device=None):
+    kind = 1
+
+    def __init__(self, z_t, device=None, engine="native"):
         self.top_cow_validity_check = _Fixer(COW_ADJACENCY, counted=False)
-        super().__init__(z_t, device)
+        self.top_cow_validity_check._owner = self
+        super().__init__(z_t, device, engine)
 
     def valid_graph_fn(self, g):
         return self.top_cow_validity_check.is_valid_graph(g)
@@ -439,9 +566,12 @@ class CoWVanillaProjector(_VanillaProjector):
 class ATMVanillaTreeProjector(_VanillaProjector):
     """:917-1052 -- ATM generation adjacency and no cycles, violating edges deleted."""
 
-    def __init__(self, z_t, device=None):
+    kind = 3
+
+    def __init__(self, z_t, device=None, engine="native"):
         self.atm_validity_check = _Fixer(ATM_ADJACENCY, counted=False)
-        super().__init__(z_t, device)
+        self.atm_validity_check._owner = self
+        super().__init__(z_t, device, engine)
 
     def valid_graph_fn(self, g):
         return self.atm_validity_check.is_valid_graph(g) and has_no_cycles(g)
@@ -451,9 +581,7 @@ class TreeProjector(_VanillaProjector):
     """:157-164 over AbstractProjector :16-147 -- unlabelled forest constraint on the 0/1 adjacency."""
 
     binary = True
-
-    def __init__(self, z_t, device=None):
-        super().__init__(z_t, device)
+    kind = 4
 
     def valid_graph_fn(self, g):
         return has_no_cycles(g)

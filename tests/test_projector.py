@@ -30,15 +30,16 @@ def _blocked(proj, shape):
     return out
 
 
+@pytest.mark.parametrize("engine", ["native", "python"])
 @pytest.mark.parametrize("name,cls", CASES)
-def test_projector_matches_reference_trajectory(name, cls):
+def test_projector_matches_reference_trajectory(name, cls, engine):
     g = np.load(os.path.join(GOLD, f"f12_projector_{name}.npz"))
     mask, C = torch.from_numpy(g["node_mask"]), int(g["C"])
     props, cands, want = g["props"], g["cands"], g["out_labels"]
     B, n = mask.shape
     np.random.seed(int(g["seed"]))
     z = torch.zeros(B, n, n, dtype=torch.long)
-    proj = cls(_holder(z, None, mask, C), torch.device("cpu"))
+    proj = cls(_holder(z, None, mask, C), torch.device("cpu"), engine=engine)
     for s in range(props.shape[0]):
         raw = torch.where(z == 0, torch.from_numpy(props[s]).long(), z)
         z_s = _holder(raw, torch.from_numpy(cands[s]).long(), mask, C)
@@ -55,8 +56,9 @@ def test_projector_matches_reference_trajectory(name, cls):
         assert fixer.counter == int(g["counter"])
 
 
+@pytest.mark.parametrize("engine", ["native", "python"])
 @pytest.mark.parametrize("name,cls", CASES)
-def test_state_route_equals_placeholder_route(name, cls):
+def test_state_route_equals_placeholder_route(name, cls, engine):
     """project_labels (int8 state, -1 on padding and diagonal) == project (one-hot) on the same trajectory (CPU tensors)."""
     g = np.load(os.path.join(GOLD, f"f12_projector_{name}.npz"))
     mask = torch.from_numpy(g["node_mask"])
@@ -67,7 +69,7 @@ def test_state_route_equals_placeholder_route(name, cls):
     lab = torch.where(pair, 0, -1).to(torch.int8)
     z_T = PlaceHolder(X=mask[..., None].float(), E=None, y=torch.zeros(B, 0), node_mask=mask, pos=torch.zeros(B, n, 3))
     z_T._labels = lab
-    proj = cls(z_T, torch.device("cpu"))
+    proj = cls(z_T, torch.device("cpu"), engine=engine)
     for s in range(props.shape[0]):
         lab = torch.where(lab == 0, torch.from_numpy(props[s]), lab)
         proj.project_labels(lab, torch.from_numpy(cands[s]))
@@ -100,3 +102,41 @@ def test_projector_for_names():
     assert PJ.projector_for("cow_proj") is PJ.CoWProjector
     assert PJ.projector_for("atm_proj_vanilla") is PJ.ATMVanillaTreeProjector
     assert PJ.projector_for("planar") is PJ.BaseValidProjector
+
+
+def test_native_projector_rejects_bad_input_without_side_effects():
+    import ctypes as C
+    from semantically_consistent_graph_generation_amd import _lib
+    L = _lib.lib()
+    nn_ = np.asarray([5, 4], dtype=np.int32)
+    h = C.c_void_p()
+    assert L.scgg_projector_create(99, 2, nn_.ctypes.data, C.byref(h)) != 0
+    assert L.scgg_projector_create(0, 2, nn_.ctypes.data, C.byref(h)) == 0
+    fbg, fbc, nfb = np.zeros(2, np.int32), np.zeros(2, np.int32), C.c_int32(0)
+
+    def begin(rows, k=4):
+        rec = np.asarray(rows, dtype=np.int32).reshape(-1, 4 + k)
+        return L.scgg_projector_begin(h, rec.shape[0], rec.ctypes.data, k, fbg.ctypes.data, fbc.ctypes.data, C.byref(nfb))
+    good = [0, 0, 1, 1, 1, 2, 3, 0]
+    assert begin([good, [0, 0, 1, 2, 1, 2, 3, 0]]) != 0 and b"sorted" in L.scgg_last_error()        # repeated pair
+    assert begin([[0, 1, 0, 1, 1, 2, 3, 0]]) != 0                                                    # i >= j
+    assert begin([[1, 0, 4, 1, 1, 2, 3, 0]]) != 0                                                    # node outside the graph
+    assert begin([[0, 0, 1, 14, 1, 2, 3, 0]]) != 0 and b"validity table" in L.scgg_last_error()     # class 14
+    assert begin([[0, 0, 1, 1]], k=0) != 0                                                           # repairs need candidates
+    assert begin([good, [1, 0, 1, 1, 1, 2, 3, 0], [1, 0, 2, 13, 0, 0, 0, 0]]) == 0
+    assert nfb.value == 2 and fbg.tolist() == [0, 1] and fbc.tolist() == [1, 2]      # 1 edge -> one by one; 1-13 clash, no repair
+    assert begin([good]) != 0 and b"not finished" in L.scgg_last_error()
+    out, ne = np.zeros((3, 4), np.int32), C.c_int64(0)
+    bad = np.asarray([0, 1, 1], dtype=np.int32)
+    assert L.scgg_projector_finish(h, bad.ctypes.data, 3, out.ctypes.data, 3, C.byref(ne)) != 0       # not a permutation
+    assert L.scgg_projector_finish(h, bad.ctypes.data, 2, out.ctypes.data, 3, C.byref(ne)) != 0       # wrong length
+    perm = np.asarray([0, 0, 1], dtype=np.int32)           # identity for both graphs
+    assert L.scgg_projector_finish(h, perm.ctypes.data, 3, out.ctypes.data, 3, C.byref(ne)) == 0
+    got = {tuple(r) for r in out[:ne.value].tolist()}
+    # graph 0 keeps (0,1)=1; graph 1: (0,1)=1 enters first, then (0,2)=13 clashes with it, no candidate -> deleted and blocked
+    assert got == {(0, 0, 1, 1), (1, 0, 1, 1), (1, 0, 2, 0)}
+    blk = np.zeros((4, 4), np.uint8)
+    lab = np.zeros((4, 4), np.int8)
+    assert L.scgg_projector_export(h, 1, lab.ctypes.data, blk.ctypes.data) == 0
+    assert blk[0, 2] == 1 and blk.sum() == 1 and lab[0, 1] == 1 and lab[1, 0] == 1 and lab.astype(bool).sum() == 2
+    L.scgg_projector_destroy(h)
