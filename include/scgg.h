@@ -177,7 +177,7 @@ int scgg_eigen_features(const float* laplacian, const uint8_t* node_mask, int32_
  * labels_s > labels_t (binary != 0: where it is > 0 and labels_t is not), upper triangle only.  offsets [B+1] int32
  * receives the exclusive prefix of the per-graph counts (offsets[B] = total m); rec receives m records of
  * 4 + top_k int32 (graph, i, j, label, candidates...) in (graph, i, j) order -- the order of Tensor.nonzero() --
- * at most `cap` records are written; status[0] (caller-zeroed) gets bit 0 set when an edge of labels_t is missing
+ * at most `cap` records are written; status[0] is cleared and then gets bit 0 set when an edge of labels_t is missing
  * or lowered in labels_s (the reference asserts on that, :261).
  * scgg_apply_edge_edits writes the host's decisions back: edits int32 [n_edits,4] = (graph, i, j, class), both
  * (i,j) and (j,i) are set (the reference's in-place z_s.E[...] = one_hot writes, :288-293, :323-324, :340-355). */

@@ -107,9 +107,11 @@ struct NewEdge {
   int8_t cands[MAX_TOPK];
 };
 
+// A graph that falls back to one-by-one insertion.  Its stored graph is back in the state before the step (a new
+// edge sits on a pair that had no edge, so the reference's "nx_graph = old_nx_graph" is undone by removing the
+// step's edges again: no copies of the graph are kept).
 struct Fallback {
   int b;
-  Graph old;
   std::vector<NewEdge> edges;      // the unblocked new edges of graph b, in row-major order
 };
 
@@ -233,6 +235,10 @@ int scgg_projector_begin(scgg_projector* p, int64_t m, const int32_t* rec, int32
     if (b < prev_b || (b == prev_b && (u < prev_u || (u == prev_u && v <= prev_v))))
       return fail("scgg_projector_begin: records must be sorted by (graph, i, j) without repeats");
     prev_b = b; prev_u = u; prev_v = v;
+    // a class change on a stored edge (possible only outside the absorbing process; the reference would relabel it)
+    // is refused: the undo below relies on new edges sitting on empty pairs
+    if (p->graphs[b].lab[(size_t)u * n + v])
+      return fail("scgg_projector_begin: record %lld: pair (%d,%d) of graph %d already holds an edge", (long long)k, u, v, b);
     // the reference indexes its table with class-1 and fails on a class outside it
     if (p->table && (c < 1 || c >= p->n_cls)) return fail("edge class %d outside the validity table (1..%d)", c, p->n_cls - 1);
     if (!p->table && c < 1) return fail("scgg_projector_begin: record %lld: class %d is not an edge", (long long)k, c);
@@ -261,12 +267,8 @@ int scgg_projector_begin(scgg_projector* p, int64_t m, const int32_t* rec, int32
     lo = hi;
     if (keep.empty()) continue;
     const int mk = (int)keep.size();
-    bool fallback;
-    if (mk == 1) {
-      fallback = true;                       // :327 / :552 / :106 (the graph is untouched so far)
-      p->pending.push_back({b, g, keep});
-    } else {
-      Graph old = g;
+    bool fallback = true;                    // one edge: straight to one by one, :327 / :552 / :106 (graph untouched)
+    if (mk > 1) {
       if (p->fixing) {
         if (p->try_fix(g, keep.data(), mk))  // :318-324: labels may have been repaired
           for (const NewEdge& e : keep) p->edits.push_back({b, e.u, e.v, g.lab[(size_t)e.u * g.n + e.v]});
@@ -275,8 +277,10 @@ int scgg_projector_begin(scgg_projector* p, int64_t m, const int32_t* rec, int32
         for (const NewEdge& e : keep) g.add(e.u, e.v, e.label);
         fallback = !p->valid_fn(g);
       }
-      if (fallback) p->pending.push_back({b, std::move(old), keep});
+      if (fallback)
+        for (const NewEdge& e : keep) g.remove(e.u, e.v);      // nx_graph = old_nx_graph
     }
+    if (fallback) p->pending.push_back({b, keep});
     if (fallback) {
       fb_graph[*n_fb] = b;
       fb_count[*n_fb] = mk;
@@ -306,7 +310,7 @@ int scgg_projector_finish(scgg_projector* p, const int32_t* perm, int64_t n_perm
   off = 0;
   for (Fallback& f : p->pending) {
     const int b = f.b, mk = (int)f.edges.size();
-    Graph g = std::move(f.old);
+    Graph& g = p->graphs[b];
     std::vector<uint8_t>& blocked = p->blocked[b];
     for (int k = 0; k < mk; ++k) {
       // np.random.shuffle(edges_to_add) moved the edges only: position k holds edge perm[k] but still the k-th
@@ -314,7 +318,6 @@ int scgg_projector_finish(scgg_projector* p, const int32_t* perm, int64_t n_perm
       NewEdge e = f.edges[k];
       e.u = f.edges[perm[off + k]].u;
       e.v = f.edges[perm[off + k]].v;
-      Graph old = g;
       bool ok;
       if (p->fixing) {
         ok = p->try_fix(g, &e, 1);
@@ -323,14 +326,13 @@ int scgg_projector_finish(scgg_projector* p, const int32_t* perm, int64_t n_perm
         ok = p->valid_fn(g);
       }
       if (!ok) {
-        g = std::move(old);
+        g.remove(e.u, e.v);                              // nx_graph = old_nx_graph
         p->edits.push_back({b, e.u, e.v, 0});
         blocked[(size_t)e.u * g.n + e.v] = 1;            // :349 blocked for the rest of the chain
       } else if (p->fixing) {
         p->edits.push_back({b, e.u, e.v, g.lab[(size_t)e.u * g.n + e.v]});      // :353-355
       }
     }
-    p->graphs[b] = std::move(g);
     off += mk;
   }
   p->pending.clear();

@@ -124,6 +124,7 @@ int scgg_new_edges(const int8_t* labels_s, const int8_t* labels_t, const int8_t*
   if (top_k < 0 || (top_k > 0 && !cands)) return fail("new_edges: top_k=%d needs the candidate tensor", top_k);
   if ((long long)n * n > 0x7fffffffll / 2) return fail("new_edges: n=%d is too large", n);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(status, 0, sizeof(int32_t), st) != hipSuccess) return fail("new_edges: clearing the status word failed");
   hipLaunchKernelGGL(new_edges_count_kernel, dim3(B), dim3(T), 0, st, labels_s, labels_t, n, binary, offsets, status);
   hipLaunchKernelGGL(new_edges_scan_kernel, dim3(1), dim3(T), 0, st, offsets, B);
   hipLaunchKernelGGL(new_edges_fill_kernel, dim3(B), dim3(T), 0, st, labels_s, labels_t, cands, n, top_k, binary, offsets, rec,

@@ -370,7 +370,6 @@ class _Projector:
                                        rec=torch.empty(max(cap, 1), 4 + k, dtype=torch.int32, device=labels.device),
                                        prev=self.z_t_adj.to(device=labels.device, dtype=torch.int8).contiguous())
         meta, rec, prev = buf["meta"], buf["rec"], buf["prev"]
-        meta[B + 1] = 0
         st = _lib.stream_ptr()
         status_ptr = C.c_void_p(meta.data_ptr() + 4 * (B + 1))
         _lib.check(L.scgg_new_edges(_lib.ptr(labels), _lib.ptr(prev), _lib.ptr(cands), B, n, k, int(self.binary),
@@ -397,14 +396,13 @@ class _Projector:
             n_fb = C.c_int32(0)
             _lib.check(L.scgg_projector_begin(self._native, m, rec.ctypes.data, k, self._fb_graph.ctypes.data,
                                               self._fb_count.ctypes.data, C.byref(n_fb)), "projector_begin")
-            counts = self._fb_count[:n_fb.value]
-            perm = np.empty(int(counts.sum()), dtype=np.int32)
-            off = 0
-            for c in counts.tolist():                # np.random.shuffle of the reference, in graph order (:330)
-                perm[off:off + c] = np.arange(c, dtype=np.int32)
-                if c > 1:                            # a 1-element shuffle draws nothing from the stream
-                    self._shuffle(perm[off:off + c])
-                off += c
+            counts = self._fb_count[:n_fb.value].astype(np.int64)
+            ends = np.cumsum(counts)
+            perm = (np.arange(int(ends[-1]) if len(ends) else 0) - np.repeat(ends - counts, counts)).astype(np.int32)
+            shuffle = self._shuffle
+            for lo, hi in zip((ends - counts)[counts > 1].tolist(), ends[counts > 1].tolist()):
+                shuffle(perm[lo:hi])                 # np.random.shuffle of the reference, in graph order (:330); a
+                                                     # 1-element shuffle draws nothing from the stream and is skipped
             out = np.empty((max(m, 1), 4), dtype=np.int32)
             ne = C.c_int64(0)
             _lib.check(L.scgg_projector_finish(self._native, perm.ctypes.data, perm.size, out.ctypes.data, out.shape[0],
