@@ -28,3 +28,21 @@ for name, proj in cases:
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"{name}: {dt * 1e3 / T:.2f} ms/step, {512 / dt * T / 500:.0f} graphs/s at T=500 rate, edges {int((lab > 0).sum()) // 2}", flush=True)
+
+
+def chain_rng(cls, seed):
+    rs = np.random.RandomState(seed)
+    f = lambda z, d: cls(z, d, rng=rs)
+    f.project_labels = True
+    return f
+
+
+for nb in (2, 3):
+    reqs = [dict(n_nodes=n_nodes, seed=7 + k, n_max=bench.N_MAX, graph_id_base=512 * k, projector=chain_rng(PJ.CoWProjector, k),
+                 return_state=True) for k in range(nb)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sampler.sample_batches(reqs)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"cow_proj, {nb} batches pipelined: {dt * 1e3 / T / nb:.2f} ms/step/batch, {nb * 512 / dt * T / 500:.0f} graphs/s at T=500 rate", flush=True)

@@ -37,22 +37,35 @@ const int ATM_TABLE[4][4] = {{0, 1, 0, 0}, {1, 0, 1, 0}, {0, 1, 0, 1}, {0, 0, 1,
 // One sample's graph: lab[u*n+v] = class of edge {u,v} (0 = none; the unlabelled tree projector stores 1),
 // cnt[u*MAX_CLS+c] = edges of class c at node u, present[u] = bit set of the classes with cnt > 0.
 struct Graph {
-  int n = 0, n_edges = 0;
+  int n = 0, n_edges = 0, n_bad = 0;
+  const uint32_t* allowed = nullptr;   // class adjacency bit sets (nullptr: no class rule)
   std::vector<int8_t> lab;
   std::vector<uint16_t> cnt;
   std::vector<uint32_t> present;
+  std::vector<uint8_t> bad;            // bad[u]: two classes present at node u that the table does not join
 
-  void init(int n_) {
+  void init(int n_, const uint32_t* allowed_) {
     n = n_;
-    n_edges = 0;
+    n_edges = n_bad = 0;
+    allowed = allowed_;
     lab.assign((size_t)n * n, 0);
     cnt.assign((size_t)n * MAX_CLS, 0);
     present.assign(n, 0);
+    bad.assign(n, 0);
   }
   void bump(int u, int c, int d) {
     uint16_t& k = cnt[(size_t)u * MAX_CLS + c];
     k = (uint16_t)(k + d);
     if (k) present[u] |= 1u << c; else present[u] &= ~(1u << c);
+  }
+  void refresh(int u) {                // the class rule is local to a node: only the two end points can change
+    if (!allowed) return;
+    const uint32_t p = present[u];
+    uint8_t b = 0;
+    for (uint32_t q = p; q; q &= q - 1)
+      if (p & ~allowed[__builtin_ctz(q)]) { b = 1; break; }
+    n_bad += (int)b - (int)bad[u];
+    bad[u] = b;
   }
   void add(int u, int v, int c) {          // nx.Graph.add_edge: an existing edge takes the new label
     int8_t old = lab[(size_t)u * n + v];
@@ -60,6 +73,8 @@ struct Graph {
     lab[(size_t)u * n + v] = lab[(size_t)v * n + u] = (int8_t)c;
     bump(u, c, 1);
     bump(v, c, 1);
+    refresh(u);
+    refresh(v);
   }
   void remove(int u, int v) {
     int8_t old = lab[(size_t)u * n + v];
@@ -68,21 +83,16 @@ struct Graph {
     bump(v, old, -1);
     lab[(size_t)u * n + v] = lab[(size_t)v * n + u] = 0;
     --n_edges;
+    refresh(u);
+    refresh(v);
   }
 };
 
 // is_line_graph_valid: two edges are joined in the line graph iff they share a node, so the class pairs it marks are
 // the pairs of classes present at a common node; invalid iff two different classes at one node are not adjacent in
 // the table (the diagonal is cleared, :457).
-bool line_valid(const Graph& g, const uint32_t* allowed) {
-  for (int u = 0; u < g.n; ++u) {
-    uint32_t p = g.present[u];
-    if ((p & (p - 1)) == 0) continue;      // fewer than two classes here
-    for (uint32_t q = p; q; q &= q - 1)
-      if (p & ~allowed[__builtin_ctz(q)]) return false;
-  }
-  return true;
-}
+// Kept per node and updated by add / remove (Graph::refresh), so the test itself is one comparison.
+bool line_valid(const Graph& g) { return g.n_bad == 0; }
 
 bool no_cycles(const Graph& g, std::vector<int>& parent) {      // has_no_cycles :150-154
   if (g.n_edges >= g.n) return false;
@@ -131,7 +141,7 @@ struct scgg_projector {
   std::vector<int> uf;
 
   bool valid_fn(const Graph& g) {          // the vanilla / tree validity functions (:593, :1046, :158)
-    if (table && !line_valid(g, allowed)) return false;
+    if (table && !line_valid(g)) return false;
     return forest ? no_cycles(g, uf) : true;
   }
 
@@ -141,7 +151,7 @@ struct scgg_projector {
     for (int k = 0; k < m; ++k) {
       g.add(e[k].u, e[k].v, e[k].label);
       bool ok = true;
-      if (!line_valid(g, allowed)) {
+      if (!line_valid(g)) {
         ok = false;
         if (counted) --counter;
         for (int c = 0; c < top_k; ++c) {
@@ -150,7 +160,7 @@ struct scgg_projector {
           if (cand == 0) continue;         // class 0 would delete the edge
           g.remove(e[k].u, e[k].v);
           g.add(e[k].u, e[k].v, cand);
-          if (line_valid(g, allowed)) { ok = true; break; }
+          if (line_valid(g)) { ok = true; break; }
         }
       }
       all_ok = all_ok && ok;
@@ -205,7 +215,7 @@ int scgg_projector_create(int32_t kind, int32_t B, const int32_t* n_nodes, scgg_
       delete p;
       return fail("scgg_projector_create: graph %d has no nodes (the forest check is undefined on it)", b);
     }
-    p->graphs[b].init(n_nodes[b]);
+    p->graphs[b].init(n_nodes[b], p->table ? p->allowed : nullptr);
     p->blocked[b].assign((size_t)n_nodes[b] * n_nodes[b], 0);
   }
   *out = p;

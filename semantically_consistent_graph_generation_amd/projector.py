@@ -236,10 +236,11 @@ class _Projector:
     can_block_edges = True
     kind = None              # SCGG_PROJ_* of include/scgg.h
 
-    def __init__(self, z_t, device=None, engine="native"):
+    def __init__(self, z_t, device=None, engine="native", rng=None):
         if engine not in ("native", "python"):
             raise ValueError(f"engine {engine!r}")
         self.engine = engine
+        self.rng = rng           # None: numpy's global stream, as the reference; else a np.random.RandomState of this chain
         self.batch_size = z_t.X.shape[0]
         self.device = torch.device(device) if device is not None else z_t.X.device
         if getattr(z_t, "E", None) is not None:
@@ -250,6 +251,7 @@ class _Projector:
         self._n_nodes = [int(k) for k in z_t.node_mask.sum(dim=1).tolist()]
         self._native = None
         self._dev_buf = None
+        self._in_flight = None
         if engine == "native":
             L = _lib.lib()
             nn_ = np.asarray(self._n_nodes, dtype=np.int32)
@@ -357,6 +359,21 @@ class _Projector:
         return len(edits)
 
     def _project_labels_device(self, labels, cands):
+        self.project_labels_begin(labels, cands)
+        return self.project_labels_end()
+
+    HOST_CHUNK = 8192        # records copied to the host together with the count; a step with more takes a second copy
+
+    def project_labels_begin(self, labels, cands=None):
+        """Device half of a step, enqueued on the current stream without waiting: compaction of the new edges, then an
+        asynchronous copy of the count and the first HOST_CHUNK records into pinned memory, then an event.
+        ``project_labels_end`` waits for that event only, so work enqueued behind it (another batch's step) keeps the
+        device busy during the host half."""
+        if self.uses_cands and cands is None:
+            raise _lib.ScggError(f"{type(self).__name__}.project_labels needs the top-k candidates")
+        if not labels.is_cuda or labels.dtype != torch.int8 or labels.dim() != 3 or not labels.is_contiguous():
+            raise _lib.ScggError("project_labels_begin: labels must be a contiguous int8 [B,n,n] tensor on the GPU")
+        cands = cands if self.uses_cands else None
         L = _lib.lib()
         B, n, _ = labels.shape
         k = cands.shape[-1] if cands is not None else 0
@@ -365,25 +382,53 @@ class _Projector:
         buf = self._dev_buf
         if buf is None or buf["key"] != (B, n, k, labels.device):
             cap = B * (n * (n - 1) // 2)                         # every pair of every graph new at once
-            buf = self._dev_buf = dict(key=(B, n, k, labels.device), cap=cap,
-                                       meta=torch.zeros(B + 2, dtype=torch.int32, device=labels.device),
-                                       rec=torch.empty(max(cap, 1), 4 + k, dtype=torch.int32, device=labels.device),
-                                       prev=self.z_t_adj.to(device=labels.device, dtype=torch.int8).contiguous())
-        meta, rec, prev = buf["meta"], buf["rec"], buf["prev"]
-        st = _lib.stream_ptr()
+            chunk = max(1, min(cap, self.HOST_CHUNK))
+            dev = labels.device
+            buf = self._dev_buf = dict(key=(B, n, k, dev), cap=cap, chunk=chunk,
+                                       meta=torch.zeros(B + 2, dtype=torch.int32, device=dev),
+                                       rec=torch.empty(max(cap, 1), 4 + k, dtype=torch.int32, device=dev),
+                                       prev=self.z_t_adj.to(device=dev, dtype=torch.int8).contiguous(),
+                                       meta_host=torch.zeros(2, dtype=torch.int32).pin_memory(),
+                                       rec_host=torch.empty(chunk, 4 + k, dtype=torch.int32).pin_memory(),
+                                       edits_host=torch.empty(chunk, 4, dtype=torch.int32).pin_memory(),
+                                       edits=torch.empty(chunk, 4, dtype=torch.int32, device=dev),
+                                       event=torch.cuda.Event())
+        meta, rec = buf["meta"], buf["rec"]
         status_ptr = C.c_void_p(meta.data_ptr() + 4 * (B + 1))
-        _lib.check(L.scgg_new_edges(_lib.ptr(labels), _lib.ptr(prev), _lib.ptr(cands), B, n, k, int(self.binary),
-                                    _lib.ptr(meta), _lib.ptr(rec), buf["cap"], status_ptr, st), "new_edges")
-        m, status = meta[B:].tolist()                            # sync 1: how many records
+        _lib.check(L.scgg_new_edges(_lib.ptr(labels), _lib.ptr(buf["prev"]), _lib.ptr(cands), B, n, k, int(self.binary),
+                                    _lib.ptr(meta), _lib.ptr(rec), buf["cap"], status_ptr, _lib.stream_ptr()), "new_edges")
+        buf["meta_host"].copy_(meta[B:], non_blocking=True)
+        buf["rec_host"].copy_(rec[:buf["chunk"]], non_blocking=True)
+        buf["event"].record()
+        self._in_flight = labels
+
+    def project_labels_end(self):
+        """Host half: wait for the step's records, decide per graph, enqueue the edits and the new z_t."""
+        labels, self._in_flight = self._in_flight, None
+        if labels is None:
+            raise _lib.ScggError("project_labels_end without project_labels_begin")
+        buf = self._dev_buf
+        B, n, k, _ = buf["key"]
+        buf["event"].synchronize()                               # this batch's step only, not the whole stream
+        m, status = buf["meta_host"].tolist()
         assert status == 0, "Once unmasked, the edges cannot be removed."
-        edits = self._run(rec[:m].cpu().numpy() if m else np.zeros((0, 4 + k), dtype=np.int32))      # sync 2: the records
-        if len(edits):
-            e = torch.from_numpy(edits).to(labels.device)
-            _lib.check(L.scgg_apply_edge_edits(_lib.ptr(labels), _lib.ptr(e), len(edits), B, n, st), "apply_edge_edits")
-            e.record_stream(torch.cuda.current_stream())
-        prev.copy_(labels)
-        self.z_t_adj = prev
-        return len(edits)
+        if m <= buf["chunk"]:
+            rec = buf["rec_host"][:m].numpy()
+        else:                                                    # rare: a step with more new edges than the pinned chunk
+            rec = buf["rec"][:m].cpu().numpy()
+        edits = self._run(rec)
+        ne = len(edits)
+        if ne:
+            if ne > buf["edits_host"].shape[0]:
+                buf["edits_host"] = torch.empty(ne, 4, dtype=torch.int32).pin_memory()
+                buf["edits"] = torch.empty(ne, 4, dtype=torch.int32, device=labels.device)
+            buf["edits_host"][:ne].numpy()[...] = edits
+            buf["edits"][:ne].copy_(buf["edits_host"][:ne], non_blocking=True)
+            _lib.check(_lib.lib().scgg_apply_edge_edits(_lib.ptr(labels), _lib.ptr(buf["edits"]), ne, B, n, _lib.stream_ptr()),
+                       "apply_edge_edits")
+        buf["prev"].copy_(labels)
+        self.z_t_adj = buf["prev"]
+        return ne
 
     # ---- host part ------------------------------------------------------------------------------------------
     def _run(self, rec: np.ndarray) -> np.ndarray:
@@ -420,9 +465,8 @@ class _Projector:
             last[(int(b), int(u), int(v))] = int(c)
         return np.asarray([(b, u, v, c) for (b, u, v), c in last.items()], dtype=np.int32).reshape(-1, 4)
 
-    @staticmethod
-    def _shuffle(x):
-        np.random.shuffle(x)
+    def _shuffle(self, x):
+        (np.random if self.rng is None else self.rng).shuffle(x)
 
     def _drop_blocked(self, b, edges, edits):
         """:282-301: an edge blocked in an earlier step is deleted again at once; returns the indices kept."""
@@ -521,10 +565,10 @@ class CoWProjector(_FixingProjector):
 
     kind = 0
 
-    def __init__(self, z_t, device=None, engine="native"):
+    def __init__(self, z_t, device=None, engine="native", rng=None):
         self.top_cow_validity_check_and_fix_obj = _Fixer(COW_ADJACENCY, counted=True)
         self.top_cow_validity_check_and_fix_obj._owner = self
-        super().__init__(z_t, device, engine)
+        super().__init__(z_t, device, engine, rng)
 
     def _try(self, g):
         return self.top_cow_validity_check_and_fix_obj.check_validity_and_fix_if_needed(g)
@@ -535,10 +579,10 @@ class ATMTreeProjector(_FixingProjector):
 
     kind = 2
 
-    def __init__(self, z_t, device=None, engine="native"):
+    def __init__(self, z_t, device=None, engine="native", rng=None):
         self.atm_validity_check_and_fix_obj = _Fixer(ATM_ADJACENCY, counted=False)
         self.atm_validity_check_and_fix_obj._owner = self
-        super().__init__(z_t, device, engine)
+        super().__init__(z_t, device, engine, rng)
 
     def _try(self, g):
         return self.atm_validity_check_and_fix_obj.check_validity_and_fix_if_needed(g) and has_no_cycles(g)
@@ -552,10 +596,10 @@ class CoWVanillaProjector(_VanillaProjector):
 
     kind = 1
 
-    def __init__(self, z_t, device=None, engine="native"):
+    def __init__(self, z_t, device=None, engine="native", rng=None):
         self.top_cow_validity_check = _Fixer(COW_ADJACENCY, counted=False)
         self.top_cow_validity_check._owner = self
-        super().__init__(z_t, device, engine)
+        super().__init__(z_t, device, engine, rng)
 
     def valid_graph_fn(self, g):
         return self.top_cow_validity_check.is_valid_graph(g)
@@ -566,10 +610,10 @@ class ATMVanillaTreeProjector(_VanillaProjector):
 
     kind = 3
 
-    def __init__(self, z_t, device=None, engine="native"):
+    def __init__(self, z_t, device=None, engine="native", rng=None):
         self.atm_validity_check = _Fixer(ATM_ADJACENCY, counted=False)
         self.atm_validity_check._owner = self
-        super().__init__(z_t, device, engine)
+        super().__init__(z_t, device, engine, rng)
 
     def valid_graph_fn(self, g):
         return self.atm_validity_check.is_valid_graph(g) and has_no_cycles(g)

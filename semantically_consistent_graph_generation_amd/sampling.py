@@ -101,13 +101,38 @@ class DiscreteSampler:
             st["y_in"][:, -1] = t / self.T
         return model_input(st["X_in"], st["E_in"], st["y_in"], node_mask)
 
-    @torch.no_grad()
     def sample_batch(self, n_nodes, seed: int = 0, graph_id_base: int = 0, projector=None, n_max=None,
                      steps=None, return_state=False):
         """reference sample_batch :583-684 (loop :653-663, collapse :684) for one batch of graphs.
 
         n_nodes: list / tensor of node counts.  Returns the collapsed PlaceHolder (X, E integer labels, -1 padding,
-        pos) -- or the raw int8 state with ``return_state``.  ``steps`` limits the number of reverse steps (tests)."""
+        pos) -- or the raw int8 state with ``return_state``.  ``steps`` limits the number of reverse steps (tests).
+        ``projector``: a class / factory ``projector(z_T, device)`` with the reference's interface (projector.py, or the
+        reference's own classes)."""
+        return self.sample_batches([dict(n_nodes=n_nodes, seed=seed, graph_id_base=graph_id_base, projector=projector,
+                                         n_max=n_max, steps=steps, return_state=return_state)])[0]
+
+    @torch.no_grad()
+    def sample_batches(self, requests):
+        """Several independent batches (each a dict of ``sample_batch`` arguments) advanced in turn, one reverse step at a
+        time: while the host half of one batch's projector step runs (projector.py: wait for the compacted new edges,
+        per-graph validity work, edits back), the device is busy with the next batch's step.  The reference's loop has
+        a true dependence inside a batch (step s-1 needs the projected z_s), so the overlap is across batches only.
+        Without a projector there is nothing to wait for and the batches simply run one after the other."""
+        chains = [self._chain(**r) for r in requests]
+        results = [None] * len(chains)
+        live = list(range(len(chains)))
+        while live:
+            for k in list(live):
+                try:
+                    next(chains[k])
+                except StopIteration as done:
+                    results[k] = done.value
+                    live.remove(k)
+        return results
+
+    def _chain(self, n_nodes, seed=0, graph_id_base=0, projector=None, n_max=None, steps=None, return_state=False):
+        """One reverse chain as a generator: yields wherever the host would have to wait for the device."""
         dev = next(self.model.parameters()).device
         if dev.type != "cuda":
             raise _lib.ScggError("sampling runs on the MI355X only; move the model to the GPU")
@@ -127,6 +152,7 @@ class DiscreteSampler:
         if steps is not None:
             s_values = s_values[:steps]
         proj = projector(z_T, dev) if projector is not None else None
+        split = on_state and hasattr(proj, "project_labels_begin")
         t = self.T
         for s in s_values:
             labels_t = st["labels"][cur]
@@ -136,7 +162,11 @@ class DiscreteSampler:
             nm.reverse_step_state(pred.E, labels_t, node_mask, st["t_all"][t], st["t_all"][s], rng,
                                   labels_out=st["labels"][cur ^ 1], cands_out=st["cands"][cur ^ 1])
             cur ^= 1
-            if proj is not None and on_state:      # projector.py: compacted new edges to the host, edits scattered back
+            if proj is not None and split:         # projector.py: compacted new edges to the host, edits scattered back
+                proj.project_labels_begin(st["labels"][cur], st["cands"][cur])
+                yield                               # the step is enqueued; the host half needs its result
+                proj.project_labels_end()
+            elif proj is not None and on_state:
                 proj.project_labels(st["labels"][cur], st["cands"][cur])
             elif proj is not None:   # any other host-side projector: reference types in, in-place edit of z_s.E
                 s_int = torch.full((B, 1), s, dtype=torch.long, device=dev)
