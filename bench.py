@@ -120,6 +120,10 @@ def main():
     ap.add_argument("--T", type=int, default=500, help="diffusion steps per chain (BASELINE: 500)")
     ap.add_argument("--batch", type=int, default=512, help="graphs per GPU per chain (BASELINE: 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--projector", default=None, help="cfg.model.rev_proj (cow_proj, cow_proj_vanilla): SURVEY config 4; "
+                                                      "not the headline configuration")
+    ap.add_argument("--pipeline", type=int, default=1, help="independent batches advanced in turn per step (sample_batches); "
+                                                            "a step then samples pipeline * batch graphs per GPU")
     a = ap.parse_args()
 
     from semantically_consistent_graph_generation_amd import sharding
@@ -141,8 +145,22 @@ def main():
     hd = DIMS["hidden_dims"]
     flops_per_launch = valid_pairs * (6 * hd["de"] * hd["dx"] + 4 * hd["de"] * hd["dim_ffE"])
 
+    def projector_factory(seed):
+        if not a.projector:
+            return None
+        import numpy as np
+        from semantically_consistent_graph_generation_amd.projector import projector_for
+        cls, rs = projector_for(a.projector), np.random.RandomState(seed)      # one shuffle stream per chain
+
+        def make(z_T, device):
+            return cls(z_T, device, rng=rs)
+        make.project_labels = True
+        return make
+
     def chain(k):
-        return sampler.sample_batch(n_nodes, seed=1000 + k, graph_id_base=shard.start, n_max=N_MAX, return_state=True)
+        reqs = [dict(n_nodes=n_nodes, seed=1000 + k * a.pipeline + p, graph_id_base=shard.start, n_max=N_MAX, return_state=True,
+                     projector=projector_factory(1000 + k * a.pipeline + p)) for p in range(a.pipeline)]
+        return sampler.sample_batches(reqs)[-1]
 
     for k in range(a.warmup):
         chain(k)
@@ -168,13 +186,15 @@ def main():
         algorithmic = flops_per_launch / (kernel_ms * 1e-3) / 1e12 if n_launch else 0.0
         achieved = X3_PRODUCTS * algorithmic
         out = {
-            "metric": "sampled graphs/sec (full T-step reverse diffusion)", "value": world * a.batch * a.steps / elapsed,
+            "metric": "sampled graphs/sec (full T-step reverse diffusion)", "value": world * a.batch * a.pipeline * a.steps / elapsed,
             "unit": "graphs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"CoW-shaped full {a.T}-step reverse sampling, B={a.batch}/GPU, n<=32 (n_i~U[12,32]), "
                                    "ConStruct dims (dx256 de64 dy64 h8, 5 layers), extra features on, C=14, top_k=4, "
-                                   "absorbing_edges, projector None (BASELINE configs[1])",
+                                   f"absorbing_edges, projector {a.projector}"
+                                   + (" (BASELINE configs[1])" if not a.projector and a.pipeline == 1 else
+                                      f", {a.pipeline} batches in turn per step"),
                        "graphs_per_gpu": a.batch, "diffusion_steps": a.T, "valid_pairs_per_forward": valid_pairs,
                        "sampled_edges_last_chain": edges},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
