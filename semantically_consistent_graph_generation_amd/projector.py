@@ -270,7 +270,10 @@ class _Projector:
     def __del__(self):
         h, self._native = getattr(self, "_native", None), None
         if h:
-            _lib.lib().scgg_projector_destroy(h)
+            try:
+                _lib.lib().scgg_projector_destroy(h)
+            except Exception:          # interpreter shutdown: the library object may be gone already
+                pass
 
     # ---- the reference's attributes ---------------------------------------------------------------------------
     def _export(self, b):
