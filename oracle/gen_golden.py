@@ -461,10 +461,69 @@ def gen_projector(R):
              blocked=blocked, counter=counter)
 
 
+def gen_sample_plan(R):
+    """F13: the batching rule of sample_n_graphs (diffusion_model_discrete_3d.py:753-843), recorded by calling the REAL
+    method on a stand-in ``self`` whose sample_batch only notes the node counts it is given.  The module's other
+    imports (Lightning, visualisation, molecular metrics, the 3D models, torch_geometric loaders) are stubbed: none of
+    them is touched by this method."""
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        m.__path__ = []
+        sys.modules[name] = m
+        return m
+
+    class _D:
+        def __init__(self, *a, **k):
+            pass
+    stub("pytorch_lightning", LightningModule=_D)
+    stub("src.ConStruct.analysis.visualization", Visualizer=_D)
+    stub("src.ConStruct.diffusion.extra_features_molecular", ExtraMolecularFeatures=_D)
+    stub("src.ConStruct.metrics.train_metrics", TrainLoss=_D, TrainMolecularMetrics=_D)
+    stub("src.ConStruct.metrics.abstract_metrics", NLL=_D, TrainAbstractMetrics=_D, XKl=_D, ChargesKl=_D, EKl=_D)
+    stub("src.ConStruct.models.equivariant_pos_transformer_model", EquivariantGraph3DTransformer=_D)
+    stub("src.ConStruct.models.pos_transformer_model", Graph3DTransformer=_D)
+    sys.modules["torch_geometric"].__path__ = []
+    stub("torch_geometric.data", Batch=_D, Dataset=_D, LightningDataset=_D)
+    stub("torch_geometric.data.data", BaseData=_D)
+    stub("torch_geometric.loader", DataLoader=_D)
+    import src.ConStruct.diffusion_model_discrete_3d as DM
+    arrays = {}
+    cases = [  # name, to_generate, chains_to_save, samples_to_save, batch_size, adaptive, reference_bs
+        ("fixed_small", 41, 2, 5, 4, False, 0), ("fixed_only_first", 9, 3, 20, 3, False, 0),
+        ("fixed_none_first", 50, 0, 0, 5, False, 0), ("adaptive", 60, 1, 12, 0, True, 6), ("adaptive_big", 90, 0, 7, 0, True, 40),
+        ("single", 1, 0, 0, 8, False, 0)]
+    for ci, (name, n_gen, n_chain, n_save, bs, adaptive, ref_bs) in enumerate(cases):
+        rs = np.random.RandomState(700 + ci)
+        draws = []
+
+        class Dist:
+            def sample_n(self, k, device):
+                v = torch.from_numpy(rs.randint(3, 41, size=k))
+                draws.append(v.clone())
+                return v
+        calls = []
+        me = SimpleNamespace(nodes_dist=Dist(), device="cpu", number_chain_steps=10,
+                             cfg=SimpleNamespace(dataset=SimpleNamespace(adaptive_loader=adaptive),
+                                                 train=SimpleNamespace(batch_size=bs, reference_batch_size=ref_bs)),
+                             sample_batch=lambda n_nodes, **k: calls.append([int(v) for v in n_nodes]) or len(calls))
+        DM.Discrete3dDenoisingDiffusion.sample_n_graphs(me, n_gen, n_chain, n_save, False)
+        arrays[f"{name}/args"] = np.array([n_gen, n_chain, n_save, bs, int(adaptive), ref_bs])
+        arrays[f"{name}/first"] = draws[0].numpy() if min(n_gen, max(n_save, n_chain)) > 0 else np.zeros(0, np.int64)
+        rest = draws[-1].numpy() if len(draws) > (1 if min(n_gen, max(n_save, n_chain)) > 0 else 0) else np.zeros(0, np.int64)
+        arrays[f"{name}/rest"] = rest
+        arrays[f"{name}/batch_sizes"] = np.array([len(c) for c in calls])
+        arrays[f"{name}/batches_flat"] = np.array([v for c in calls for v in c])
+        print(f"{name}: {len(calls)} batches, sizes {[len(c) for c in calls]}")
+    save("f13_sample_plan", names=np.array([c[0] for c in cases]), **arrays)
+
+
 def main():
     R = import_reference()
     if sys.argv[1:] == ["projector"]:
         return gen_projector(R)
+    if sys.argv[1:] == ["sample_plan"]:
+        return gen_sample_plan(R)
     gen_block_and_layer(R)
     gen_graph_transformer(R)
     gen_pooling(R)
@@ -474,6 +533,7 @@ def main():
     gen_sample_discrete(R)
     gen_placeholder(R)
     gen_projector(R)
+    gen_sample_plan(R)
 
 
 if __name__ == "__main__":

@@ -13,6 +13,7 @@ graph draws the same Philox stream whatever the sharding.
 """
 from __future__ import annotations
 
+import math
 import os
 
 import torch
@@ -186,3 +187,72 @@ class DiscreteSampler:
         X = torch.where(node_mask, torch.zeros_like(n_nodes[:, None].expand(-1, n)), torch.full((B, n), -1, device=dev))
         return PlaceHolder(X=X, charges=torch.where(node_mask, 0, 1000), E=E, y=torch.zeros(B, 0, device=dev),
                            node_mask=node_mask, pos=pos)
+
+    # ------------------------------------------------------------------------------------------ driver-level API
+    def sample_n_graphs(self, n_nodes_first, n_nodes_rest=(), batch_size: int = 128, adaptive_loader: bool = False,
+                        reference_batch_size: int = None, seed: int = 0, projector=None, pipeline: int = 2, **kw):
+        """reference sample_n_graphs (diffusion_model_discrete_3d.py:753-843): cut the requested node counts into
+        batches by the reference's rule (``plan_sample_batches``) and sample every batch.  The batches are independent,
+        which is what ``sample_batches`` needs: ``pipeline`` of them are advanced in turn (useful with a projector).
+        ``n_nodes_first`` / ``n_nodes_rest``: what ``nodes_dist.sample_n`` returned for the unsorted first part
+        (:767-769) and for the remainder (:816-818).  Global graph ids follow the order of the batches, so the result
+        does not depend on ``pipeline``.  Returns one ``sample_batch`` result per batch, in the reference's order."""
+        plan = plan_sample_batches(n_nodes_first, n_nodes_rest, batch_size, adaptive_loader, reference_batch_size)
+        reqs, base = [], 0
+        for k, ns in enumerate(plan):
+            reqs.append(dict(n_nodes=ns, seed=seed + k, graph_id_base=base, projector=projector, **kw))
+            base += len(ns)
+        out = []
+        step = max(1, int(pipeline))
+        for lo in range(0, len(reqs), step):
+            out.extend(self.sample_batches(reqs[lo:lo + step]))
+        return out
+
+
+def effective_batch_size(max_size, reference_batch_size, reference_size=20, sampling=False):
+    """datasets/adaptive_loader.py:18-22."""
+    x = reference_batch_size * (reference_size / max_size) ** 2
+    return math.floor(1.8 * x) if sampling else math.floor(x)
+
+
+def plan_sample_batches(n_nodes_first, n_nodes_rest=(), batch_size: int = 128, adaptive_loader: bool = False,
+                        reference_batch_size: int = None):
+    """The batching rule of the reference's sample_n_graphs, as lists of node counts (one list per sample_batch call).
+
+    First part (:767-813, the graphs that are visualised; sizes in the order drawn): a graph joins the current batch while
+    ``ebs > len(batch)`` with ``ebs = int(1.8 * batch_size)`` (:782-785; no backward pass at sampling time), or
+    ``effective_batch_size(max size so far incl. this graph, reference_batch_size, sampling=True)`` with the adaptive
+    loader (:776-781).  Remainder (:816-842): sorted by decreasing size when adaptive (:820-822); the limit there is
+    the FLOAT ``1.8 * batch_size`` (:832-833, no int()), and the running maximum is updated before the test (:827)."""
+    def as_list(x):
+        return [int(v) for v in (x.tolist() if hasattr(x, "tolist") else x)]
+    first, rest = as_list(n_nodes_first), as_list(n_nodes_rest)
+    if adaptive_loader and reference_batch_size is None:
+        raise ValueError("adaptive_loader needs reference_batch_size (cfg.train.reference_batch_size)")
+    plan = []
+    if first:
+        cur, cur_max = [], 0
+        for n in first:
+            pot_max = max(cur_max, n)
+            ebs = effective_batch_size(pot_max, reference_batch_size, sampling=True) if adaptive_loader else int(1.8 * batch_size)
+            if ebs > len(cur) or len(cur) == 0:
+                cur.append(n)
+                cur_max = pot_max
+            else:
+                plan.append(cur)
+                cur, cur_max = [n], n
+        plan.append(cur)
+    if rest:
+        if adaptive_loader:
+            rest = sorted(rest, reverse=True)
+        cur, max_size = [], 0
+        for n in rest:
+            max_size = max(max_size, n)
+            ebs = effective_batch_size(max_size, reference_batch_size, sampling=True) if adaptive_loader else 1.8 * batch_size
+            if ebs > len(cur) or len(cur) == 0:
+                cur.append(n)
+            else:
+                plan.append(cur)
+                cur, max_size = [n], n
+        plan.append(cur)
+    return plan

@@ -191,3 +191,23 @@ def test_pipelined_batches_equal_sequential_batches():
     for (la, ca, _, _), (lb, cb, _, _) in zip(together, alone):
         assert torch.equal(la, lb) and torch.equal(ca, cb)
     assert int((together[0][0] > 0).sum()) > 0
+
+
+def test_sample_n_graphs_is_independent_of_the_pipeline_depth():
+    from semantically_consistent_graph_generation_amd import projector as PJ
+    sampler, nm = make_cow_sampler(T=6)
+    first, rest = [9, 14, 5], [12, 7, 11, 8, 6, 10, 13]
+
+    def run(depth):
+        rs = [np.random.RandomState(40 + k) for k in range(8)]
+        it = iter(rs)
+
+        def make(z_T, dev):
+            return PJ.CoWProjector(z_T, dev, rng=next(it))
+        make.project_labels = True
+        return sampler.sample_n_graphs(first, rest, batch_size=2, seed=9, projector=make, pipeline=depth, return_state=True,
+                                       n_max=16)
+    a, b = run(1), run(3)
+    assert [r[0].shape[0] for r in a] == [3, 4, 3]            # int(1.8*2)=3 first, then 1.8*2=3.6 -> 4 per batch
+    for (la, _, _, _), (lb, _, _, _) in zip(a, b):
+        assert torch.equal(la, lb)

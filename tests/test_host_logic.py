@@ -130,3 +130,20 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
+def test_sample_plan_matches_reference_batching_rule():
+    """plan_sample_batches against the batches the REAL sample_n_graphs asked for (tests/golden/f13_sample_plan.npz,
+    oracle/gen_golden.py gen_sample_plan): int(1.8*bs) in the first part, the float 1.8*bs in the remainder, the
+    adaptive rule with sorting."""
+    from semantically_consistent_graph_generation_amd.sampling import effective_batch_size, plan_sample_batches
+    g = np.load(os.path.join(ROOT, "tests", "golden", "f13_sample_plan.npz"))
+    for name in g["names"]:
+        n_gen, n_chain, n_save, bs, adaptive, ref_bs = g[f"{name}/args"].tolist()
+        plan = plan_sample_batches(g[f"{name}/first"], g[f"{name}/rest"], batch_size=bs, adaptive_loader=bool(adaptive),
+                                   reference_batch_size=ref_bs or None)
+        assert [len(p) for p in plan] == g[f"{name}/batch_sizes"].tolist(), name
+        assert [v for p in plan for v in p] == g[f"{name}/batches_flat"].tolist(), name
+        assert sum(len(p) for p in plan) == n_gen
+    assert effective_batch_size(20, 10) == 10 and effective_batch_size(40, 10, sampling=True) == 4
+    assert plan_sample_batches([], []) == []
