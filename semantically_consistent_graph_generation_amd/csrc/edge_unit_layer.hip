@@ -1061,13 +1061,11 @@ int launch_attn_finish(const AttnFinishArgs& a, int M, hipStream_t st) {
 // Etoy pooling of a hidden E (layers.py:34-41): z[b] = [mean | min | max | biased variance] per channel over the n_b x n_b
 // pairs of the valid nodes of the SYMMETRISED masked tensor (the stored one is not: mfma_chain.h load_sym_tile), zero
 // diagonal included.  One workgroup per graph; thread = (channel, slice of the unordered pairs); each stored element
-// is read once per pass (pair {i,j} = 0.5 (E_ij + E_ji), weight 2); two passes (mean, then centred squares -- the
-// second pass is an L2 read).
+// is read once (pair {i,j} = 0.5 (E_ij + E_ji), weight 2); one pass, shifted sums merged pairwise (see below).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int POOL_T = 256;   // threads per graph; 13 KB of LDS: fits on a CU beside a 12-wave edge workgroup (23 KB free)
+constexpr int POOL_T = 256;   // threads per graph; 9 KB of LDS: fits on a CU beside a 12-wave edge workgroup (23 KB free)
 __global__ __launch_bounds__(POOL_T) void edge_pool_stats_kernel(EdgePoolArgs a) {
-  __shared__ f32x4 red[3][POOL_T];
-  __shared__ f32x4 smean[64];
+  __shared__ f32x4 red[2][POOL_T];
   __shared__ short vidx[512];                                             // the valid nodes, in order
   __shared__ int wcount[POOL_T / 64];
   const int b = blockIdx.x, n = a.n, DE = a.de, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1106,46 +1104,69 @@ __global__ __launch_bounds__(POOL_T) void edge_pool_stats_kernel(EdgePoolArgs a)
       r += S;
     }
   };
-  // ---- pass 1: sum, min, max
-  f32x4 sum = splat4(0.f), mn = splat4(INFINITY), mx = splat4(-INFINITY);
+  // ---- one pass.  Thread t keeps, for its slice of the pairs, the sum and the sum of squares of (v - k_t), k_t = the
+  //      first value it sees: the differences are of the size of the spread, so M2_t = q - s^2 / n_t loses nothing to
+  //      cancellation; the slices are then merged with the pairwise-variance update (Chan et al.), which is as accurate
+  //      as the two-pass form this replaces and reads E once instead of twice.
+  f32x4 k = splat4(0.f), s1 = splat4(0.f), q = splat4(0.f), mn = splat4(INFINITY), mx = splat4(-INFINITY);
+  int cnt_t = 0;
   walk([&](const f32x4& v) {
+    if (cnt_t == 0) k = v;
+    ++cnt_t;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { sum[e] += v[e]; mn[e] = fminf(mn[e], v[e]); mx[e] = fmaxf(mx[e], v[e]); }
+    for (int e = 0; e < 4; ++e) {
+      const float d = v[e] - k[e];
+      s1[e] += d; q[e] += d * d;
+      mn[e] = fminf(mn[e], v[e]); mx[e] = fmaxf(mx[e], v[e]);
+    }
   });
   if (nv > 0) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { mn[e] = fminf(mn[e], 0.f); mx[e] = fmaxf(mx[e], 0.f); }   // the diagonal
   }
-  red[0][tid] = sum; red[1][tid] = mn; red[2][tid] = mx;
+  const float nt = (float)cnt_t, inv_nt = cnt_t > 0 ? 1.f / nt : 0.f;
+  f32x4 mean_t, m2_t;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { mean_t[e] = k[e] + s1[e] * inv_nt; m2_t[e] = q[e] - s1[e] * s1[e] * inv_nt; }
+  red[0][tid] = mean_t; red[1][tid] = m2_t;
+  __syncthreads();
+  f32x4 mean = mean_t, m2 = m2_t;
+  const int np_all = nv * (nv - 1) / 2;
+  if (sl == 0) {
+    float na = nt;
+    for (int t = 1; t < S; ++t) {
+      const int c = t < np_all ? (np_all - t + S - 1) / S : 0;        // pairs of slice t: t, t + S, ...
+      if (c == 0) break;
+      const float nb = (float)c, nab = na + nb;
+      const f32x4 mb = red[0][t * G4 + c4], qb = red[1][t * G4 + c4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = mb[e] - mean[e];
+        mean[e] += d * (nb / nab);
+        m2[e] += qb[e] + d * d * (na * nb / nab);
+      }
+      na = nab;
+    }
+  }
+  __syncthreads();
+  red[0][tid] = mn; red[1][tid] = mx;
   __syncthreads();
   if (sl == 0) {
     for (int t = 1; t < S; ++t) {
-      const f32x4 s2 = red[0][t * G4 + c4], n2 = red[1][t * G4 + c4], x2 = red[2][t * G4 + c4];
+      const f32x4 n2 = red[0][t * G4 + c4], x2 = red[1][t * G4 + c4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { sum[e] += s2[e]; mn[e] = fminf(mn[e], n2[e]); mx[e] = fmaxf(mx[e], x2[e]); }
+      for (int e = 0; e < 4; ++e) { mn[e] = fminf(mn[e], n2[e]); mx[e] = fmaxf(mx[e], x2[e]); }
     }
-    smean[c4] = sum * (2.f / cnt);
-    red[1][c4] = mn; red[2][c4] = mx;
-  }
-  __syncthreads();
-  // ---- pass 2: centred squares (L2 reads)
-  const f32x4 mean = smean[c4];
-  f32x4 q = splat4(0.f);
-  walk([&](const f32x4& v) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { const float d = v[e] - mean[e]; q[e] += d * d; }
-  });
-  __syncthreads();
-  red[0][tid] = q;
-  __syncthreads();
-  if (sl == 0) {
-    for (int t = 1; t < S; ++t) q += red[0][t * G4 + c4];
+    // from the unordered pairs (mean, M2 about it, np_all of them) to all nv x nv entries: every pair counts twice, the
+    // nv diagonal entries are zero
     float* z = a.z + (long long)b * a.z_stride + a.z_offset + 4 * c4;
-    const f32x4 mnv = red[1][c4], mxv = red[2][c4];
+    const float npf = (float)np_all;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float qq = 2.f * q[e] + (float)nv * mean[e] * mean[e];        // pairs count twice; nv diagonal zeros
-      z[e] = mean[e]; z[DE + e] = mnv[e]; z[2 * DE + e] = mxv[e]; z[3 * DE + e] = qq / cnt;
+      const float m = 2.f * npf * mean[e] / cnt;
+      const float dm = mean[e] - m;
+      const float qq = 2.f * (m2[e] + npf * dm * dm) + (float)nv * m * m;
+      z[e] = m; z[DE + e] = mn[e]; z[2 * DE + e] = mx[e]; z[3 * DE + e] = qq / cnt;
     }
   }
 }
