@@ -245,3 +245,23 @@ GraphTransformer.read_edge_layer_profile = _profile_read
 def model_input(X, E, y, node_mask):
     """Convenience: the minimal object GraphTransformer.forward needs."""
     return SimpleNamespace(X=X, E=E, y=y, node_mask=node_mask)
+
+
+def load_lightning_checkpoint(model: "GraphTransformer", checkpoint, prefix: str = "model."):
+    """Load the denoiser's weights out of a checkpoint of the reference's Lightning module.
+
+    The reference restores ``Discrete3dDenoisingDiffusion`` with ``model.load_state_dict(checkpoint["state_dict"])``
+    (edge_denoiser_efficiency_check.py:198-199; main.py:113-126 through ``ckpt_path``), where the denoiser is the
+    attribute ``self.model`` (diffusion_model_discrete_3d.py:111-132): its parameters are the keys ``model.<name>``.
+    ``checkpoint``: a path (read with ``torch.load(weights_only=True)``: nothing in the file is executed), the loaded
+    dict, or its ``state_dict``.  The keys under ``prefix`` must match this ``GraphTransformer`` exactly (strict); every
+    other key (metric buffers, noise-model tables) is returned, untouched, as the list of ignored names."""
+    import os
+    if isinstance(checkpoint, (str, os.PathLike)):
+        checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=True)
+    sd = checkpoint.get("state_dict", checkpoint)
+    own = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    if not own:
+        raise KeyError(f"no '{prefix}*' keys in the checkpoint ({len(sd)} keys)")
+    model.load_state_dict(own, strict=True)
+    return [k for k in sd if not k.startswith(prefix)]

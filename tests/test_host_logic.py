@@ -147,3 +147,26 @@ def test_sample_plan_matches_reference_batching_rule():
         assert sum(len(p) for p in plan) == n_gen
     assert effective_batch_size(20, 10) == 10 and effective_batch_size(40, 10, sampling=True) == 4
     assert plan_sample_batches([], []) == []
+
+
+def test_load_lightning_checkpoint_key_mapping(tmp_path):
+    """`model.` prefix of the reference's Lightning module (diffusion_model_discrete_3d.py:111-132), strict match, other
+    keys reported; the file is read with weights_only=True."""
+    from semantically_consistent_graph_generation_amd.transformer_model import GraphTransformer, load_lightning_checkpoint
+    dims = fx.TINY_DIMS
+    make = lambda: GraphTransformer(2, fx.dims_ns(4, 11, 7), dims["hidden_mlp_dims"], dims["hidden_dims"], fx.dims_ns(1, 6, 0))
+    src, dst = make(), make()
+    sd = fx.make_state_dict({k: tuple(v.shape) for k, v in src.state_dict().items()}, seed=3)
+    ckpt = {"state_dict": {**{"model." + k: v for k, v in sd.items()}, "train_loss.lambda_train": torch.ones(4),
+                           "noise_model._betas": torch.zeros(3)}, "epoch": 7}
+    path = tmp_path / "last.ckpt"
+    torch.save(ckpt, path)
+    ignored = load_lightning_checkpoint(dst, str(path))
+    assert sorted(ignored) == ["noise_model._betas", "train_loss.lambda_train"]
+    for k, v in dst.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    bad = {"state_dict": {"model." + k: v for k, v in list(sd.items())[1:]}}
+    with pytest.raises(RuntimeError):
+        load_lightning_checkpoint(make(), bad)
+    with pytest.raises(KeyError):
+        load_lightning_checkpoint(make(), {"state_dict": {"other.w": torch.ones(1)}})
