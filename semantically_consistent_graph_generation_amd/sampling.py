@@ -103,15 +103,19 @@ class DiscreteSampler:
         return model_input(st["X_in"], st["E_in"], st["y_in"], node_mask)
 
     def sample_batch(self, n_nodes, seed: int = 0, graph_id_base: int = 0, projector=None, n_max=None,
-                     steps=None, return_state=False):
+                     steps=None, return_state=False, keep_chain: int = 0, number_chain_steps: int = 50):
         """reference sample_batch :583-684 (loop :653-663, collapse :684) for one batch of graphs.
 
         n_nodes: list / tensor of node counts.  Returns the collapsed PlaceHolder (X, E integer labels, -1 padding,
         pos) -- or the raw int8 state with ``return_state``.  ``steps`` limits the number of reverse steps (tests).
         ``projector``: a class / factory ``projector(z_T, device)`` with the reference's interface (projector.py, or the
-        reference's own classes)."""
+        reference's own classes).  ``keep_chain`` > 0: the first ``keep_chain`` graphs are also recorded along the chain
+        as the reference does (:622-631, :665-677, :689-699): ``number_chain_steps`` frames of collapsed X / E / pos, frame
+        ``N-1-(s*N)//T`` taken after every step s with ``(s*N) % T == 0``, the last frame overwritten with the result; they
+        come back as ``.chains`` of the returned PlaceHolder (with ``return_state``: as a fifth element)."""
         return self.sample_batches([dict(n_nodes=n_nodes, seed=seed, graph_id_base=graph_id_base, projector=projector,
-                                         n_max=n_max, steps=steps, return_state=return_state)])[0]
+                                         n_max=n_max, steps=steps, return_state=return_state, keep_chain=keep_chain,
+                                         number_chain_steps=number_chain_steps)])[0]
 
     @torch.no_grad()
     def sample_batches(self, requests):
@@ -132,7 +136,21 @@ class DiscreteSampler:
                     live.remove(k)
         return results
 
-    def _chain(self, n_nodes, seed=0, graph_id_base=0, projector=None, n_max=None, steps=None, return_state=False):
+    @staticmethod
+    def _collapse_labels(labels, node_mask):
+        """collapse (utils.py:169-195) of the int8 state: X = 0 on nodes / -1 on padding; E = class on live pairs, 0 on the
+        diagonal of valid nodes (argmax of a zero row), -1 on padded pairs."""
+        B, n = node_mask.shape
+        E = labels.long()
+        eye = torch.eye(n, dtype=torch.bool, device=labels.device)[None]
+        valid = node_mask[:, :, None] & node_mask[:, None, :]
+        E = torch.where(valid & eye, torch.zeros_like(E), E)
+        E = torch.where(valid, E, torch.full_like(E, -1))
+        X = torch.where(node_mask, 0, -1).long()
+        return X, E
+
+    def _chain(self, n_nodes, seed=0, graph_id_base=0, projector=None, n_max=None, steps=None, return_state=False,
+               keep_chain=0, number_chain_steps=50):
         """One reverse chain as a generator: yields wherever the host would have to wait for the device."""
         dev = next(self.model.parameters()).device
         if dev.type != "cuda":
@@ -154,6 +172,14 @@ class DiscreteSampler:
             s_values = s_values[:steps]
         proj = projector(z_T, dev) if projector is not None else None
         split = on_state and hasattr(proj, "project_labels_begin")
+        chains = None
+        if keep_chain > 0:
+            assert 0 < number_chain_steps < self.T                                        # :620
+            N, kc = number_chain_steps, min(int(keep_chain), B)
+            chains = PlaceHolder(X=torch.zeros(N, kc, n, dtype=torch.long, device=dev),
+                                 E=torch.zeros(N, kc, n, n, dtype=torch.long, device=dev), y=None,
+                                 charges=torch.zeros(N, kc, n, dtype=torch.long, device=dev),
+                                 pos=torch.zeros(N, kc, n, 3, device=dev))
         t = self.T
         for s in s_values:
             labels_t = st["labels"][cur]
@@ -176,17 +202,21 @@ class DiscreteSampler:
                 z_s._labels = None
                 st["labels"][cur].copy_(NoiseModel._labels_of(z_s, nm.E_classes))
             t = s
+            if chains is not None and (s * N) % self.T == 0:                               # :666-677
+                w = N - 1 - (s * N) // self.T
+                cX, cE = self._collapse_labels(st["labels"][cur][:kc], node_mask[:kc])
+                chains.X[w], chains.E[w], chains.pos[w] = cX, cE, pos[:kc]
         labels = st["labels"][cur]
+        X, E = self._collapse_labels(labels, node_mask)
+        if chains is not None:                                                             # :689-699
+            chains.X[-1], chains.E[-1], chains.pos[-1] = X[:kc], E[:kc], pos[:kc]
         if return_state:
-            return labels, st["cands"][cur], node_mask, pos
-        E = labels.long()                                  # collapse (utils.py:169-195): diag of valid nodes -> argmax of a
-        eye = torch.eye(n, dtype=torch.bool, device=dev)[None]          # zero row = 0, padded pairs -> -1
-        valid = node_mask[:, :, None] & node_mask[:, None, :]
-        E = torch.where(valid & eye, torch.zeros_like(E), E)
-        E = torch.where(valid, E, torch.full_like(E, -1))
-        X = torch.where(node_mask, torch.zeros_like(n_nodes[:, None].expand(-1, n)), torch.full((B, n), -1, device=dev))
-        return PlaceHolder(X=X, charges=torch.where(node_mask, 0, 1000), E=E, y=torch.zeros(B, 0, device=dev),
-                           node_mask=node_mask, pos=pos)
+            state = (labels, st["cands"][cur], node_mask, pos)
+            return state + (chains,) if chains is not None else state
+        out = PlaceHolder(X=X, charges=torch.where(node_mask, 0, 1000), E=E, y=torch.zeros(B, 0, device=dev),
+                          node_mask=node_mask, pos=pos)
+        out.chains = chains
+        return out
 
     # ------------------------------------------------------------------------------------------ driver-level API
     def sample_n_graphs(self, n_nodes_first, n_nodes_rest=(), batch_size: int = 128, adaptive_loader: bool = False,

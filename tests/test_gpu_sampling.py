@@ -211,3 +211,20 @@ def test_sample_n_graphs_is_independent_of_the_pipeline_depth():
     assert [r[0].shape[0] for r in a] == [3, 4, 3]            # int(1.8*2)=3 first, then 1.8*2=3.6 -> 4 per batch
     for (la, _, _, _), (lb, _, _, _) in zip(a, b):
         assert torch.equal(la, lb)
+
+
+def test_keep_chain_frames_follow_the_reference_rule():
+    """:622-631, :665-677, :689-699: frame N-1-(s*N)//T after every step s with (s*N) % T == 0, last frame = result."""
+    sampler, nm = make_cow_sampler(T=10)
+    n_nodes = [12, 7, 9]
+    out = sampler.sample_batch(n_nodes, seed=21, keep_chain=2, number_chain_steps=5)
+    ch = out.chains
+    assert ch.E.shape == (5, 2, 12, 12) and ch.X.shape == (5, 2, 12) and ch.pos.shape == (5, 2, 12, 3)
+    assert torch.equal(ch.E[-1], out.E[:2]) and torch.equal(ch.X[-1], out.X[:2])
+    for frame, steps in ((0, 2), (1, 4), (2, 6), (3, 8)):          # s = 8, 6, 4, 2 are reached after 2, 4, 6, 8 steps
+        part = sampler.sample_batch(n_nodes, seed=21, steps=steps)
+        assert torch.equal(ch.E[frame], part.E[:2]), frame
+    assert bool((ch.E[:, 1, 7:, :] == -1).all()) and bool((ch.X[:, 1, 7:] == -1).all())      # graph 1 has 7 nodes
+    assert sampler.sample_batch(n_nodes, seed=21).chains is None
+    state = sampler.sample_batch(n_nodes, seed=21, keep_chain=5, number_chain_steps=2, return_state=True)
+    assert len(state) == 5 and state[4].E.shape == (2, 3, 12, 12)
