@@ -207,12 +207,13 @@ class DiscreteSampler:
                 cX, cE = self._collapse_labels(st["labels"][cur][:kc], node_mask[:kc])
                 chains.X[w], chains.E[w], chains.pos[w] = cX, cE, pos[:kc]
         labels = st["labels"][cur]
+        if return_state and chains is None:
+            return labels, st["cands"][cur], node_mask, pos
         X, E = self._collapse_labels(labels, node_mask)
         if chains is not None:                                                             # :689-699
             chains.X[-1], chains.E[-1], chains.pos[-1] = X[:kc], E[:kc], pos[:kc]
         if return_state:
-            state = (labels, st["cands"][cur], node_mask, pos)
-            return state + (chains,) if chains is not None else state
+            return labels, st["cands"][cur], node_mask, pos, chains
         out = PlaceHolder(X=X, charges=torch.where(node_mask, 0, 1000), E=E, y=torch.zeros(B, 0, device=dev),
                           node_mask=node_mask, pos=pos)
         out.chains = chains
