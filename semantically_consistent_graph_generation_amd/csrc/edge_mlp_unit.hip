@@ -352,6 +352,12 @@ static bool mlp_x3(int ib) {
   }
   return mode == 1 && ib % 2 == 0;
 }
+// The x3 kernels take K in chunks of 32 channels (two 16-channel blocks): an odd block count of the INPUT MLP is rounded
+// up, the extra block is zero in the packed weights and in the loaded rows (both are guarded by the true width).
+static int in_blocks(int dE_in) {
+  const int ib = (dE_in + 15) / 16;
+  return (ib % 2 != 0 && mlp_x3(ib + 1)) ? ib + 1 : ib;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 #define SCGG_MLP_IN_CASES CASE(1, 8, 4) CASE(2, 8, 4) CASE(3, 8, 4) CASE(4, 8, 4) CASE(1, 2, 2) CASE(2, 2, 2)   /* (ceil(in_E/16), hid_E/16, de/16) */
@@ -369,14 +375,14 @@ static int n_cu_cached() {
 }
 
 long long edge_mlp_img_f4(int K1, int N1, int N2) {
-  const int ib = (K1 + 15) / 16, hb = N1 / 16, ob = (N2 + 15) / 16;
+  const int ib = in_blocks(K1), hb = N1 / 16, ob = (N2 + 15) / 16;
   if (N1 % 32 != 0) return -1;
   if (mlp_x3(ib)) return (long long)(hb * (ib / 2) + ob * (hb / 2)) * 192 + hb * 4 + ob * 4;
   return (long long)hb * ib * 64 + (long long)ob * hb * 64 + hb * 4 + ob * 4;
 }
 
 int launch_edge_mlp_pack(const EdgeMlpPackArgs& a, hipStream_t st) {
-  const int ib = (a.K1 + 15) / 16, hb = a.N1 / 16, ob = (a.N2 + 15) / 16;
+  const int ib = in_blocks(a.K1), hb = a.N1 / 16, ob = (a.N2 + 15) / 16;
 #define CASE(IB, HB, OB)                                                                             \
   if (ib == IB && hb == HB && ob == OB) {                                                            \
     if constexpr (IB % 2 == 0) {                                                                     \
@@ -417,7 +423,7 @@ static int launch_mlp(const EdgeMlpUnitArgs& a, hipStream_t st) {
 }
 
 int launch_edge_mlp_in(const EdgeMlpUnitArgs& a, int dE_in, int hid, int de, hipStream_t st) {
-  const int ib = (dE_in + 15) / 16, hb = hid / 16, ob = de / 16;
+  const int ib = in_blocks(dE_in), hb = hid / 16, ob = de / 16;
   if (hid % 32 != 0 || de % 16 != 0) return -1;
 #define CASE(IB, HB, OB) \
   if (ib == IB && hb == HB && ob == OB) return launch_mlp<IB, HB, OB, false>(a, st);
