@@ -140,3 +140,40 @@ def test_native_projector_rejects_bad_input_without_side_effects():
     assert L.scgg_projector_export(h, 1, lab.ctypes.data, blk.ctypes.data) == 0
     assert blk[0, 2] == 1 and blk.sum() == 1 and lab[0, 1] == 1 and lab[1, 0] == 1 and lab.astype(bool).sum() == 2
     L.scgg_projector_destroy(h)
+
+
+@pytest.mark.parametrize("name,cls", CASES)
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_native_engine_equals_python_engine_on_random_trajectories(name, cls, seed):
+    """Beyond the recorded trajectories: denser proposals, more steps, other sizes; the C++ engine and the readable
+    restatement must agree on every step, on the blocked tables and on the repair counter."""
+    rs = np.random.RandomState(100 + seed)
+    C = 5 if "atm" in name or name == "tree" else 14
+    n_nodes = [int(v) for v in rs.randint(1, 12, size=7)]
+    n = max(n_nodes)
+    mask = torch.arange(n)[None, :] < torch.tensor(n_nodes)[:, None]
+    B = len(n_nodes)
+    pair = (mask[:, :, None] & mask[:, None, :]) & ~torch.eye(n, dtype=torch.bool)[None]
+    outs = {}
+    for engine in ("native", "python"):
+        r2 = np.random.RandomState(200 + seed)
+        shuffle_rng = np.random.RandomState(300 + seed)
+        lab = torch.where(pair, 0, -1).to(torch.int8)
+        z_T = PlaceHolder(X=mask[..., None].float(), E=None, y=torch.zeros(B, 0), node_mask=mask, pos=torch.zeros(B, n, 3))
+        z_T._labels = lab
+        proj = cls(z_T, torch.device("cpu"), engine=engine, rng=shuffle_rng)
+        steps = []
+        for s in range(16):
+            prop = np.triu(r2.randint(1, C, (B, n, n)) * (r2.rand(B, n, n) < 0.15), 1)
+            prop = torch.from_numpy(prop + prop.transpose(0, 2, 1)).to(torch.int8)
+            cd = torch.from_numpy(r2.randint(0, C, (B, n, n, 3))).to(torch.int8)
+            cd = torch.where(torch.triu(torch.ones(n, n, dtype=torch.bool), 1)[None, :, :, None], cd, cd.transpose(1, 2))
+            lab = torch.where((lab == 0) & pair, prop, lab).contiguous()
+            proj.project_labels(lab, cd.contiguous())
+            steps.append(lab.clone())
+        fixer = getattr(proj, "top_cow_validity_check_and_fix_obj", None)
+        outs[engine] = (steps, proj.blocked_edges, fixer.counter if fixer is not None else 0)
+    for a, b in zip(outs["native"][0], outs["python"][0]):
+        assert torch.equal(a, b)
+    assert outs["native"][1] == outs["python"][1] and outs["native"][2] == outs["python"][2]
+    assert int((outs["native"][0][-1] > 0).sum()) > 0
