@@ -114,7 +114,10 @@ __device__ __forceinline__ void y_add_layernorm(float* y, const float* t, int ld
 }
 
 __global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
-  __builtin_amdgcn_s_setprio(3);   // a short latency chain beside the edge kernel's waves on the same SIMDs: issue first
+  // Default wave priority: the y round has ~130 us of slack beside the edge kernel (it must be done before node kernel l
+  // waits for the FiLM vectors); at s_setprio(3) it finished no sooner that mattered and cost the edge kernel 10 us per
+  // launch (0.280 -> 0.270 ms, 452 -> 454.6 graphs/s)
+  __builtin_amdgcn_s_setprio(0);
   extern __shared__ __attribute__((aligned(16))) float ysm[];
   const int tid = threadIdx.x;
   const int dy = a.dy, kcat = a.kcat;
