@@ -102,12 +102,15 @@ def laplacian_for_eigh(E, node_mask):
     return L * m[:, None, :] * m[:, :, None] + pad
 
 
-def eigen_features(E, node_mask, num_eigenvectors=5, num_eigenvalues=9, eigh=torch.linalg.eigh):
+def eigen_features(E, node_mask, num_eigenvectors=5, num_eigenvalues=9, eigh=torch.linalg.eigh, pad_noise=None):
     """EigenFeatures.compute_features (:87-112) -> evalue_feat[B,1+num_eigenvalues], evector_feat[B,n,1+num_eigenvectors].
 
-    Deviation (documented, SURVEY.md Hard parts): the reference adds randn to padded entries before
-    taking the mode (:171-173) so that 0 cannot win; here the mode is taken over valid nodes only
-    (ties -> smallest value), which is the same whenever a valid value occurs at least twice."""
+    ``pad_noise`` [B,n]: the ``torch.randn(bs, n)`` the reference adds on the PADDED slots before taking the mode of the
+    rounded first eigenvector (:171-173, "to prevent 0 from becoming the mode"); None draws it from torch's global
+    generator exactly as the reference does (so ``torch.manual_seed`` reproduces a reference run).  The padded values
+    are distinct with probability 1, so they only matter when no valid value occurs twice: then ``torch.mode`` returns the
+    smallest of all n values, valid or not.  The HIP kernel takes the mode over the valid nodes only, i.e. the limit in
+    which a padded value is never the smallest."""
     B, n = node_mask.shape
     m = node_mask.float()
     L = laplacian_for_eigh(E, node_mask)
@@ -122,12 +125,11 @@ def eigen_features(E, node_mask, num_eigenvectors=5, num_eigenvalues=9, eigh=tor
     first_ev = torch.gather(evp, 1, idx)
     evalue_feat = torch.cat([ncc[:, None].to(ev.dtype), first_ev], dim=1)
 
-    v0 = torch.round(vec[:, :, 0], decimals=3)
-    not_lcc = torch.zeros(B, n)
-    for b in range(B):
-        vals = v0[b][node_mask[b]]
-        mode = torch.mode(vals).values if vals.numel() else torch.tensor(0.0)
-        not_lcc[b] = ((v0[b] != mode) & node_mask[b]).float()
+    if pad_noise is None:
+        pad_noise = torch.randn(B, n)                                          # :171
+    v0 = torch.round(vec[:, :, 0], decimals=3) * m + pad_noise * (1 - m)       # :169-172
+    mode = torch.mode(v0, dim=1).values                                        # :173
+    not_lcc = ((v0 != mode[:, None]) & node_mask).float()                      # :174-175
     ext = int(ncc.max()) + num_eigenvectors - n
     vp = torch.cat([vec, torch.zeros(B, n, ext)], dim=2) if ext > 0 else vec
     idx = (torch.arange(num_eigenvectors)[None, None] + ncc[:, None, None]).expand(-1, n, -1)
@@ -136,11 +138,11 @@ def eigen_features(E, node_mask, num_eigenvectors=5, num_eigenvalues=9, eigh=tor
 
 
 def extra_features(X, E, node_mask, max_n_nodes, num_degree=10, max_degree=10, cycle_features=True,
-                   eigenfeatures=True, num_eigenvectors=5, num_eigenvalues=9):
+                   eigenfeatures=True, num_eigenvectors=5, num_eigenvalues=9, pad_noise=None, eigh=torch.linalg.eigh):
     """ExtraFeatures.__call__ (:60-77) -> (X_extra, E_extra, y_extra)."""
     nfrac = node_mask.sum(dim=1, keepdim=True) / max_n_nodes
     x, y, e = adjacency_features(X, E, node_mask, num_degree, max_degree, cycle_features)
     if eigenfeatures:
-        evl, evc = eigen_features(E, node_mask, num_eigenvectors, num_eigenvalues)
+        evl, evc = eigen_features(E, node_mask, num_eigenvectors, num_eigenvalues, eigh=eigh, pad_noise=pad_noise)
         return torch.cat([x, evc], dim=-1), e, torch.cat([nfrac, y, evl], dim=1)
     return x, e, torch.cat([nfrac, y], dim=1)

@@ -518,8 +518,169 @@ def gen_sample_plan(R):
     save("f13_sample_plan", names=np.array([c[0] for c in cases]), **arrays)
 
 
+def _spanning_tree_labels(n_nodes, n, C, seed):
+    """Airway-like clean graphs: a random spanning tree over the valid nodes, labels in 1..C-1."""
+    rs = np.random.RandomState(seed)
+    lab = np.zeros((len(n_nodes), n, n), dtype=np.int64)
+    for b, k in enumerate(n_nodes):
+        for v in range(1, int(k)):
+            u = rs.randint(0, v)
+            lab[b, u, v] = lab[b, v, u] = rs.randint(1, C)
+    return torch.from_numpy(lab)
+
+
+def gen_training(R):
+    """F10: one training step of the reference (diffusion_model_discrete_3d.py:215-239): apply_noise (noise_model.py:187-233)
+    under injected uniforms, GraphTransformer forward in train mode with dropout 0, TrainLoss (train_metrics.py:25-85,
+    lambda_train = [1, 2, 5, 0]), loss.backward().  Stored: the clean graphs, t, the uniforms, z_t, logits, the loss and
+    every parameter gradient (tiny dims).  torchmetrics is absent here, so ``Metric`` is a minimal stand-in with the
+    published forward semantics (the value of the CURRENT batch: reset, update, compute, then merge into the running
+    state); the arithmetic inside update / compute is the reference's own (abstract_metrics.py:77-93)."""
+    import torch.nn as nn
+
+    class Metric(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+            self._defaults = {}
+
+        def add_state(self, name, default, dist_reduce_fx=None):
+            self._defaults[name] = default
+            setattr(self, name, default.clone())
+
+        def reset(self):
+            for k, v in self._defaults.items():
+                setattr(self, k, v.clone())
+
+        def forward(self, *a, **k):
+            keep = {n: getattr(self, n) for n in self._defaults}
+            self.reset()
+            self.update(*a, **k)
+            val = self.compute()
+            for n in self._defaults:
+                setattr(self, n, keep[n] + getattr(self, n).detach())
+            return val
+    sys.modules["torchmetrics"].Metric = Metric
+    sys.modules["torchmetrics"].MeanSquaredError = Metric
+    sys.modules["torchmetrics"].MetricCollection = Metric
+    for mod in ("src.ConStruct.metrics.train_metrics", "src.ConStruct.metrics.abstract_metrics"):
+        sys.modules.pop(mod, None)
+    from src.ConStruct.metrics import train_metrics as TL
+    feed = _UniformFeed()
+    for name, tr, C, n_nodes, dims, n_layers in (("atm_tiny", "absorbing_edges", 5, [11, 6, 9, 2], fx.TINY_DIMS, 2),
+                                                 ("cow_marg_tiny", "marginal", 6, [8, 12, 5], fx.TINY_DIMS, 2)):
+        em = torch.tensor([0.7, 0.1, 0.1, 0.05, 0.03, 0.02]) if tr == "marginal" else None
+        nm = _noise_model(R, tr, "cow", C, 4, e_marg=em)
+        mask = fx.ragged_mask(n_nodes)
+        B, n = mask.shape
+        lab = _spanning_tree_labels(n_nodes, n, C, 300 + C)
+        E0 = fx.one_hot_edges(lab, mask, C)
+        # the reference's dense_data (utils.to_dense): zero rows on padding AND on the diagonal (mask()), one-hot elsewhere
+        X0 = mask[..., None].float()
+        g = torch.Generator().manual_seed(910 + C)
+        pos = torch.randn(B, n, 3, generator=g)
+        dense = R.U.PlaceHolder(X=X0, charges=torch.zeros(B, n, 0), E=E0, y=torch.zeros(B, 0), node_mask=mask, pos=pos)
+        t_int = torch.randint(1, 501, (B, 1), generator=g)
+        ux = torch.rand(B * n, 1, generator=g).numpy()
+        u0 = torch.rand(B * n * n, 1, generator=g).numpy()
+        feed.queue = [ux, u0]
+        feed.install()
+        try:
+            z_t = nm.apply_noise(dense, t_int=t_int)
+        finally:
+            feed.remove()
+        assert not feed.queue
+        model = R.TM.GraphTransformer(n_layers=n_layers, input_dims=fx.dims_ns(1, C, 1), hidden_mlp_dims=dims["hidden_mlp_dims"],
+                                      hidden_dims=dims["hidden_dims"], output_dims=fx.dims_ns(1, C, 0), dropout=0.0).train()
+        # quirk: GraphTransformer does not hand its ``dropout`` to the layers (transformer_model.py:309-317), which keep the
+        # default 0.1 (:35) whatever the config says; "dropout 0" therefore needs the modules switched off one by one
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        sd = fx.make_state_dict(shapes, seed=70 + C)
+        model.load_state_dict(sd)
+        inp = SimpleNamespace(X=z_t.X.float(), E=z_t.E.float(), y=z_t.t.float(), node_mask=mask)
+        pred = model(inp)
+        loss_fn = TL.TrainLoss(lambda_train=[1, 2, 5, 0])
+        loss, _ = loss_fn(masked_pred=pred, masked_true=dense, log=False)
+        loss.backward()
+        grads = {}
+        for k, p in model.named_parameters():          # big tensors (lin_y1/2: dy x 2048): head + norm + sum only
+            assert p.grad is not None, k
+            if p.grad.numel() <= 4096:
+                grads["grad/" + k] = p.grad
+            else:
+                grads["gradhead/" + k] = p.grad.flatten()[:1024]
+                grads["gradstat/" + k] = torch.stack([p.grad.double().norm(), p.grad.double().sum()])
+        save(f"f10_training_{name}", node_mask=mask, C=C, transition=tr, n_layers=n_layers, labels0=lab, t_int=t_int, pos=pos,
+             ux=ux.reshape(B, n), u0=u0.reshape(B, n, n), zt_E=z_t.E, zt_X=z_t.X, zt_pos=z_t.pos, zt_t=z_t.t,
+             logits_E=pred.E.detach(), logits_X=pred.X.detach(), loss=loss.detach(), sd_seed=70 + C,
+             e_marginals=em if em is not None else np.zeros(0), **grads)
+        print(f"{name}: loss {float(loss.detach()):.6f}")
+
+
+def gen_extra_features_large(R):
+    """F5b: AdjacencyFeatures + EigenFeatures beyond n = 32 (SURVEY configs 3 / 5): n_max = 40 (CoW classes) and
+    n_max = 256 (ATM classes, tree-like graphs with a few extra edges so that cycles exist).  Only what does not depend
+    on the eigenvector basis is stored in full; E features as the labels they derive from are large, so the reachability /
+    Adamic-Adar tensor is stored for a strided subset of rows."""
+    cfg = SimpleNamespace(model=SimpleNamespace(eigenfeatures=True, num_degree=10, max_degree=10, cycle_features=True,
+                                                num_eigenvectors=5, num_eigenvalues=9))
+    for name, n_nodes, C, dens, seed in (("n40", [40, 33, 37, 21], 14, 0.06, 53), ("n256", [256, 201], 5, None, 54)):
+        mask = fx.ragged_mask(n_nodes)
+        B, n = mask.shape
+        if dens is not None:
+            labs = fx.random_labels(mask, C, dens, seed)
+        else:
+            labs = _spanning_tree_labels(n_nodes, n, C, seed)
+            rs = np.random.RandomState(seed)
+            for b, k in enumerate(n_nodes):            # a few chords -> cycles of several lengths
+                for _ in range(12):
+                    i, j = rs.randint(0, k, 2)
+                    if i != j:
+                        labs[b, i, j] = labs[b, j, i] = rs.randint(1, C)
+        E = fx.one_hot_edges(labs, mask, C)
+        X = mask[..., None].float()
+        data = SimpleNamespace(X=X, E=E, y=torch.zeros(B, 0), node_mask=mask)
+        ef = R.EF.ExtraFeatures(cfg, SimpleNamespace(max_n_nodes=n))
+        ax, ay, ae = ef.adj_features(data)
+        torch.manual_seed(seed)
+        evl, evc = ef.eigenfeatures.compute_features(data)
+        rows = np.arange(0, n, 1 if n <= 40 else 9)
+        save(f"f5_extra_features_{name}", labels=labs.to(torch.int8), node_mask=mask, C=C, adj_x=ax, adj_y=ay, rows=rows,
+             adj_e_rows=ae[:, rows].to(torch.float16) if n > 40 else ae[:, rows], eval_feat=evl, evec_feat=evc,
+             kdiag=torch.stack([torch.diagonal(ef.adj_features.k[i], dim1=-2, dim2=-1) for i in range(10)]))
+
+
+def gen_graph_transformer_large(R):
+    """F3b: GraphTransformer forward at ATM size (n_max = 256, vessel dims, 5 layers; SURVEY config 3's forward).  The output
+    E is [B,256,256,5]: a strided subset of rows is stored, plus the per-graph sums over all entries."""
+    torch.manual_seed(36)
+    dims, in_dims, out_dims, n_layers, n_nodes, seed = fx.VESSEL_DIMS, (1, 5, 1), (1, 5, 0), 5, [256, 203], 36
+    mask = fx.ragged_mask(n_nodes)
+    B, n = mask.shape
+    model = R.TM.GraphTransformer(n_layers=n_layers, input_dims=fx.dims_ns(*in_dims), hidden_mlp_dims=dims["hidden_mlp_dims"],
+                                  hidden_dims=dims["hidden_dims"], output_dims=fx.dims_ns(*out_dims), dropout=0.1).eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(fx.make_state_dict(shapes, seed=seed))
+    lab = _spanning_tree_labels(n_nodes, n, 5, seed)
+    E = fx.one_hot_edges(lab, mask, 5)
+    X = mask[..., None].float()
+    y = torch.tensor([[0.37], [0.81]])
+    with torch.no_grad():
+        out = model(SimpleNamespace(X=X, E=E, y=y, node_mask=mask))
+    rows = np.arange(0, n, 17)
+    save("f3_gt_vessel_n256", labels=lab.to(torch.int8), node_mask=mask, y=y, n_layers=n_layers, seed=seed, rows=rows,
+         outE_rows=out.E[:, rows], outX=out.X, outE_sum=out.E.double().sum(dim=(1, 2)),
+         outE_abs_sum=out.E.double().abs().sum(dim=(1, 2)),
+         shape_keys=np.array(sorted(shapes)), shape_vals=np.array([",".join(map(str, shapes[k])) for k in sorted(shapes)]))
+
+
 def main():
     R = import_reference()
+    extra = {"training": gen_training, "extra_large": gen_extra_features_large, "gt_large": gen_graph_transformer_large}
+    if len(sys.argv) == 2 and sys.argv[1] in extra:
+        return extra[sys.argv[1]](R)
     if sys.argv[1:] == ["projector"]:
         return gen_projector(R)
     if sys.argv[1:] == ["sample_plan"]:
@@ -534,6 +695,9 @@ def main():
     gen_placeholder(R)
     gen_projector(R)
     gen_sample_plan(R)
+    gen_training(R)
+    gen_extra_features_large(R)
+    gen_graph_transformer_large(R)
 
 
 if __name__ == "__main__":

@@ -183,8 +183,16 @@ class NoiseModel:
         ph._labels, ph._cands = labels, cands
         return ph
 
-    def sample_limit_dist(self, node_mask, generator=None, with_onehot=True):
-        """reference :248-340.  For absorbing / absorbing_edges the limit is the all-"no edge" graph (:253-261)."""
+    @staticmethod
+    def _fresh_rng(step=0):
+        """A stream nobody has used yet, seeded from torch's global generator (which the reference consumes directly):
+        two calls without an explicit ``rng`` never draw the same uniforms, and ``torch.manual_seed`` reproduces them."""
+        return Rng(seed=int(torch.randint(0, 2 ** 31 - 1, (1,))), step=step)
+
+    def sample_limit_dist(self, node_mask, generator=None, with_onehot=True, rng: Rng = None):
+        """reference :248-340.  For absorbing / absorbing_edges the limit is the all-"no edge" graph (:253-261); for the
+        other transitions z_T is drawn from the marginals with ``rng`` (seed, graph_id_base; the step word is T + 1, which
+        no reverse step uses), default: a fresh stream from torch's global generator."""
         B, n = node_mask.shape
         dev = node_mask.device
         if self.X_classes != 1 or self.charges_classes != 0:
@@ -196,17 +204,35 @@ class NoiseModel:
             cands = torch.zeros(B, n, n, top_k, dtype=torch.int8, device=dev) if top_k > 1 else None
         else:
             prob = self.E_marginals.float().to(dev).expand(B, n, n, -1).contiguous()
-            labels, cands = self.sample_edges_from_probs(prob, node_mask, top_k if top_k > 1 else 0, Rng(seed=0, step=self.T + 1))
+            zr = self._fresh_rng() if rng is None else rng
+            zr = Rng(seed=zr.seed, step=self.T + 1, graph_id_base=zr.graph_id_base)
+            labels, cands = self.sample_edges_from_probs(prob, node_mask, top_k if top_k > 1 else 0, zr)
         t_int = torch.full((B, 1), self.T, dtype=torch.long, device=dev)
         pos = torch.randn(B, n, 3, device=dev, generator=generator)
         if self.node_coord_model is not None:
             pos = self.node_coord_model(pos, node_mask)
-        pos = pos * node_mask[..., None]
-        pos = pos - pos.mean(dim=1, keepdim=True)
+        raw = pos * node_mask[..., None]
         radius = torch.zeros(B, n, n, 1, device=dev)
-        ph = self._to_placeholder(labels, cands, node_mask, t_int, pos, B, radius, with_onehot)
+        ph = self._to_placeholder(labels, cands, node_mask, t_int, self.pos_after_masks(raw, node_mask, 1), B, radius,
+                                  with_onehot)
         ph.t = torch.ones(B, 1, device=dev)
+        ph._pos_raw = raw
         return ph
+
+    @staticmethod
+    def pos_after_masks(raw, node_mask, t: int):
+        """``pos`` after ``t`` applications of PlaceHolder.mask (utils.py:160-164: zero the padded slots, subtract the mean
+        over ALL n slots), in closed form.  The reference applies it once in sample_limit_dist (:340) and once per reverse
+        step (:446), so the frame of a graph with k < n nodes keeps drifting: with S = sum of the valid rows and
+        r = 1 - k/n the valid rows are x_i - (S/k)(1 - r^t) and the padded slots -(S/n) r^(t-1); k = n: centred at once.
+        ``raw``: positions with the padded slots already zero."""
+        k = node_mask.sum(dim=1, keepdim=True).to(raw.dtype)[..., None]            # [B,1,1]
+        n = float(node_mask.shape[1])
+        S = raw.sum(dim=1, keepdim=True)
+        r = 1.0 - k / n
+        ck = torch.where(k > 0, S / k.clamp(min=1.0), torch.zeros_like(S)) * (1.0 - r ** t)
+        pad = -(S / n) * r ** (t - 1)
+        return torch.where(node_mask[..., None], raw - ck, pad.expand_as(raw))
 
     def sample_edges_from_probs(self, prob_E, node_mask, top_k, rng: Rng):
         """E branch of sample_discrete_features (diffusion_utils.py:228-276) on the GPU -> (labels int8, cands int8)."""
@@ -230,7 +256,7 @@ class NoiseModel:
             raise NotImplementedError("node / charge classes beyond the CoW / ATM setting (1 / 0) are not built yet")
         Qtb = self.get_Qt_bar(t_int)
         probE = dense_data.E.float() @ Qtb.E.unsqueeze(1)
-        rng = rng or Rng(seed=int(torch.randint(0, 2 ** 31, (1,))), step=0)
+        rng = rng or self._fresh_rng()
         labels, _ = self.sample_edges_from_probs(probE, dense_data.node_mask, 0, rng)
         ph = self._to_placeholder(labels, None, dense_data.node_mask, t_int, dense_data.pos, B, dense_data.radius)
         ph.y = dense_data.y
@@ -267,8 +293,8 @@ class NoiseModel:
             raise _lib.ScggError("sample_zs_from_zt_and_pred needs cfg.model.top_k (the reference asserts on extra_info, :433)")
         node_mask = z_t.node_mask.contiguous()
         B, n = node_mask.shape
-        if rng is None:
-            rng = Rng(seed=getattr(self, "_default_seed", 0), step=int(s_int.flatten()[0]))
+        if rng is None:      # the reference draws from the global torch RNG here: a fresh stream per call
+            rng = self._fresh_rng()
         labels_t = self._labels_of(z_t, self.E_classes)
         t32 = z_t.t_int.reshape(B).to(torch.int32).contiguous()
         s32 = s_int.reshape(B).to(torch.int32).contiguous()
@@ -276,7 +302,11 @@ class NoiseModel:
         radius = None
         if getattr(pred, "radius", None) is not None:                      # :415-420
             radius = ((labels_s > 0) * pred.radius.squeeze(-1)).unsqueeze(-1)
-        z_s = self._to_placeholder(labels_s, cands_s, node_mask, s_int, z_t.pos, z_t.y.shape[0], radius, with_onehot)
+        pos = z_t.pos
+        if pos is not None:                                                # .mask() of the new PlaceHolder (:446)
+            pos = pos * node_mask[..., None]
+            pos = pos - pos.mean(dim=1, keepdim=True)
+        z_s = self._to_placeholder(labels_s, cands_s, node_mask, s_int, pos, z_t.y.shape[0], radius, with_onehot)
         return z_s
 
 

@@ -330,6 +330,13 @@ class _Projector:
             rows = torch.nn.functional.one_hot(e[:, 3], z_s.E.shape[-1]).to(z_s.E.dtype)
             z_s.E[e[:, 0], e[:, 1], e[:, 2]] = rows
             z_s.E[e[:, 0], e[:, 2], e[:, 1]] = rows
+            # our sampler's PlaceHolder also carries the int8 state the next step reads (noise_model._labels_of): keep it
+            # in step with the edited one-hot, or the next reverse step would start from the pre-projection graph
+            lab = getattr(z_s, "_labels", None)
+            if lab is not None:
+                v = e[:, 3].to(lab.dtype)
+                lab[e[:, 0], e[:, 1], e[:, 2]] = v
+                lab[e[:, 0], e[:, 2], e[:, 1]] = v
         self.z_t_adj = _adj_of(z_s, self.binary)
 
     # ---- state route ----------------------------------------------------------------------------------------

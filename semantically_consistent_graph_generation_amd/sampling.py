@@ -162,11 +162,12 @@ class DiscreteSampler:
         nm = self.noise_model
         gen = torch.Generator(device=dev).manual_seed(seed)
         on_state = hasattr(projector, "project_labels")      # our projector.py classes take the int8 state directly
-        z_T = nm.sample_limit_dist(node_mask, generator=gen, with_onehot=projector is not None and not on_state)
+        z_T = nm.sample_limit_dist(node_mask, generator=gen, with_onehot=projector is not None and not on_state,
+                                   rng=Rng(seed=seed, graph_id_base=graph_id_base))
         st = self._alloc_state(node_mask)
         cur = 0
         st["labels"][0].copy_(z_T._labels)
-        pos = z_T.pos
+        pos, pos_raw = z_T.pos, z_T._pos_raw     # pos follows the reference's per-step re-centring (pos_after_masks)
         s_values = list(reversed(range(0, self.T, self.faster_sampling)))
         if steps is not None:
             s_values = s_values[:steps]
@@ -181,6 +182,7 @@ class DiscreteSampler:
                                  charges=torch.zeros(N, kc, n, dtype=torch.long, device=dev),
                                  pos=torch.zeros(N, kc, n, 3, device=dev))
         t = self.T
+        n_done = 0
         for s in s_values:
             labels_t = st["labels"][cur]
             inp = self._build_inputs(st, labels_t, node_mask, t)
@@ -197,16 +199,20 @@ class DiscreteSampler:
                 proj.project_labels(st["labels"][cur], st["cands"][cur])
             elif proj is not None:   # any other host-side projector: reference types in, in-place edit of z_s.E
                 s_int = torch.full((B, 1), s, dtype=torch.long, device=dev)
-                z_s = nm._to_placeholder(st["labels"][cur], st["cands"][cur], node_mask, s_int, pos, B)
+                z_s = nm._to_placeholder(st["labels"][cur], st["cands"][cur], node_mask, s_int,
+                                         nm.pos_after_masks(pos_raw, node_mask, 2 + n_done), B)
                 proj.project(z_s)
                 z_s._labels = None
                 st["labels"][cur].copy_(NoiseModel._labels_of(z_s, nm.E_classes))
             t = s
+            n_done += 1
             if chains is not None and (s * N) % self.T == 0:                               # :666-677
+                pos = nm.pos_after_masks(pos_raw, node_mask, 1 + n_done)
                 w = N - 1 - (s * N) // self.T
                 cX, cE = self._collapse_labels(st["labels"][cur][:kc], node_mask[:kc])
                 chains.X[w], chains.E[w], chains.pos[w] = cX, cE, pos[:kc]
         labels = st["labels"][cur]
+        pos = nm.pos_after_masks(pos_raw, node_mask, 1 + n_done)
         if return_state and chains is None:
             return labels, st["cands"][cur], node_mask, pos
         X, E = self._collapse_labels(labels, node_mask)

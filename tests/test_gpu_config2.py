@@ -1,0 +1,251 @@
+"""GPU parity at the sizes and in the mode the benchmark runs:
+  * the ConStruct-dims denoiser at BASELINE configs[1] size (B = 512, n <= 32): a slice of graphs against the oracle at
+    1e-4, invariants on the whole batch;
+  * a reverse chain WITH extra features against an oracle chain, step by step: adjacency and eigenvalue features,
+    logits, sampled labels and candidates.  Eigenvector / LCC columns are basis-dependent inside degenerate eigenspaces
+    in the reference itself (torch.linalg.eigh: LAPACK here, cuSOLVER / rocSOLVER on a GPU): they are compared where the
+    spectrum is simple, checked as eigenvectors everywhere, and handed to the oracle's denoiser as the device produced
+    them, so that everything downstream of them is pinned;
+  * apply_noise against the reference fixture F10;
+  * the reference-style loop (sample_zs_from_zt + projector.project on the PlaceHolder) against the state route.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import denoiser as D
+from oracle import extra_features as XF
+from oracle import fixtures as fx
+from oracle import noise as N
+from test_host_logic import make_noise_model
+
+pytestmark = pytest.mark.gpu
+NU = dict(x=1, c=1, e=1, y=1, e_small=1, e_mid=1, e_large=1)
+
+
+def PAD(B, n):
+    """Noise on the padded slots (extra_features.py:171) that never wins the mode: distinct values above every valid one
+    -- the limit the HIP kernel implements (mode over the valid nodes)."""
+    return 1e6 + torch.arange(n, dtype=torch.float32)[None].expand(B, n)
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy()
+    assert a.shape == b.shape and np.isfinite(a).all()
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def test_denoiser_at_config2_size():
+    """B = 512, n_i ~ U[12,32], ConStruct dims, 5 layers, CoW widths with extra features (10, 25, 43) -> (1, 14, 0)."""
+    from semantically_consistent_graph_generation_amd.transformer_model import GraphTransformer, model_input
+    dims = fx.CONSTRUCT_DIMS
+    gen = torch.Generator().manual_seed(1234)
+    nn_ = torch.randint(12, 33, (512,), generator=gen)
+    nn_[0] = 32
+    mask = fx.ragged_mask(nn_, 32)
+    B, n = mask.shape
+    model = GraphTransformer(5, fx.dims_ns(10, 25, 43), dims["hidden_mlp_dims"], dims["hidden_dims"], fx.dims_ns(1, 14, 0)).eval()
+    sd = fx.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 33)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    X = torch.randn(B, n, 10, generator=gen)
+    E = torch.randn(B, n, n, 25, generator=gen)
+    E = 0.5 * (E + E.transpose(1, 2))
+    E[..., :14] = fx.one_hot_edges(fx.random_labels(mask, 14, 0.1, 7), mask, 14)
+    y = torch.randn(B, 43, generator=gen)
+    out = model(model_input(X.cuda(), E.cuda(), y.cuda(), mask.cuda()))
+    torch.cuda.synchronize()
+    oE, oX = out.E.cpu(), out.X.cpu()
+    assert bool(torch.isfinite(oE).all()) and torch.equal(oE, oE.transpose(1, 2))
+    dead = ~(mask[:, :, None] & mask[:, None, :]) | torch.eye(n, dtype=torch.bool)[None]
+    assert float(oE[dead].abs().max()) == 0.0 and float(oX[~mask].abs().max()) == 0.0
+    sl = torch.tensor([0, 1, 2, 255, 256, 509, 510, 511])          # first / middle / last graphs of the batch
+    dd = D.DenoiserDims(5, dims["hidden_dims"]["n_head"], 1, 14, 0)
+    with torch.no_grad():
+        rX, _, rE, _ = D.graph_transformer_forward(sd, dd, X[sl], E[sl], y[sl], mask[sl])
+    assert rel_err(oE[sl], rE) < 1e-4 and rel_err(oX[sl], rX) < 1e-4
+    # a graph's output does not depend on its batch: the same 8 graphs alone
+    out8 = model(model_input(X[sl].cuda(), E[sl].cuda(), y[sl].cuda(), mask[sl].cuda()))
+    assert rel_err(out8.E, oE[sl]) < 2e-6
+
+
+def make_cow(n_layers=2, T=12, max_n=16, seed=5):
+    from semantically_consistent_graph_generation_amd.extra_features import ExtraFeatures
+    from semantically_consistent_graph_generation_amd.sampling import DiscreteSampler
+    from semantically_consistent_graph_generation_amd.transformer_model import GraphTransformer
+    C = 14
+    c = SimpleNamespace(model=SimpleNamespace(num_degree=10, max_degree=10, cycle_features=True, num_eigenvectors=5,
+                                              num_eigenvalues=9, eigenfeatures=True))
+    ef = ExtraFeatures(c, SimpleNamespace(max_n_nodes=max_n))
+    dims = fx.TINY_DIMS
+    model = GraphTransformer(n_layers, fx.dims_ns(10, 25, 43), dims["hidden_mlp_dims"], dims["hidden_dims"], fx.dims_ns(1, C, 0)).eval()
+    sd = fx.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed)
+    model.load_state_dict(sd)
+    nm = make_noise_model("absorbing_edges", C, T=T, top_k=4)
+    return DiscreteSampler(model.cuda(), nm, ef), nm, ef, sd
+
+
+def test_chain_with_extra_features_matches_oracle_chain():
+    """12 reverse steps, extra features ON (the benchmarked mode), B = 5 ragged graphs."""
+    from semantically_consistent_graph_generation_amd.noise_model import Rng
+    C, T, top_k, seed, base, max_n = 14, 12, 4, 77, 9, 16
+    sampler, nm, ef, sd = make_cow(T=T, max_n=max_n)
+    n_nodes = [13, 6, 10, 1, 16]
+    m = fx.ragged_mask(n_nodes)
+    B, n = m.shape
+    md = m.cuda()
+    live = (m[:, :, None] & m[:, None, :]) & ~torch.eye(n, dtype=torch.bool)[None]
+    tr = N.Transition(N.Schedule(T, "absorbing_edges", NU), [1.0], np.ones(C, np.float32) / C)
+    dd = D.DenoiserDims(2, fx.TINY_DIMS["hidden_dims"]["n_head"], 1, C, 0)
+    lab = torch.where(live, 0, -1)
+    Xn = m[..., None].float()
+    simple_cols = degenerate_cols = 0
+    for step, s in enumerate(reversed(range(T))):
+        t = s + 1
+        E = fx.one_hot_edges(lab.clamp(min=0), m, C)
+        # ---- device features of this state (PlaceHolder route: what forward() of the reference sees)
+        z = SimpleNamespace(X=Xn.cuda(), E=E.cuda(), y=torch.zeros(B, 0, device="cuda"), node_mask=md,
+                            charges=torch.zeros(B, n, 0, device="cuda"), t=torch.full((B, 1), t / T, device="cuda"))
+        dev = ef(z)
+        dX, dE, dy = dev.X.cpu(), dev.E.cpu(), dev.y.cpu()
+        # ---- oracle features
+        ox, oy, oe = XF.adjacency_features(Xn, E, m)
+        L = XF.laplacian_for_eigh(E, m)
+        w, V = torch.linalg.eigh(L)
+        oevl, oevc = XF.eigen_features(E, m, pad_noise=PAD(B, n))
+        np.testing.assert_allclose(dX[..., :3].numpy(), ox.numpy(), atol=1e-6)
+        np.testing.assert_allclose(dE.numpy(), oe.numpy(), rtol=1e-5, atol=1e-6)
+        ky = oy.shape[1]
+        np.testing.assert_allclose(dy[:, 0].numpy(), np.asarray(n_nodes) / max_n, atol=1e-7)
+        np.testing.assert_allclose(dy[:, 1:1 + ky].numpy(), oy.numpy(), atol=1e-6)
+        np.testing.assert_allclose(dy[:, 1 + ky:].numpy(), oevl.numpy(), rtol=1e-4, atol=3e-5)      # eigenvalue features
+        # eigenvector columns: column k is eigenvector ncc + k; simple eigenvalue -> equal up to sign; always an eigenvector
+        ncc = oevl[:, 0].long()
+        for b in range(B):
+            nv = n_nodes[b]
+            wb = w[b, :nv] if nv else w[b, :0]
+            for k in range(5):
+                idx = int(ncc[b]) + k
+                col = dX[b, :, 4 + k]
+                if idx >= nv:
+                    assert float(col.abs().max()) == 0.0                       # out of range: the padding value
+                    continue
+                lam = float(wb[idx])
+                gap = min([abs(lam - float(x)) for i, x in enumerate(wb) if i != idx] or [1.0])
+                res = (L[b] @ col - lam * col).abs().max()
+                assert float(res) < 2e-4 * max(1.0, float(L[b, :nv, :nv].abs().max())) and abs(float(col.norm()) - 1) < 1e-4
+                if gap > 1e-2:
+                    ref = oevc[b, :, 1 + k]
+                    sgn = torch.sign((col * ref).sum())
+                    np.testing.assert_allclose((col * sgn).numpy(), ref.numpy(), atol=5e-4)
+                    simple_cols += 1
+                else:
+                    degenerate_cols += 1
+            if int(ncc[b]) == 1:                                               # connected: the LCC flag is determined
+                np.testing.assert_array_equal(dX[b, :, 3].numpy(), oevc[b, :, 0].numpy())
+        # ---- denoiser: device logits vs the oracle's on [oracle adjacency + eigenvalue | DEVICE eigenvector] features
+        pred = sampler.forward(z)
+        Xin = torch.cat([Xn, ox, dX[..., 3:]], dim=-1)
+        Ein = torch.cat([E, oe], dim=-1)
+        yin = torch.cat([torch.tensor(n_nodes)[:, None] / max_n, oy, oevl, torch.full((B, 1), t / T)], dim=1)
+        with torch.no_grad():
+            _, _, logits, _ = D.graph_transformer_forward(sd, dd, Xin, Ein, yin, m)
+        assert rel_err(pred.E, logits) < 1e-4, f"logits at step {step}"
+        # ---- reverse step: oracle on its own logits, device state route over the whole chain so far
+        u0, uk = N.philox_edge_uniforms(seed, s, base + np.arange(B), n, top_k)
+        r = N.reverse_step(tr, Xn, E, torch.zeros(B, n, 1), logits, m, torch.full((B, 1), t), torch.full((B, 1), s),
+                           np.zeros((B, n), np.float32), u0, uk)
+        lab = r["labels_E"]
+        dl, dc, _, _ = sampler.sample_batch(n_nodes, seed=seed, graph_id_base=base, steps=step + 1, return_state=True)
+        assert int((dl.cpu().long() != lab).sum()) == 0, f"labels after step {step}"
+        assert int(((dc.cpu().long() * live[..., None]) != r["extra_info"]).sum()) == 0
+    assert int((lab > 0).sum()) > 0 and simple_cols > 20 and degenerate_cols > 0
+
+
+def test_limit_state_eigenvectors_are_the_identity_basis():
+    """z_T of the absorbing chain is the empty graph: L = 0 on the valid nodes (fully degenerate).  The Jacobi kernel
+    applies no rotation to a diagonal matrix, so its basis is the identity -- which is also what LAPACK returns for a
+    diagonal input; the two agree on z_T although nothing forces them to."""
+    sampler, nm, ef, sd = make_cow()
+    n_nodes = [7, 12, 3]
+    m = fx.ragged_mask(n_nodes)
+    B, n = m.shape
+    E = fx.one_hot_edges(torch.zeros(B, n, n, dtype=torch.long), m, 14)
+    z = SimpleNamespace(X=m[..., None].float().cuda(), E=E.cuda(), y=torch.zeros(B, 0, device="cuda"), node_mask=m.cuda())
+    dev = ef(z)
+    oevl, oevc = XF.eigen_features(E, m, pad_noise=PAD(B, n))
+    np.testing.assert_allclose(dev.y.cpu()[:, -10:].numpy(), oevl.numpy(), atol=1e-6)
+    np.testing.assert_array_equal(dev.X.cpu()[..., 3:].numpy(), oevc.numpy())
+
+
+@pytest.mark.parametrize("name", ["f10_training_atm_tiny", "f10_training_cow_marg_tiny"])
+def test_apply_noise_matches_reference(name):
+    """noise_model.py:187-233 under the fixture's uniforms: z_t.E bit-exact, pos / t as the reference's .mask()."""
+    from semantically_consistent_graph_generation_amd.noise_model import Rng
+    from semantically_consistent_graph_generation_amd.placeholder import PlaceHolder
+    g = load_golden(name)
+    C = int(g["C"])
+    m = torch.from_numpy(g["node_mask"])
+    tr = str(g["transition"])
+    nm = make_noise_model(tr, C, T=500, top_k=4, e_marg=g["e_marginals"] if g["e_marginals"].size else None)
+    E0 = fx.one_hot_edges(torch.from_numpy(g["labels0"]), m, C)
+    dense = PlaceHolder(X=m[..., None].float().cuda(), charges=torch.zeros(*m.shape, 0, device="cuda"), E=E0.cuda(),
+                        y=torch.zeros(m.shape[0], 0, device="cuda"), node_mask=m.cuda(), pos=torch.from_numpy(g["pos"]).cuda())
+    z = nm.apply_noise(dense, t_int=torch.from_numpy(g["t_int"]).cuda(), rng=Rng(u0=torch.from_numpy(g["u0"]).cuda()))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(z.E.cpu().numpy(), g["zt_E"])
+    np.testing.assert_array_equal(z.X.cpu().numpy(), g["zt_X"])
+    np.testing.assert_allclose(z.pos.cpu().numpy(), g["zt_pos"], atol=1e-6)
+    np.testing.assert_allclose(z.t.cpu().numpy(), g["zt_t"], rtol=2e-7)        # t_int / T: the device divide is within 1 ulp
+    assert z.E.dtype == torch.float32 and z.t_int.dtype == torch.long
+    # without an explicit stream two calls draw different noise (the reference consumes the global RNG)
+    torch.manual_seed(0)
+    a = nm.apply_noise(dense, t_int=torch.from_numpy(g["t_int"]).cuda())._labels
+    b = nm.apply_noise(dense, t_int=torch.from_numpy(g["t_int"]).cuda())._labels
+    torch.manual_seed(0)
+    c = nm.apply_noise(dense, t_int=torch.from_numpy(g["t_int"]).cuda())._labels
+    assert not torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_reference_style_loop_with_projector_equals_state_route():
+    """The loop an unmodified caller writes (diffusion_model_discrete_3d.py:653-663): z_s = sample_zs_from_zt(z_t, s);
+    projector.project(z_s); z_t = z_s -- with nothing resetting the cached int8 state in between."""
+    from semantically_consistent_graph_generation_amd import projector as PJ
+    from semantically_consistent_graph_generation_amd.noise_model import Rng
+    sampler, nm, ef, sd = make_cow(T=10)
+    n_nodes = [14, 6, 11, 1]
+    seed = 4
+
+    def via_state(z_T, dev):
+        return PJ.CoWProjector(z_T, dev)
+    via_state.project_labels = True
+    np.random.seed(5)
+    a, _, mask, _ = sampler.sample_batch(n_nodes, seed=seed, projector=via_state, return_state=True)
+    free, _, _, _ = sampler.sample_batch(n_nodes, seed=seed, return_state=True)
+    np.random.seed(5)
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    z = nm.sample_limit_dist(mask, generator=gen, rng=Rng(seed=seed))
+    proj = PJ.CoWProjector(z, torch.device("cuda"))
+    for s in reversed(range(nm.T)):
+        s_int = torch.full((len(n_nodes), 1), s, dtype=torch.long, device="cuda")
+        z = sampler.sample_zs_from_zt(z, s_int, Rng(seed=seed, step=s))
+        proj.project(z)
+    lab = nm._labels_of(z, 14)
+    assert torch.equal(lab, a) and not torch.equal(a, free)
+    E = z.E.cpu()
+    assert torch.equal(E.argmax(-1)[E.sum(-1) > 0], a.cpu().long()[E.sum(-1) > 0])          # one-hot and int8 state agree
+
+
+def test_limit_dist_noise_depends_on_seed_and_graph_id():
+    """Non-absorbing transitions draw z_T from the marginals: the stream follows (seed, global graph id)."""
+    from semantically_consistent_graph_generation_amd.noise_model import Rng
+    nm = make_noise_model("marginal", 5, T=20, top_k=4, e_marg=np.array([0.6, 0.1, 0.1, 0.1, 0.1], np.float32))
+    m = fx.ragged_mask([9, 9, 9, 9]).cuda()
+    a = nm.sample_limit_dist(m, rng=Rng(seed=1))._labels
+    b = nm.sample_limit_dist(m, rng=Rng(seed=2))._labels
+    c = nm.sample_limit_dist(m[:2], rng=Rng(seed=1, graph_id_base=2))._labels
+    assert not torch.equal(a, b) and torch.equal(a[2:], c) and not torch.equal(a[0], a[1])
+    assert not torch.equal(nm.sample_limit_dist(m)._labels, nm.sample_limit_dist(m)._labels)

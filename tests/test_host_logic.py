@@ -170,3 +170,23 @@ def test_load_lightning_checkpoint_key_mapping(tmp_path):
         load_lightning_checkpoint(make(), bad)
     with pytest.raises(KeyError):
         load_lightning_checkpoint(make(), {"state_dict": {"other.w": torch.ones(1)}})
+
+
+def test_pos_follows_the_reference_recentring_per_mask_call():
+    """utils.py:160-164 applied once in sample_limit_dist (:340) and once per reverse step (:446): the closed form used by
+    the sampling loop equals t iterated PlaceHolder.mask calls (pos was centred only once)."""
+    from semantically_consistent_graph_generation_amd.noise_model import NoiseModel
+    from semantically_consistent_graph_generation_amd.placeholder import PlaceHolder
+    torch.manual_seed(0)
+    B, n = 5, 9
+    m = fx.ragged_mask(torch.tensor([9, 4, 1, 6, 0]), n)
+    x = torch.randn(B, n, 3)
+    ph = PlaceHolder(X=None, E=None, y=None, pos=x.clone(), node_mask=m)
+    raw = x * m[..., None]
+    for t in range(1, 40):
+        ph.mask()
+        np.testing.assert_allclose(NoiseModel.pos_after_masks(raw, m, t).numpy(), ph.pos.numpy(), atol=2e-6)
+    g = load_golden("f11_placeholder")
+    gm = torch.from_numpy(g["node_mask"])
+    np.testing.assert_allclose(NoiseModel.pos_after_masks(torch.from_numpy(g["pos"]) * gm[..., None], gm, 1).numpy(), g["mpos"],
+                               atol=1e-6)

@@ -187,3 +187,91 @@ def test_philox_known_answer():
     pi = np.array([[0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344]], np.uint32)
     out = N.philox4x32_10(pi, np.array([0xA4093822, 0x299F31D0], np.uint32))[0]
     assert [hex(int(v)) for v in out] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+# ----------------------------------------------------------------------------------- round 2: larger graphs, training
+def test_lcc_indicator_follows_the_reference_noise_rule():
+    """extra_features.py:169-175 with the reference's own randn draw (same torch seed as the generator): the indicator is
+    pinned on every graph whose first eigenvector is determined (connected graphs); and the rule itself -- the mode runs
+    over all n slots, padded ones carrying noise -- on a single-node graph, where the noise decides."""
+    g = load_golden("f5_extra_features")
+    torch.manual_seed(51)
+    _, evc = XF.eigen_features(T(g["E"]), T(g["node_mask"]))
+    conn = [0, 1, 2, 3, 4, 7, 8]
+    np.testing.assert_array_equal(evc[..., 0].numpy()[conn], g["evec_feat"][..., 0][conn])
+    m = fx.ragged_mask([1], 4)
+    E = torch.zeros(1, 4, 4, 3)
+    lo = XF.eigen_features(E, m, pad_noise=torch.tensor([[0.0, -5.0, 1.5, 2.0]]))[1][0, 0, 0]   # a padded value is the smallest
+    hi = XF.eigen_features(E, m, pad_noise=torch.tensor([[0.0, 5.0, 6.0, 7.0]]))[1][0, 0, 0]
+    assert float(lo) == 1.0 and float(hi) == 0.0
+
+
+@pytest.mark.parametrize("name", ["f5_extra_features_n40", "f5_extra_features_n256"])
+def test_extra_features_beyond_32_nodes(name):
+    g = load_golden(name)
+    m, C = T(g["node_mask"]), int(g["C"])
+    E = fx.one_hot_edges(T(g["labels"]).long(), m, C)
+    x, y, e = XF.adjacency_features(m[..., None].float(), E, m)
+    close(x, g["adj_x"], 1e-6, 1e-6)
+    close(y, g["adj_y"], 1e-6, 1e-6)
+    close(e[:, g["rows"]], g["adj_e_rows"].astype(np.float32), 2e-3 if m.shape[1] > 40 else 1e-5, 1e-6)   # n256 rows are fp16
+    k = XF.adjacency_powers(XF.adjacency(E), 10)
+    close(torch.stack([torch.diagonal(k[i], dim1=-2, dim2=-1) for i in range(10)]), g["kdiag"], 0, 0)     # exact walk counts
+    evl, evc = XF.eigen_features(E, m)
+    close(evl, g["eval_feat"], 1e-4, 2e-5)
+    assert evc.shape == g["evec_feat"].shape
+
+
+def test_graph_transformer_n256_rows():
+    g = load_golden("f3_gt_vessel_n256")
+    m = T(g["node_mask"])
+    E = fx.one_hot_edges(T(g["labels"]).long(), m, 5)
+    sd = fx.make_state_dict(golden_shapes(g), int(g["seed"]))
+    dd = D.DenoiserDims(int(g["n_layers"]), fx.VESSEL_DIMS["hidden_dims"]["n_head"], 1, 5, 0)
+    with torch.no_grad():
+        oX, _, oE, _ = D.graph_transformer_forward(sd, dd, m[..., None].float(), E, T(g["y"]), m)
+    close(oE[:, g["rows"]], g["outE_rows"], 1e-4, 2e-5)
+    close(oX, g["outX"], 1e-4, 2e-5)
+    close(oE.double().sum(dim=(1, 2)), g["outE_sum"], 1e-4, 1e-2)
+
+
+@pytest.mark.parametrize("name", ["f10_training_atm_tiny", "f10_training_cow_marg_tiny"])
+def test_training_step_loss_and_gradients(name):
+    """apply_noise + forward (train mode, dropout 0) + TrainLoss + backward of the reference (F10)."""
+    from oracle import training as TR
+    g = load_golden(name)
+    m, C = T(g["node_mask"]), int(g["C"])
+    nu = dict(x=1, c=1, e=1, y=1, e_small=1, e_mid=1, e_large=1)
+    em = g["e_marginals"] if g["e_marginals"].size else np.ones(C, np.float32) / C
+    tr = N.Transition(N.Schedule(500, str(g["transition"]), nu), [1.0], em)
+    E0 = fx.one_hot_edges(T(g["labels0"]), m, C)
+    X0 = m[..., None].float()
+    zt = TR.apply_noise(tr, X0, E0, m, T(g["t_int"]), g["ux"], g["u0"], pos=T(g["pos"]))
+    np.testing.assert_array_equal(zt["E_t"].numpy(), g["zt_E"])
+    np.testing.assert_array_equal(zt["X_t"].numpy(), g["zt_X"])
+    close(zt["pos"], g["zt_pos"], 1e-6, 1e-6)
+    close(zt["t"], g["zt_t"], 0, 0)
+    shapes = {k[5:]: v.shape for k, v in g.items() if k.startswith("grad/")}
+    shapes.update({k[9:]: (16, 2048) if k.endswith("lin_y2.weight") else (2048, 16) for k in g if k.startswith("gradhead/")})
+    from semantically_consistent_graph_generation_amd.transformer_model import GraphTransformer
+    ref_shapes = {k: tuple(v.shape) for k, v in GraphTransformer(int(g["n_layers"]), fx.dims_ns(1, C, 1), fx.TINY_DIMS["hidden_mlp_dims"],
+                                                                  fx.TINY_DIMS["hidden_dims"], fx.dims_ns(1, C, 0)).state_dict().items()}
+    assert {k: tuple(v) for k, v in shapes.items()} == ref_shapes
+    sd = fx.make_state_dict(ref_shapes, int(g["sd_seed"]))
+    dd = D.DenoiserDims(int(g["n_layers"]), fx.TINY_DIMS["hidden_dims"]["n_head"], 1, C, 0)
+    loss, grads, _, logits = TR.training_step(sd, dd, tr, X0, E0, m, T(g["t_int"]), g["ux"], g["u0"])
+    close(logits, g["logits_E"], 1e-4, 1e-5)
+    close(loss, g["loss"], 1e-5, 1e-6)
+    for k in ref_shapes:
+        if "grad/" + k in g:
+            close(grads[k], g["grad/" + k], 1e-3, 2e-6)
+        else:
+            close(grads[k].flatten()[:1024], g["gradhead/" + k], 1e-3, 2e-6)
+            close(torch.stack([grads[k].double().norm(), grads[k].double().sum()]), g["gradstat/" + k], 1e-4, 1e-5)
+
+
+def test_dropout_stream_is_a_pure_function_of_its_counter():
+    from oracle import training as TR
+    a = TR.dropout_keep(7, 3, 4096, 0.3)
+    assert np.array_equal(a, TR.dropout_keep(7, 3, 4096, 0.3)) and not np.array_equal(a, TR.dropout_keep(7, 4, 4096, 0.3))
+    assert abs(a.mean() - 0.7) < 0.03 and np.array_equal(a[:100], TR.dropout_keep(7, 3, 100, 0.3))

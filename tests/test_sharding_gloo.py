@@ -75,3 +75,43 @@ def test_two_gloo_ranks_reproduce_the_single_process_result(tmp_path, n_graphs):
     want = _fake_chain(range(n_graphs), n, seed)
     assert got["wall"] == 1.5 + (world - 1)
     assert got["full"].dtype == torch.int8 and torch.equal(got["full"], want)
+
+
+# ------------------------------------------------------------------------------------------ bench.py's own launcher
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, env=None):
+    import json
+    import subprocess
+    import sys
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub-gloo"] + args, env=e, capture_output=True,
+                       text=True, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_gpus_flag_starts_its_own_ranks_and_gathers(tmp_path):
+    """`python bench.py --gpus 2` without torch.distributed.run: two fresh child ranks (gloo rehearsal with a stub chain),
+    barrier-bracketed timing, n_gpus = 2 in the line, and the gathered labels are those of one process that owns every
+    global graph id."""
+    two, one = str(tmp_path / "two.pt"), str(tmp_path / "one.pt")
+    rc, line, err = _bench(["--gpus", "2", "--batch", "6", "--steps", "2", "--warmup", "1", "--dump-labels", two])
+    assert rc == 0, err
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["graphs_gathered"] == 12
+    assert line["ms_per_step"] >= 20.0            # the stub's rank 1 sleeps 20 ms per chain: MAX over ranks, not rank 0's time
+    rc, line1, err = _bench(["--gpus", "1", "--batch", "12", "--steps", "2", "--warmup", "1", "--dump-labels", one])
+    assert rc == 0, err
+    assert line1["n_gpus"] == 1
+    a, b = torch.load(two, weights_only=True), torch.load(one, weights_only=True)
+    assert a.dtype == torch.int8 and torch.equal(a, b)
+    assert line["config"]["gathered_labels_checksum"] == line1["config"]["gathered_labels_checksum"]
+
+
+def test_bench_refuses_a_world_that_contradicts_gpus():
+    rc, line, err = _bench(["--gpus", "4", "--batch", "2", "--steps", "1", "--warmup", "0"],
+                           env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
+    assert rc != 0 and line is None and "WORLD_SIZE=1" in err
