@@ -363,16 +363,7 @@ static int in_blocks(int dE_in) {
 #define SCGG_MLP_IN_CASES CASE(1, 8, 4) CASE(2, 8, 4) CASE(3, 8, 4) CASE(4, 8, 4) CASE(1, 2, 2) CASE(2, 2, 2)   /* (ceil(in_E/16), hid_E/16, de/16) */
 #define SCGG_MLP_OUT_CASES CASE(4, 8, 1) CASE(4, 8, 2) CASE(2, 2, 1)   /* (de/16, hid_E/16, ceil(C/16)) */
 
-static int n_cu_cached() {
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
-    n_cu = prop.multiProcessorCount;
-  }
-  return n_cu;
-}
+static int n_cu_cached() { return device_cu_count(); }
 
 long long edge_mlp_img_f4(int K1, int N1, int N2) {
   const int ib = in_blocks(K1), hb = N1 / 16, ob = (N2 + 15) / 16;
@@ -403,21 +394,18 @@ template <int IB, int HB, int OB, bool OUT>
 static int launch_mlp(const EdgeMlpUnitArgs& a, hipStream_t st) {
   const int n_cu = n_cu_cached();
   if (n_cu <= 0) return -2;
-  static bool attr_set = false;
+  static LdsAttrOnce attr_f32, attr_x3;
+  LdsAttrOnce* attr = &attr_f32;
   void (*kern)(EdgeMlpUnitArgs) = edge_mlp_unit_kernel<IB, HB, OB, OUT>;
   size_t lds = (size_t)MlpGeom<IB, HB, OB>::IMG_F4 * 16;
   if constexpr (IB % 2 == 0) {
     if (mlp_x3(IB)) {
       kern = edge_mlp_unit_x3_kernel<IB, HB, OB, OUT>;
       lds = (size_t)MlpGeomX3<IB, HB, OB>::IMG_F4 * 16;
+      attr = &attr_x3;
     }
   }
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess)
-      return -2;
-    attr_set = true;
-  }
+  if (set_max_dynamic_lds(*attr, reinterpret_cast<const void*>(kern), lds)) return -2;
   hipLaunchKernelGGL(kern, dim3(2 * n_cu), dim3(512), lds, st, a);
   return 0;
 }

@@ -1223,41 +1223,26 @@ int launch_edge_unit_pack(const EdgeUnitPackArgs& a, int dx, int de, int ffe, hi
 
 template <int NXB, int NEB, int NFB>
 static int launch_one(const EdgeLayerArgs& a, int n_cu, hipStream_t st) {
-  static bool attr_set = false;
+  static LdsAttrOnce attr_x3, attr_f32;
   if (edge_x3()) {
     constexpr int NW = SCGG_X3_WAVES;
     auto kern = edge_unit_layer_x3_kernel<NXB, NEB, NFB, NW>;
     const size_t lds = UnitGeomX3<NXB, NEB, NFB>::lds_bytes(NW);
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-          hipSuccess)
-        return -2;
-      attr_set = true;
-    }
+    if (set_max_dynamic_lds(attr_x3, reinterpret_cast<const void*>(kern), lds)) return -2;
     hipLaunchKernelGGL(kern, dim3(n_cu), dim3(NW * 64), lds, st, a);        // one persistent workgroup per CU
   } else {
     constexpr int NW = SCGG_UNIT_WAVES;
     auto kern = edge_unit_layer_kernel<NXB, NEB, NFB, NW>;
     const size_t lds = UnitGeom<NXB, NEB, NFB>::lds_bytes(NW);
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-          hipSuccess)
-        return -2;
-      attr_set = true;
-    }
+    if (set_max_dynamic_lds(attr_f32, reinterpret_cast<const void*>(kern), lds)) return -2;
     hipLaunchKernelGGL(kern, dim3(n_cu * (16 / NW)), dim3(NW * 64), lds, st, a);
   }
   return 0;
 }
 
 int launch_edge_layer(const EdgeLayerArgs& a, int dx, int de, int ffe, hipStream_t st) {
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -2;
-    n_cu = prop.multiProcessorCount;
-  }
+  const int n_cu = device_cu_count();
+  if (n_cu <= 0) return -2;
 #define CASE(NXB, NEB, NFB) \
   if (dx == 32 * NXB && de == 32 * NEB && ffe == 32 * NFB) return launch_one<NXB, NEB, NFB>(a, n_cu, st);
   SCGG_UNIT_CASES

@@ -10,6 +10,34 @@ const char* last_error();
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+// ---- per-DEVICE launch set-up caches (a process may drive more than one GPU: nothing below is per process)
+constexpr int MAX_DEVICES = 64;
+inline int current_device() {
+  int d = -1;
+  return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < MAX_DEVICES) ? d : -1;
+}
+inline int device_cu_count() {   // CUs of the current device (-1 on failure)
+  static int n_cu[MAX_DEVICES] = {};
+  const int d = current_device();
+  if (d < 0) return -1;
+  if (n_cu[d] == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) != hipSuccess) return -1;
+    n_cu[d] = prop.multiProcessorCount;
+  }
+  return n_cu[d];
+}
+struct LdsAttrOnce { bool done[MAX_DEVICES] = {}; };   // one per kernel instantiation (a function-local static)
+inline int set_max_dynamic_lds(LdsAttrOnce& once, const void* kern, size_t lds) {
+  const int d = current_device();
+  if (d < 0) return -2;
+  if (!once.done[d]) {
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+    once.done[d] = true;
+  }
+  return 0;
+}
+
 struct EdgeMlpPackArgs {  // raw (torch layout) two-layer MLP -> LDS image of edge_mlp_unit_kernel
   const float* W1;        // [N1, K1]
   const float* b1;

@@ -568,14 +568,9 @@ __global__ __launch_bounds__(512) void node_linear_x3_kernel(NodeLinearArgs a, c
 template <int KC>
 static int launch_linear_x3(const NodeLinearArgs& a, const f32x4* W3, int M, hipStream_t st) {
   constexpr size_t lds = (size_t)3 * 48 * (32 * KC + 8) * 2;
-  static bool attr_set = false;
+  static LdsAttrOnce attr;
   auto kern = node_linear_x3_kernel<KC>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess)
-      return -2;
-    attr_set = true;
-  }
+  if (set_max_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds)) return -2;
   hipLaunchKernelGGL(kern, dim3((M + 47) / 48), dim3(512), lds, st, a, W3);
   return 0;
 }
@@ -592,16 +587,11 @@ static bool node_x3() {
 
 template <int DXB, int FXB>
 static int launch_one(const NodeLayerArgs& a, int M, hipStream_t st) {
-  static bool attr_set = false;
+  static LdsAttrOnce attr_x3, attr_f32;
   const bool x3 = node_x3() && a.W3_xout && a.W3_lin1 && a.W3_lin2;
   auto kern = x3 ? node_layer_x3_kernel<DXB, FXB> : node_layer_kernel<DXB, FXB>;
   const size_t lds = x3 ? NodeGeomX3<DXB, FXB>::LDS_BYTES : NodeGeom<DXB, FXB>::LDS_BYTES;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess)
-      return -2;
-    attr_set = true;
-  }
+  if (set_max_dynamic_lds(x3 ? attr_x3 : attr_f32, reinterpret_cast<const void*>(kern), lds)) return -2;
   const int rows_per_tile = x3 ? NodeGeomX3<DXB, FXB>::TR : 32;
   hipLaunchKernelGGL(kern, dim3((M + rows_per_tile - 1) / rows_per_tile), dim3(512), lds, st, a);
   return 0;
