@@ -67,6 +67,20 @@ int scgg_denoiser_forward(scgg_denoiser* h, const float* X, const float* E, cons
                           int32_t B, int32_t n, float* out_X, float* out_E, float* out_y, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* The same forward for callers that cannot allocate and have no workspace to pass (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Scratch = a file-scope
+ * `static __device__` array of scgg_denoiser_static_scratch_bytes() = 32 MiB per GPU (held until the process ends; its
+ * per-device address is looked up with hipGetSymbolAddress in scgg_denoiser_finalize, else on the first call on a device);
+ * shapes whose workspace_bytes(B, n) exceed it are rejected with an error, nothing is allocated or freed by the call.
+ * Every call on one GPU shares that GPU's array: calls that overlap on one GPU (two streams, two handles) race; calls
+ * ordered on one stream do not.  The buffer keeps the previous call's contents, which no kernel of the forward reads
+ * before writing (same contract as `workspace` above: contents irrelevant).  Results are bit-identical to
+ * scgg_denoiser_forward. */
+int scgg_denoiser_forward_static(scgg_denoiser* h, const float* X, const float* E, const float* y,
+                                 const uint8_t* node_mask, int32_t B, int32_t n, float* out_X, float* out_E,
+                                 float* out_y, void* stream);
+size_t scgg_denoiser_static_scratch_bytes(void);
+
 /* The engine's second stream (a hipStream_t, owned by the handle; NULL + scgg_last_error on failure).  The forward
  * runs every consumer of its X and y arguments on this stream and only the edge path on the caller's, so work that
  * PRODUCES X or y may be enqueued on it before scgg_denoiser_forward is called (after making it wait for whatever that

@@ -34,6 +34,8 @@ SIGNATURES = {
     "scgg_denoiser_refresh": (C.c_int, [_vp, _vp]),
     "scgg_denoiser_workspace_bytes": (_sz, [_vp, _i32, _i32]),
     "scgg_denoiser_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "scgg_denoiser_forward_static": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "scgg_denoiser_static_scratch_bytes": (_sz, []),
     "scgg_denoiser_forward_hidden": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "scgg_denoiser_side_stream": (C.c_void_p, [_vp]),
     "scgg_denoiser_profile": (C.c_int, [_vp, _i32, _i32]),

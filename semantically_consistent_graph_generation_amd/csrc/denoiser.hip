@@ -16,6 +16,12 @@
 #include "kernels.h"
 #include "sampling.h"
 
+// Scratch of the allocation-free entry point scgg_denoiser_forward_static (include/scgg.h): the forward's workspace as a
+// file-scope device array.  Every GPU the library runs on holds its own copy until the process ends; host code never
+// uses the array's name as an address, only the per-device pointer hipGetSymbolAddress returned (static_scratch()).
+#define SCGG_STATIC_SCRATCH_BYTES (32u << 20)
+static __device__ __align__(256) unsigned char scgg_static_scratch[SCGG_STATIC_SCRATCH_BYTES];
+
 namespace scgg {
 
 static thread_local char g_err[512] = "";
@@ -33,6 +39,21 @@ static int check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail("%s: %s", what, hipGetErrorString(e));
   return 0;
+}
+
+// device address of this GPU's copy of scgg_static_scratch: looked up once per device, with that device current
+static void* static_scratch() {
+  constexpr int MAX_DEV = 64;
+  static void* ptr[MAX_DEV] = {};
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) { fail("static scratch: no current device"); return nullptr; }
+  if (ptr[dev] == nullptr) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scgg_static_scratch));
+    if (e != hipSuccess || p == nullptr) { fail("hipGetSymbolAddress(scgg_static_scratch): %s", hipGetErrorString(e)); return nullptr; }
+    ptr[dev] = p;
+  }
+  return ptr[dev];
 }
 
 static inline int pad32(int v) { return (v + 31) / 32 * 32; }
@@ -770,6 +791,9 @@ int scgg_denoiser_finalize(scgg_denoiser* h, void* stream) {
   if (hipMalloc(reinterpret_cast<void**>(&h->arena), h->arena_bytes) != hipSuccess)
     return fail("hipMalloc of %zu bytes for the packed weights failed", h->arena_bytes);
   if (build(h, true, static_cast<hipStream_t>(stream))) return -1;
+  // set-up work the compute calls must not do: the second stream and its events, and this device's scratch address
+  if (ensure_streams(h)) return -1;
+  if (static_scratch() == nullptr) return -1;
   h->finalized = true;
   return 0;
 }
@@ -792,6 +816,25 @@ int scgg_denoiser_forward(scgg_denoiser* h, const float* X, const float* E, cons
   return run_forward(h, X, E, y, node_mask, B, n, h ? h->c.n_layers : 0, false, out_X, out_E, out_y, workspace,
                      workspace_bytes, static_cast<hipStream_t>(stream));
 }
+
+int scgg_denoiser_forward_static(scgg_denoiser* h, const float* X, const float* E, const float* y,
+                                 const uint8_t* node_mask, int32_t B, int32_t n, float* out_X, float* out_E,
+                                 float* out_y, void* stream) {
+  if (!X || !E || !y || !node_mask || !out_E) return fail("forward_static: null tensor");
+  if (!h || !h->finalized) return fail("forward_static: denoiser not finalized");
+  if (h->c.out_X > 0 && !out_X) return fail("forward_static: out_X is NULL");
+  if (B <= 0 || n <= 0) return fail("forward_static: bad batch shape B=%d n=%d", B, n);
+  const size_t need = carve(h->c, B, n, nullptr).bytes;
+  if (need > (size_t)SCGG_STATIC_SCRATCH_BYTES)
+    return fail("forward_static: B=%d n=%d needs %zu bytes of scratch, the static buffer holds %zu (use scgg_denoiser_forward "
+                "with a caller workspace)", B, n, need, (size_t)SCGG_STATIC_SCRATCH_BYTES);
+  void* ws = static_scratch();          // per-device pointer from hipGetSymbolAddress, never the array's name
+  if (ws == nullptr) return -1;
+  return run_forward(h, X, E, y, node_mask, B, n, h->c.n_layers, false, out_X, out_E, out_y, ws,
+                     (size_t)SCGG_STATIC_SCRATCH_BYTES, static_cast<hipStream_t>(stream));
+}
+
+size_t scgg_denoiser_static_scratch_bytes(void) { return (size_t)SCGG_STATIC_SCRATCH_BYTES; }
 
 int scgg_denoiser_forward_hidden(scgg_denoiser* h, const float* X, const float* E, const float* y,
                                  const uint8_t* node_mask, int32_t B, int32_t n, int32_t n_run_layers, float* hid_X,
