@@ -84,14 +84,25 @@ int main(int argc, char** argv) {
   printf("B=%d rows=%d units=%d pairs=%lld  %.1f us/launch  %.1f TFLOP/s (algorithmic, valid pairs)\n", B, rows_valid, n_units, pairs,
          ms * 1e3, pairs * 131072.0 / (ms * 1e-3) / 1e12);
 #ifdef SCGG_STAMP
-  unsigned long long st[8][96];
-  CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(scgg::g_stamps), sizeof(st)));
-  const int NP = 3 + 6 * 8 + 4 + 4;
-  const unsigned long long t0 = st[0][0];
-  for (int k = 0; k < NP; ++k) {
-    printf("%2d:", k);
-    for (int w = 0; w < 8; ++w) printf(" %8lld", (long long)(st[w][k] - t0));
-    printf("\n");
+  {
+    static unsigned long long st[4][16][scgg::STAMP_SEGS];
+    CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(scgg::g_stamps), sizeof(st)));
+    const char* names[14] = {"unit set-up", "S0 e_mul/e_add", "barrier S0", "S1 FiLM+e_out+dma wait", "barrier S1",
+                             "S2 dma issue+softmax", "barrier S2", "F0 (LN1)+linE1", "barrier F0", "F1 relu+linE2+wait",
+                             "barrier F1", "F2 dma (+LN2,store,loads)", "barrier F2", "-"};
+    for (int wg = 0; wg < 4; ++wg) {
+      const double iters = (double)st[wg][0][15];
+      printf("workgroup slot %d: %g rounds; cycles per round, waves 0..11 then mean\n", wg, iters);
+      double tot_mean = 0;
+      for (int k = 0; k < 14; ++k) {
+        printf("%-26s", names[k]);
+        double m = 0;
+        for (int w = 0; w < 12; ++w) { const double v = st[wg][w][k] / iters; printf(" %6.0f", v); m += v / 12; }
+        printf("  | %7.0f\n", m);
+        tot_mean += m;
+      }
+      printf("%-26s %7.0f cycles per round (mean over waves)\n", "total", tot_mean);
+    }
   }
 #endif
   return 0;

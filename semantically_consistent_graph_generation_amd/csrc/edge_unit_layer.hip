@@ -834,6 +834,9 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
     // ================================================================== channel-block phases
 #pragma unroll 1
     for (int cb = 0; cb < NXB; ++cb) {
+      // A wave with a unit has consumed its K / V loads, which are younger than its share of this phase's weight DMA, so
+      // that share has landed; a wave WITHOUT a unit waits for nothing on its own and must retire its share here.
+      if (!active) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (cb + 1 < NXB)
         stage_phase_unit<G::CB_F4, NW>(a.phase_img + (size_t)(cb + 1) * G::PH_F4, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
@@ -950,6 +953,7 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
     // accumulated directly onto E (which holds the LN1 output, i.e. the residual).
 #pragma unroll
     for (int f = 0; f < G::NFF; ++f) {
+      if (!active || f > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // f > 0: no younger load was consumed since
       __syncthreads();
       if (f + 1 < G::NFF)
         stage_phase_unit<G::FF_F4, NW>(a.phase_img + (size_t)(NXB + f + 1) * G::PH_F4, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
@@ -1010,6 +1014,512 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
     un = nx;
     mk = nmk;
   }
+}
+
+// =========================================================================================================
+// The x3 layer with the three waves of every SIMD one SUB-STEP apart ("x3s": staggered).
+//
+// Why.  Cycle stamps of the x3 kernel above (profiles/r02_edge_stamps_before.txt): its three waves per SIMD walk each
+// phase in lockstep -- all in the e_mul / e_add MFMAs, then all in the FiLM / softmax VALU -- so the matrix pipe is busy
+// ~40 % of a phase and the VALU tail of the slowest wave is exposed at the phase barrier (20 % of a round is barrier
+// wait).  Fewer DMA issuers or a register prefetch of the next unit did not help (the first moves the imbalance, the
+// second spills).
+//
+// How.  A phase is cut into three sub-steps with a barrier after each:
+//   channel block cb : S0 = K/V requests + e_mul / e_add (48 MFMAs)   S1 = FiLM, split, e_out slice (24 MFMAs)
+//                      S2 = attention statistics + partial stores + this wave's share of the weight DMA
+//   FFN half phase h : F0 = (h = 0: residual, LayerNorm 1, split) + linE1 for 32 hidden channels (24 MFMAs)
+//                      F1 = ReLU, split, their columns of linE2 (24 MFMAs)
+//                      F2 = DMA share (+ after the last half phase: LayerNorm 2, E store, next unit's requests)
+// Wave group g = wave / 4 (one wave of every SIMD) starts g barriers late, so that at any time a SIMD holds one wave in
+// S0, one in S1 and one in S2: matrix work of one wave beside the VALU work of the others, in every slot.
+//
+// Weight images: three LDS buffers (image q lives in buffer q mod 3).  While group 0 is in phase q the buffers hold
+// q - 1 (still read by the groups behind), q and q + 1.  Image q + 2 goes into the buffer of q - 1, whose last reader is
+// group 2 in S1 of phase q - 1, i.e. the slot BEFORE group 0's S1 of phase q: groups 0 and 1 issue their share of image
+// q + 2 in their S2 of phase q, group 2 in its S2 of phase q - 1 (as "its phase + 3"); every wave retires its DMA with an
+// explicit vmcnt(0) at the end of its next S1 / F1, at least one barrier before group 0 reads the image in S0 of phase
+// q + 2.  All FFN phases are half phases (<= the size of a channel-block image), so three buffers + the row vectors fit:
+// 3 x 37.9 KB + 36 KB = 147 KB at ConStruct dims (13 KB stay free for the y kernel that runs beside this one).
+// =========================================================================================================
+template <int NXB, int NEB, int NFB>
+struct UnitGeomX3S {
+  static constexpr int DX = 32 * NXB, DE = 32 * NEB, FFE = 32 * NFB;
+  static constexpr int IBE = DE / 16, QE = NEB;
+  static constexpr int B_CB = 4 * QE + IBE;                  // e_mul, e_add (2 row blocks x QE chunks each), e_out slice
+  static constexpr int B_FH = 2 * QE + IBE;                  // linE1 rows of 32 hidden channels, their columns of linE2
+  static constexpr int BMAX = B_CB > B_FH ? B_CB : B_FH;
+  static constexpr int BIAS_F4 = 64;
+  static constexpr int CB_F4 = BIAS_F4 + B_CB * 192, FH_F4 = BIAS_F4 + B_FH * 192;
+  static constexpr int PH_F4 = BIAS_F4 + BMAX * 192;
+  static constexpr int NPH = NXB + NFB;                      // phases per unit
+  static constexpr int NW = 12;                              // three groups of four waves
+  static constexpr size_t lds_bytes() { return (size_t)3 * PH_F4 * 16 + (size_t)NW * 3 * DX * 4; }
+};
+
+// Phase images of the staggered kernel: channel-block phases as in edge_unit_pack_x3_kernel; FFN half phase h:
+//   linE1: for q, for ob = 0,1: rows 32h+16ob, cols 32q | linE2: for ob = 0..IBE-1: rows 16ob, cols 32h..32h+31;
+//   biases: [0,32) linE1 bias of the 32 hidden channels, [64,64+DE) linE2 bias
+template <int NXB, int NEB, int NFB>
+__global__ __launch_bounds__(512) void edge_unit_pack_x3s_kernel(EdgeUnitPackArgs a) {
+  using G = UnitGeomX3S<NXB, NEB, NFB>;
+  constexpr int DX = G::DX, DE = G::DE, FFE = G::FFE, IBE = G::IBE, QE = G::QE;
+  const int ph = blockIdx.x;
+  u32x4* img = reinterpret_cast<u32x4*>(a.img) + (size_t)ph * G::PH_F4;
+  for (int idx = threadIdx.x; idx < G::PH_F4; idx += blockDim.x) {
+    u32x4 out = {0u, 0u, 0u, 0u};
+    if (idx >= G::BIAS_F4) {
+      const int bi = idx - G::BIAS_F4;
+      const int t = bi / 192, term = (bi % 192) >> 6, l = bi & 63;
+      const float* W = nullptr;
+      int row0 = 0, col0 = 0, K = 0;
+      if (ph < NXB) {
+        const int cb = ph;
+        if (t < 4 * QE) {
+          W = t < 2 * QE ? a.W_mul : a.W_add;
+          const int rem = t % (2 * QE);
+          row0 = 32 * cb + 16 * (rem & 1); col0 = 32 * (rem >> 1); K = DE;
+        } else if (t < 4 * QE + IBE) {
+          W = a.W_out; row0 = 16 * (t - 4 * QE); col0 = 32 * cb; K = DX;
+        }
+      } else {
+        const int h = ph - NXB;
+        if (t < 2 * QE) { W = a.W_ff1; row0 = 32 * h + 16 * (t & 1); col0 = 32 * (t >> 1); K = DE; }
+        else if (t < 2 * QE + IBE) { W = a.W_ff2; row0 = 16 * (t - 2 * QE); col0 = 32 * h; K = FFE; }
+      }
+      if (W != nullptr) {
+        const int o = row0 + (l & 15), g = l >> 4;
+        unsigned hw[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int col = col0 + (i < 4 ? 4 * g + i : 16 + 4 * g + i - 4);
+          float x = W[(size_t)o * K + col];
+          for (int tt = 0; tt < term; ++tt) x = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+          hw[i] = __float_as_uint(x) >> 16;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) out[d] = hw[2 * d] | (hw[2 * d + 1] << 16);
+      }
+    } else {
+      const int fo = idx * 4;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (ph < NXB) {
+        if (fo < 64) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fo < 32 ? a.b_mul[32 * ph + fo + e] + 1.0f : a.b_add[32 * ph + fo - 32 + e];
+        }
+      } else if (fo < 32) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = a.b_ff1[32 * (ph - NXB) + fo + e];
+      } else if (fo >= 64 && fo < 64 + DE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = a.b_ff2[fo - 64 + e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[e] = __float_as_uint(v[e]);
+    }
+    img[idx] = out;
+  }
+}
+
+// ---- diagnostic build only (-DSCGG_STAMP, scripts/probe/edge_layer_probe.hip): per-wave cycle sums of the sub-steps of
+//      a round, read with s_memtime; they leave the kernel through g_stamps, which nothing else reads.
+#ifdef SCGG_STAMP
+constexpr int STAMP_SEGS = 16;
+__device__ unsigned long long g_stamps[4][16][STAMP_SEGS];             // [probed workgroup][wave][segment]
+#define SCGG_STAMP_DECL unsigned long long st_acc[STAMP_SEGS] = {}; unsigned long long st_last = 0; \
+  { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define SCGG_STAMP_AT(k) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+  st_acc[k] += t_ - st_last; st_last = t_; }
+#else
+#define SCGG_STAMP_DECL
+#define SCGG_STAMP_AT(k)
+#endif
+
+// One LDS-DMA piece (64 lanes x 16 B -> 1 KiB of LDS at the wave-uniform byte address `lds_addr`) issued from inline asm,
+// so that hipcc does not see it: with the builtin, every later ds_read of the wave (of ANY LDS address) is preceded by a
+// compiler-inserted vmcnt(0), which drains a weight image requested two phases ahead at the very next sub-step.  The
+// callers retire these pieces themselves (explicit vmcnt waits).  M0 is saved / restored inside the statement
+// (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void lds_dma16(const void* gsrc_lane, unsigned lds_addr_uniform) {
+  unsigned keep;
+  const unsigned dst = lds_addr_uniform;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc_lane), "s"(dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)(unsigned long long)((__attribute__((address_space(3))) const char*)p);
+}
+
+template <int NXB, int NEB, int NFB>
+__global__ __launch_bounds__(768) void edge_unit_layer_x3s_kernel(EdgeLayerArgs a) {
+  using G = UnitGeomX3S<NXB, NEB, NFB>;
+  constexpr int DX = G::DX, DE = G::DE, IBE = G::IBE, NPH = G::NPH, QE = G::QE, NW = G::NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* wbuf = reinterpret_cast<f32x4*>(smem);                        // [3][PH_F4]
+  float* fl = reinterpret_cast<float*>(wbuf + 3 * G::PH_F4);
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  // Lane-derived LDS offsets are recomputed per sub-step from an opaque copy of the lane id (SCGG_LANE: 3 VALU) instead
+  // of living in registers across the unit loop, where they were spilled and their reload (scratch_load + vmcnt(0))
+  // stalled every S0 behind its own K / V requests.
+  // Sub-step barrier: the LDS reads of this wave are back (lgkmcnt) and nothing else is waited for.  __syncthreads() would
+  // also drain vmcnt -- the weight DMA just issued (an LDS-DMA counts as a pending LDS write) -- at every S2 / F2.
+#define SCGG_SUBSTEP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define SCGG_LANE int lane_ = lane; asm volatile("" : "+v"(lane_)); const int g_ = lane_ >> 4; (void)g_;                                           // 0, 1, 2: runs grp sub-steps behind group 0
+  float* vecw = fl + wave * (3 * DX);                                  // Q row / sqrt(df) | y_e_add | y_e_mul+1
+  const int n = a.n;
+  const int nch = (n + 15) >> 4;
+  const int count = *a.unit_count;
+  const int per_iter = NW * gridDim.x;
+  const int full = count / per_iter, rest = count - full * per_iter;
+  const int iters = full + (rest > 0 ? 1 : 0);
+  const int q_last = (rest + (int)gridDim.x - 1) / (int)gridDim.x;
+  auto slot = [&](int it) -> int {                                     // as in the x3 kernel: last partial round spread out
+    if (it < full) return (it * (int)gridDim.x + (int)blockIdx.x) * NW + wave;
+    const int r = (int)blockIdx.x * q_last + wave;
+    return (it == full && wave < q_last && r < rest) ? full * per_iter + r : count;
+  };
+  constexpr float LOG2E = 1.4426950408889634f;
+  typedef const char* cptr;
+  auto ldo = [](cptr base, unsigned off) { return *reinterpret_cast<const f32x4*>(base + off); };
+
+  // this wave's share (pieces wave, wave + 12, ...) of weight image `img` (index in the endless phase sequence) into
+  // buffer img mod 3; the image's size follows from its phase
+  auto stage_share = [&](int img) {
+#ifdef SCGG_ABL_NO_DMA
+    return;
+#endif
+    const int ph = img % NPH;
+    const int pieces = (ph < NXB ? G::CB_F4 : G::FH_F4) / 64;
+    f32x4* buf = wbuf + (img % 3) * G::PH_F4;
+    unsigned voff = (unsigned)(wave * 64 + lane) * 16u;
+    asm volatile("" : "+v"(voff));
+    typedef const __attribute__((address_space(1))) char* gptr;
+    const gptr src = (gptr)(reinterpret_cast<const char*>(a.phase_img + (size_t)ph * G::PH_F4));
+#pragma unroll
+    for (int s = 0; s < (G::PH_F4 / 64 + NW - 1) / NW; ++s) {
+      const int piece = wave + NW * s;                                 // wave-uniform
+      if (piece < pieces)
+        lds_dma16((const char*)src + (size_t)s * NW * 1024 + voff, lds_addr_of(buf + piece * 64));
+    }
+  };
+
+  struct Unit {
+    bool active;
+    int u, row, b, i, j0;
+  };
+  auto unit_of = [&](int uidx) {
+    Unit t;
+    t.active = uidx < count;
+    t.u = t.active ? __builtin_amdgcn_readfirstlane(a.units[uidx]) : 0;
+    t.row = t.u / nch;
+    t.j0 = (t.u - t.row * nch) * 16;
+    t.b = t.row / n;
+    t.i = t.row - t.b * n;
+    return t;
+  };
+  auto mask_byte = [&](const Unit& t) -> int {
+    const int j = t.j0 + p;
+    return (t.active && j < n) ? (int)a.mask[t.b * n + j] : 0;
+  };
+  // The unit's row vectors (Q row | y_e_add | y_e_mul + 1: 3 DX floats) go global -> LDS by LDS-DMA, 1 KiB per
+  // instruction, no staging registers; only the issuing wave reads them, so its own vmcnt wait orders the reads.
+  // 1/sqrt(df) is applied where the query is used.
+  auto vec_dma = [&](const Unit& t) {
+    typedef const __attribute__((address_space(1))) char* gptr;
+    const gptr qrow = (gptr)reinterpret_cast<cptr>(a.Q + (long long)t.row * a.ldqkv);
+    const gptr film = (gptr)reinterpret_cast<cptr>(a.film + (long long)t.b * (4 * DX));
+    unsigned voff = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(voff));
+#pragma unroll
+    for (int k = 0; k < (3 * DX + 255) / 256; ++k) {
+      const int c0 = 256 * k;                                           // first float of this 1 KiB piece
+      if (c0 + 256 <= DX)
+        lds_dma16((const char*)qrow + 4 * c0 + voff, lds_addr_of(vecw + c0));
+      else if (c0 >= DX && c0 + 256 <= 3 * DX)
+        lds_dma16((const char*)film + 4 * (c0 - DX) + voff, lds_addr_of(vecw + c0));
+      else {                                                            // piece straddles a boundary (DX not a multiple of 256)
+        const int c = c0 + lane * 4;
+        if (c < 3 * DX) {
+          const f32x4 t4 = c < DX ? *reinterpret_cast<const f32x4*>(reinterpret_cast<cptr>(a.Q + (long long)t.row * a.ldqkv) + 4 * c)
+                                  : *reinterpret_cast<const f32x4*>(reinterpret_cast<cptr>(a.film + (long long)t.b * (4 * DX)) + 4 * (c - DX));
+          *reinterpret_cast<f32x4*>(vecw + c) = t4;
+        }
+      }
+    }
+  };
+  auto tile_load = [&](const Unit& t, int jj, f32x4 (&x0)[IBE], f32x4 (&x1)[IBE]) {
+    const cptr bij = reinterpret_cast<cptr>(a.E_in + (long long)t.row * n * DE);
+    const cptr bji = reinterpret_cast<cptr>(a.E_in + ((long long)t.b * n * n + t.i) * DE);
+    const unsigned oij = 4u * (jj * DE + 4 * g), oji = 4u * (jj * n * DE + 4 * g);
+#pragma unroll
+    for (int eb = 0; eb < IBE; ++eb) {
+      x0[eb] = ldo(bij, oij + 64u * eb);
+      x1[eb] = ldo(bji, oji + 64u * eb);
+    }
+  };
+
+  // ---- prologue: images 0 and 1 (all waves), image 2 (group 2's share: the others issue theirs in S2 of phase 0)
+  stage_share(0);
+  stage_share(1);
+  if (grp == 2) stage_share(2);
+
+  Unit un = unit_of(slot(0));
+  int mk = mask_byte(un);
+  f32x4 e[IBE];
+  f32x4 nx0[IBE], nx1[IBE];                                            // the next unit's E tile, in flight
+  {
+    const int j = un.j0 + p, jj = j < n ? j : 0;
+    vec_dma(un);
+    tile_load(un, jj, nx0, nx1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SCGG_SUBSTEP_BARRIER();
+  for (int k = 0; k < grp; ++k) SCGG_SUBSTEP_BARRIER();                       // the stagger: group g starts g sub-steps late
+
+  int ph_glob = 0;                                                     // this wave's phase in the endless image sequence
+  const int dma_ahead = grp == 2 ? 3 : 2;
+  SCGG_STAMP_DECL
+  for (int it = 0; it < iters; ++it) {
+    const bool active = un.active;
+    const int j = un.j0 + p;
+    const bool inb = j < n, vj = mk != 0, live = vj && j != un.i;
+    const int jj = inb ? j : 0;
+    const Unit nx = unit_of(slot(it + 1));
+    const int nmk = mask_byte(nx);
+
+    const cptr kbase = reinterpret_cast<cptr>(a.K + (long long)un.b * n * a.ldqkv);
+    const cptr vbase = reinterpret_cast<cptr>(a.V + (long long)un.b * n * a.ldqkv);
+    const unsigned kvoff = 4u * (jj * a.ldqkv + 4 * g);
+    const float *b_out = a.b_out, *ln1_g = a.ln1_g, *ln1_b = a.ln1_b, *ln2_g = a.ln2_g, *ln2_b = a.ln2_b;
+    asm volatile("" : "+s"(b_out), "+s"(ln1_g), "+s"(ln1_b), "+s"(ln2_g), "+s"(ln2_b));
+    f32x4 accO[IBE];
+    u32x4 eh[QE], em[QE], el[QE];
+    if (active) {
+      // the unit's symmetrised E tile (requested one sub-step ago, or in the prologue).  Its row vectors were requested
+      // BEFORE the tile (vec_dma, then tile_load): vmcnt retires in issue order, so the wait the compiler places in front
+      // of the first use of the tile also covers the LDS-DMA of the vectors, which are first read in S1.
+#pragma unroll
+      for (int eb = 0; eb < IBE; ++eb) e[eb] = live ? 0.5f * (nx0[eb] + nx1[eb]) : splat4(0.f);
+#pragma unroll
+      for (int eb = 0; eb < IBE; ++eb) accO[eb] = ld4(b_out + 16 * eb + 4 * g);
+#pragma unroll
+      for (int q = 0; q < QE; ++q) split3(e[2 * q], e[2 * q + 1], eh[q], em[q], el[q]);
+    }
+    // e is dead from here to LayerNorm 1: the exact split is summed back there (16 registers less in the S0 - S2 sub-steps)
+    SCGG_STAMP_AT(0)                                                     // 0: unit set-up (loads consumed, split)
+
+    // ================================================================== channel-block phases
+#pragma unroll 1
+    for (int cb = 0; cb < NXB; ++cb, ++ph_glob) {
+      const f32x4* img = wbuf + (ph_glob % 3) * G::PH_F4;
+      const float* bias = reinterpret_cast<const float*>(img);
+      const f32x4* W = img + G::BIAS_F4;
+      f32x4 k[2], vn[2], a1[2], a2[2];
+      // ---------------------------------------------------------------- S0
+      if (active) {
+        SCGG_LANE
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          k[blk] = ldo(kbase, kvoff + 4u * (32 * cb + 16 * blk));
+          vn[blk] = ldo(vbase, kvoff + 4u * (32 * cb + 16 * blk));
+        }
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+          a1[ob] = ld4(bias + 16 * ob + 4 * g_);                        // e_mul bias + 1
+          a2[ob] = ld4(bias + 32 + 16 * ob + 4 * g_);                   // e_add bias
+        }
+        block_pipeline_deep<4 * QE>(W, lane_, [&](int t, const Frag3& w) {
+          const int rem = t % (2 * QE), q = rem >> 1, ob = rem & 1;
+          if (t < 2 * QE) mfma_x3(a1[ob], w, eh[q], em[q], el[q]);      // e_mul
+          else mfma_x3(a2[ob], w, eh[q], em[q], el[q]);                 // e_add
+        });
+      }
+      SCGG_STAMP_AT(1)                                                   // 1: S0 work
+      SCGG_SUBSTEP_BARRIER();
+      SCGG_STAMP_AT(2)                                                   // 2: barrier after S0
+      // ---------------------------------------------------------------- S1
+      f32x4 y[2], v[2];
+      if (active) {
+        f32x4 z[2];
+        Frag3 fa, fb;
+        SCGG_LANE
+        load_frag3(fa, W + 4 * QE * 192, lane_);                         // first e_out block: in flight under the FiLM
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          const int co = 32 * cb + 16 * blk + 4 * g_;
+          const f32x4 q = ld4(vecw + co);                               // Q_i
+          const f32x4 yea = ld4(vecw + DX + co);
+          const f32x4 yem = ld4(vecw + 2 * DX + co);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float kk = vj ? k[blk][r] * a.inv_sqrt_df : 0.f;
+            const float yy = (q[r] * kk) * a1[blk][r] + a2[blk][r];     // Y = QK/sqrt(df) * (E1+1) + E2
+            z[blk][r] = yea[r] + yem[r] * yy;                           // FiLM by y before e_out
+            y[blk][r] = vj ? yy : -INFINITY;
+            v[blk][r] = vj ? vn[blk][r] : 0.f;
+          }
+        }
+        u32x4 zh, zm, zl;
+        split3(z[0], z[1], zh, zm, zl);
+        block_pipeline<IBE, 0>(W + 4 * QE * 192, nullptr, fa, fb, lane_,
+                               [&](int t, const Frag3& w) { mfma_x3(accO[t], w, zh, zm, zl); });
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // retires this wave's weight DMA (see the header)
+      SCGG_STAMP_AT(3)                                                   // 3: S1 work
+      SCGG_SUBSTEP_BARRIER();
+      SCGG_STAMP_AT(4)                                                   // 4: barrier after S1
+      // ---------------------------------------------------------------- S2
+      stage_share(ph_glob + dma_ahead);
+      if (active) {
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, y[blk][r]);
+        const float M = row_max16_fused(mloc);
+        const float nM = M == -INFINITY ? 0.f : -M * LOG2E;
+        f32x4 cm[2], cs[2], ca[2];
+        bool under = false;
+        {
+          float red[16];
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pe = __builtin_amdgcn_exp2f(fmaf(y[blk][r], LOG2E, nM));
+              red[4 * blk + r] = pe;
+              red[8 + 4 * blk + r] = pe * v[blk][r];
+            }
+          row_sum16_many<16>(red);
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              cs[blk][r] = red[4 * blk + r];
+              ca[blk][r] = red[8 + 4 * blk + r];
+              cm[blk][r] = M;
+              under |= cs[blk][r] == 0.f;
+            }
+        }
+        if (__any(under && M > -INFINITY)) {
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float yy = y[blk][r];
+              const float mx = row_max16(yy);
+              const float ex = yy == -INFINITY ? 0.f : __expf(yy - mx);
+              cm[blk][r] = mx;
+              cs[blk][r] = row_sum16(ex);
+              ca[blk][r] = row_sum16(ex * v[blk][r]);
+            }
+        }
+        if (p == 0) {
+          float* dst = a.attn_part + (long long)un.u * (3 * DX) + 32 * cb + 4 * g;
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk) {
+            *reinterpret_cast<f32x4*>(dst + 16 * blk) = cm[blk];
+            *reinterpret_cast<f32x4*>(dst + DX + 16 * blk) = cs[blk];
+            *reinterpret_cast<f32x4*>(dst + 2 * DX + 16 * blk) = ca[blk];
+          }
+        }
+      }
+      SCGG_STAMP_AT(5)                                                   // 5: S2 work
+      SCGG_SUBSTEP_BARRIER();
+      SCGG_STAMP_AT(6)                                                   // 6: barrier after S2
+    }
+
+    // ================================================================== E <- LN1(E + newE), FFN half phases
+#pragma unroll
+    for (int h = 0; h < NFB; ++h, ++ph_glob) {
+      const f32x4* img = wbuf + (ph_glob % 3) * G::PH_F4;
+      const float* bias = reinterpret_cast<const float*>(img);
+      const f32x4* W = img + G::BIAS_F4;
+      f32x4 hid[2];
+      // ---------------------------------------------------------------- F0
+      if (active) {
+        SCGG_LANE
+        Frag3 fa, fb;
+        load_frag3(fa, W, lane_);
+        if (h == 0) {
+#pragma unroll
+          for (int q = 0; q < QE; ++q) unsplit3(eh[q], em[q], el[q], e[2 * q], e[2 * q + 1]);
+#pragma unroll
+          for (int eb = 0; eb < IBE; ++eb) e[eb] += accO[eb];
+          layernorm_c16<IBE>(e, ln1_g, ln1_b, g_);
+#pragma unroll
+          for (int q = 0; q < QE; ++q) split3(e[2 * q], e[2 * q + 1], eh[q], em[q], el[q]);
+#pragma unroll
+          for (int eb = 0; eb < IBE; ++eb) e[eb] += ld4(bias + 64 + 16 * eb + 4 * g_);  // linE2 bias
+        }
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) hid[ob] = ld4(bias + 16 * ob + 4 * g_);
+        block_pipeline<2 * QE, 0>(W, nullptr, fa, fb, lane_, [&](int t, const Frag3& w) {
+          mfma_x3(hid[t & 1], w, eh[t >> 1], em[t >> 1], el[t >> 1]);
+        });
+      }
+      SCGG_STAMP_AT(7)                                                   // 7: F0 work
+      SCGG_SUBSTEP_BARRIER();
+      SCGG_STAMP_AT(8)                                                   // 8: barrier after F0
+      // ---------------------------------------------------------------- F1
+      if (active) {
+        SCGG_LANE
+        Frag3 fa, fb;
+        load_frag3(fa, W + 2 * QE * 192, lane_);
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hid[ob][r] = fmaxf(hid[ob][r], 0.f);
+        u32x4 hh, hm, hl;
+        split3(hid[0], hid[1], hh, hm, hl);
+        block_pipeline<IBE, 0>(W + 2 * QE * 192, nullptr, fa, fb, lane_,
+                               [&](int t, const Frag3& w) { mfma_x3(e[t], w, hh, hm, hl); });
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // retires this wave's weight DMA
+      SCGG_STAMP_AT(9)                                                   // 9: F1 work
+      SCGG_SUBSTEP_BARRIER();
+      SCGG_STAMP_AT(10)                                                  // 10: barrier after F1
+      // ---------------------------------------------------------------- F2
+      stage_share(ph_glob + dma_ahead);
+      if (h == NFB - 1) {
+        {   // the next unit's requests, consumed after the barrier.  Unconditional (a wave without a next unit reads unit
+            // 0's rows, which exist): a conditional definition would keep the 44 registers live through the whole round.
+          const int nj = nx.j0 + p, njj = nj < n ? nj : 0;
+          vec_dma(nx);
+          tile_load(nx, njj, nx0, nx1);
+        }
+        if (active) {
+          layernorm_c16<IBE>(e, ln2_g, ln2_b, g);
+          if (inb) {
+            float* dst = a.E_out + ((long long)un.row * n + jj) * DE + 4 * g;
+#pragma unroll
+            for (int eb = 0; eb < IBE; ++eb) *reinterpret_cast<f32x4*>(dst + 16 * eb) = live ? e[eb] : splat4(0.f);
+          }
+        }
+      }
+      SCGG_STAMP_AT(11)                                                  // 11: F2 work
+      SCGG_SUBSTEP_BARRIER();
+      SCGG_STAMP_AT(12)                                                  // 12: barrier after F2
+    }
+    un = nx;
+    mk = nmk;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // DMA issued for phases nobody runs: let it land before exit
+  for (int k = grp; k < 2; ++k) SCGG_SUBSTEP_BARRIER();                         // every wave has passed the same number of barriers
+#ifdef SCGG_STAMP
+  {
+    const int slot_ = blockIdx.x == 0 ? 0 : blockIdx.x == 1 ? 1 : blockIdx.x == gridDim.x / 2 ? 2 : blockIdx.x == gridDim.x - 1 ? 3 : -1;
+    if (slot_ >= 0 && lane == 0) {
+#pragma unroll
+      for (int k = 0; k < STAMP_SEGS; ++k) g_stamps[slot_][wave][k] = st_acc[k];
+      g_stamps[slot_][wave][15] = (unsigned long long)iters;
+    }
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1180,21 +1690,25 @@ int launch_edge_pool_stats(const EdgePoolArgs& a, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------
 #define SCGG_UNIT_CASES CASE(8, 2, 4) CASE(4, 2, 4) CASE(1, 1, 2)
 
-// SCGG_EDGE_MODE=f32 selects the plain fp32-MFMA kernel (development A/B switch); default: the x3 path
-static bool edge_x3() {
+// SCGG_EDGE_MODE (development A/B switch, read once): "f32" = the plain fp32-MFMA kernel, "x3s" = the staggered bf16x3
+// kernel (round 2 experiment: correct, 13-15 % slower), default = "x3", the bf16x3 kernel of round 1
+enum EdgeMode { EDGE_F32 = 0, EDGE_X3 = 1, EDGE_X3S = 2 };
+static int edge_mode() {
   static int mode = -1;
   if (mode < 0) {
     const char* e = getenv("SCGG_EDGE_MODE");
-    mode = (e != nullptr && e[0] == 'f') ? 0 : 1;
+    mode = (e == nullptr || e[0] == 0) ? EDGE_X3 : (e[0] == 'f' ? EDGE_F32 : (e[0] == 'x' && e[1] == '3' && e[2] == 's' ? EDGE_X3S : EDGE_X3));
   }
-  return mode == 1;
+  return mode;
 }
+static bool edge_x3() { return edge_mode() == EDGE_X3; }
 
 long long edge_phase_img_f4(int dx, int de, int ffe) {
 #define CASE(NXB, NEB, NFB)                                                                                   \
   if (dx == 32 * NXB && de == 32 * NEB && ffe == 32 * NFB)                                                    \
-    return edge_x3() ? (long long)UnitGeomX3<NXB, NEB, NFB>::NPH * UnitGeomX3<NXB, NEB, NFB>::PH_F4           \
-                     : (long long)UnitGeom<NXB, NEB, NFB>::NPH * UnitGeom<NXB, NEB, NFB>::PH_F4;
+    return edge_mode() == EDGE_X3S ? (long long)UnitGeomX3S<NXB, NEB, NFB>::NPH * UnitGeomX3S<NXB, NEB, NFB>::PH_F4 \
+           : edge_x3() ? (long long)UnitGeomX3<NXB, NEB, NFB>::NPH * UnitGeomX3<NXB, NEB, NFB>::PH_F4           \
+                       : (long long)UnitGeom<NXB, NEB, NFB>::NPH * UnitGeom<NXB, NEB, NFB>::PH_F4;
   SCGG_UNIT_CASES
 #undef CASE
   return -1;
@@ -1203,7 +1717,9 @@ long long edge_phase_img_f4(int dx, int de, int ffe) {
 int launch_edge_unit_pack(const EdgeUnitPackArgs& a, int dx, int de, int ffe, hipStream_t st) {
 #define CASE(NXB, NEB, NFB)                                                                                        \
   if (dx == 32 * NXB && de == 32 * NEB && ffe == 32 * NFB) {                                                       \
-    if (edge_x3())                                                                                                 \
+    if (edge_mode() == EDGE_X3S)                                                                                   \
+      hipLaunchKernelGGL((edge_unit_pack_x3s_kernel<NXB, NEB, NFB>), dim3(UnitGeomX3S<NXB, NEB, NFB>::NPH), dim3(512), 0, st, a); \
+    else if (edge_x3())                                                                                            \
       hipLaunchKernelGGL((edge_unit_pack_x3_kernel<NXB, NEB, NFB>), dim3(UnitGeomX3<NXB, NEB, NFB>::NPH), dim3(512), 0, st, a); \
     else                                                                                                           \
       hipLaunchKernelGGL((edge_unit_pack_kernel<NXB, NEB, NFB>), dim3(UnitGeom<NXB, NEB, NFB>::NPH), dim3(512), 0, st, a); \
@@ -1223,8 +1739,13 @@ int launch_edge_unit_pack(const EdgeUnitPackArgs& a, int dx, int de, int ffe, hi
 
 template <int NXB, int NEB, int NFB>
 static int launch_one(const EdgeLayerArgs& a, int n_cu, hipStream_t st) {
-  static LdsAttrOnce attr_x3, attr_f32;
-  if (edge_x3()) {
+  static LdsAttrOnce attr_x3, attr_f32, attr_x3s;
+  if (edge_mode() == EDGE_X3S) {
+    auto kern = edge_unit_layer_x3s_kernel<NXB, NEB, NFB>;
+    const size_t lds = UnitGeomX3S<NXB, NEB, NFB>::lds_bytes();
+    if (set_max_dynamic_lds(attr_x3s, reinterpret_cast<const void*>(kern), lds)) return -2;
+    hipLaunchKernelGGL(kern, dim3(n_cu), dim3(UnitGeomX3S<NXB, NEB, NFB>::NW * 64), lds, st, a);   // one persistent workgroup per CU
+  } else if (edge_x3()) {
     constexpr int NW = SCGG_X3_WAVES;
     auto kern = edge_unit_layer_x3_kernel<NXB, NEB, NFB, NW>;
     const size_t lds = UnitGeomX3<NXB, NEB, NFB>::lds_bytes(NW);

@@ -28,6 +28,18 @@ __device__ __forceinline__ void split3(const f32x4& b0, const f32x4& b1, u32x4& 
   }
 }
 
+// the inverse: h + m + l is the value split3 was given, bit for bit (the split is exact, and each partial sum is
+// representable: m + l is the remainder of x after its 8 leading bits, h + that is x)
+__device__ __forceinline__ void unsplit3(const u32x4& hi, const u32x4& mid, const u32x4& lo, f32x4& b0, f32x4& b1) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const float x0 = __uint_as_float(hi[d] << 16) + (__uint_as_float(mid[d] << 16) + __uint_as_float(lo[d] << 16));
+    const float x1 = __uint_as_float(hi[d] & 0xffff0000u) + (__uint_as_float(mid[d] & 0xffff0000u) + __uint_as_float(lo[d] & 0xffff0000u));
+    if (d < 2) { b0[2 * d] = x0; b0[2 * d + 1] = x1; }
+    else { b1[2 * d - 4] = x0; b1[2 * d - 3] = x1; }
+  }
+}
+
 struct Frag3 { u32x4 h, m, l; };   // one weight block: the three bf16 terms of this lane's 8 k-slots
 
 __device__ __forceinline__ void load_frag3(Frag3& f, const f32x4* w, int lane) {
@@ -65,6 +77,23 @@ __device__ __forceinline__ void block_pipeline(const f32x4* W, const f32x4* afte
     else if (after != nullptr) load_frag3(nxt, after, lane);
     __builtin_amdgcn_sched_barrier(0);
     body(t, cur);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// The same with the weight blocks read TWO blocks ahead (three register sets): for a wave that runs its matrix work
+// alone on its SIMD (edge_unit_layer_x3s_kernel) one block of cover (96 pipe cycles) is less than an LDS round trip under
+// load, and every block then starts with a stall.  On entry nothing is loaded.
+template <int NB, class Body>
+__device__ __forceinline__ void block_pipeline_deep(const f32x4* W, int lane, Body body) {
+  Frag3 f[3];
+  load_frag3(f[0], W, lane);
+  if (NB > 1) load_frag3(f[1], W + 192, lane);
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+    if (t + 2 < NB) load_frag3(f[(t + 2) % 3], W + (t + 2) * 192, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    body(t, f[t % 3]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }

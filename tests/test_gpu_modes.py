@@ -45,3 +45,17 @@ def test_x3_kernels_agree_with_fp32_mfma_kernels(tmp_path):
         scale = float(np.abs(b[k]).max())
         err = float(np.abs(a[k] - b[k]).max()) / scale
         assert err < 2e-5, f"{k}: x3 vs fp32 MFMA differ by {err:.2e} of the output scale"   # fp32 round-off over 3 layers
+
+
+@pytest.mark.gpu
+def test_staggered_x3s_kernel_agrees_with_the_default(tmp_path):
+    """SCGG_EDGE_MODE=x3s: the staggered variant of the bf16x3 edge kernel (three LDS weight buffers, wave groups one
+    sub-step apart, LDS-DMA issued from inline asm with hand-counted waits).  Same arithmetic per unit, so
+    the two agree to fp32 round-off (the accumulation order of the FFN halves differs); a missed DMA wait or a
+    mis-ordered buffer would show here as a gross error."""
+    a = _run(tmp_path, "x3", {})
+    b = _run(tmp_path, "x3s", {"SCGG_EDGE_MODE": "x3s"})
+    for k in ("X", "E"):
+        scale = float(np.abs(a[k]).max())
+        err = float(np.abs(a[k] - b[k]).max()) / scale
+        assert err < 2e-5, f"{k}: x3s vs x3 differ by {err:.2e} of the output scale"
