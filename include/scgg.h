@@ -154,18 +154,32 @@ int scgg_onehot_to_labels(const float* E_onehot, int64_t n_pairs, int32_t C, int
  *          e_out[p*e_ld + e_off ..]; with onehot_out != NULL the masked one-hot of the label goes to
  *          onehot_out[p*e_ld + 0..C)  (so the denoiser's inputs [state | extra] are assembled in one pass)
  *   lap_out[B,n,n] (optional)                         padded combinatorial Laplacian
- * n <= 32 in this round.
+ * scgg_adjacency_features: one workgroup per graph, everything in LDS, n <= 32, no workspace.
+ * scgg_adjacency_features_tiled: the same outputs for any n <= 4096 (and for n <= 32 too): the K-1 adjacency products
+ *   (calculate_kpowers :256-268) and the w w^T product of local_neighbors (:348) run as batched fp32 MFMA GEMMs over
+ *   [B,np,np] planes (np = n rounded up to 64) in `workspace` (>= scgg_adjacency_features_workspace_bytes(B, n), 256-byte
+ *   aligned, contents irrelevant).  Integer-valued outputs (cycle counts, reachability, histograms, Laplacian) are
+ *   identical to the LDS kernel's; the Adamic-Adar channel differs by fp32 summation order only.  onehot_out must be NULL
+ *   or e_out.
  * ---------------------------------------------------------------------------------------------------------- */
 int scgg_adjacency_features(const int8_t* labels, const int8_t* node_labels, const uint8_t* node_mask, int32_t B,
                             int32_t n, int32_t C, int32_t Cx, int32_t num_degree, int32_t max_degree,
                             int32_t cycle_features, float* x_out, int32_t x_ld, int32_t x_off, float* y_out,
                             int32_t y_ld, int32_t y_off, float* e_out, int32_t e_ld, int32_t e_off, float* onehot_out,
                             float* lap_out, void* stream);
+size_t scgg_adjacency_features_workspace_bytes(int32_t B, int32_t n);
+int scgg_adjacency_features_tiled(const int8_t* labels, const int8_t* node_labels, const uint8_t* node_mask, int32_t B,
+                                  int32_t n, int32_t C, int32_t Cx, int32_t num_degree, int32_t max_degree,
+                                  int32_t cycle_features, float* x_out, int32_t x_ld, int32_t x_off, float* y_out,
+                                  int32_t y_ld, int32_t y_off, float* e_out, int32_t e_ld, int32_t e_off,
+                                  float* onehot_out, float* lap_out, void* workspace, size_t workspace_bytes,
+                                  void* stream);
 
 /* The padded combinatorial Laplacian alone: replaces EigenFeatures.compute_laplacian
  * (src/ConStruct/diffusion/extra_features.py:121-127 with the padding of :88-94), bit-identical to the lap_out of
  * scgg_adjacency_features.  Separate so that scgg_eigen_features can start (on another stream) while the remaining
- * structural features are computed.  labels int8 [B,n,n] (> 0 = edge), lap_out [B,n,n].  n <= 32 in this round. */
+ * structural features are computed.  labels int8 [B,n,n] (> 0 = edge), lap_out [B,n,n].  Any n (one workgroup per
+ * graph up to 32 nodes, one wave per row beyond). */
 int scgg_laplacian(const int8_t* labels, const uint8_t* node_mask, int32_t B, int32_t n, float* lap_out, void* stream);
 
 /* EigenFeatures.compute_features after the Laplacian (extra_features.py:96-112, :138-195), including the

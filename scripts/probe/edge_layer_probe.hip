@@ -6,6 +6,7 @@
 #include "edge_unit_layer.hip"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <random>
 
@@ -83,6 +84,43 @@ int main(int argc, char** argv) {
   ms /= reps;
   printf("B=%d rows=%d units=%d pairs=%lld  %.1f us/launch  %.1f TFLOP/s (algorithmic, valid pairs)\n", B, rows_valid, n_units, pairs,
          ms * 1e3, pairs * 131072.0 / (ms * 1e-3) / 1e12);
+  if (argc > 3) {   // repeatability: the same launch must give the same bits, every time
+    const int chk = atoi(argv[3]);
+    const size_t na = (size_t)B * n * nch * 3 * DX, ne = (size_t)B * n * n * DE;
+    std::vector<float> ra(na), re(ne), ca(na), ce(ne);
+    CK(hipMemcpy(ra.data(), a.attn_part, na * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(re.data(), a.E_out, ne * 4, hipMemcpyDeviceToHost));
+    int bad = 0;
+    // argv[4] = 1: a second copy of the same launch (own outputs) runs on another stream at the same time
+    const bool twin = argc > 4 && atoi(argv[4]) != 0;
+    hipStream_t s2 = nullptr;
+    scgg::EdgeLayerArgs a2 = a;
+    if (twin) {
+      CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+      a2.E_out = dev<float>(ne); a2.attn_part = dev<float>(na);
+    }
+    for (int r = 0; r < chk; ++r) {
+      if (twin) scgg::launch_edge_layer(a2, DX, DE, FFE, s2);
+      scgg::launch_edge_layer(a, DX, DE, FFE, 0);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(ca.data(), a.attn_part, na * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(ce.data(), a.E_out, ne * 4, hipMemcpyDeviceToHost));
+      size_t da = 0, de_ = 0, first = (size_t)-1;
+      for (size_t i = 0; i < na; ++i) if (memcmp(&ca[i], &ra[i], 4)) { if (first == (size_t)-1) first = i; ++da; }
+      for (size_t i = 0; i < ne; ++i) if (memcmp(&ce[i], &re[i], 4)) ++de_;
+      if (da || de_) {
+        ++bad;
+        const size_t u = first / (3 * DX), o = first % (3 * DX);
+        printf("rep %d: attn words differ %zu (first: unit slot %zu row %zu chunk %zu section %zu channel %zu: %g vs %g)  E words differ %zu\n",
+               r, da, u, u / nch, u % nch, o / DX, o % DX, first != (size_t)-1 ? ca[first] : 0.f, first != (size_t)-1 ? ra[first] : 0.f, de_);
+        if (da && bad <= 3) {
+          size_t shown = 0;
+          for (size_t i = 0; i < na && shown < 24; ++i) if (memcmp(&ca[i], &ra[i], 4)) { printf("   [%zu | sec %zu ch %zu] %g vs %g\n", i / (3 * DX), (i % (3 * DX)) / DX, i % DX, ca[i], ra[i]); ++shown; }
+        }
+      }
+    }
+    printf("repeatability: %d of %d launches differ from the first\n", bad, chk);
+  }
 #ifdef SCGG_STAMP
   {
     static unsigned long long st[4][16][scgg::STAMP_SEGS];

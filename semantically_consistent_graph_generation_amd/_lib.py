@@ -47,6 +47,9 @@ SIGNATURES = {
     "scgg_onehot_to_labels": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "scgg_adjacency_features": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp,
                                           _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "scgg_adjacency_features_tiled": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32,
+                                                _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "scgg_adjacency_features_workspace_bytes": (C.c_size_t, [_i32, _i32]),
     "scgg_new_edges": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
     "scgg_apply_edge_edits": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "scgg_projector_create": (C.c_int, [_i32, _i32, _vp, C.POINTER(_vp)]),

@@ -601,6 +601,9 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_kernel(EdgeLayerArgs 
     tile_make(nx, nx0, nx1, e);
     un = nx;
   }
+  // the wrap-around weight DMA of the last round (and whatever an idle wave issued) must land before the wave ends: the
+  // workgroup's LDS is handed to the next workgroup on the CU as soon as its waves are gone
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // =========================================================================================================
@@ -1014,6 +1017,7 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
     un = nx;
     mk = nmk;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the wave ends (see the fp32 kernel's end)
 }
 
 // =========================================================================================================

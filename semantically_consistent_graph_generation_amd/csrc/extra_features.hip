@@ -283,7 +283,7 @@ extern "C" int scgg_laplacian(const int8_t* labels, const uint8_t* node_mask, in
                               void* stream) {
   if (!labels || !node_mask || !lap_out) return fail("laplacian: null argument");
   if (B <= 0 || n <= 0) return fail("laplacian: bad shape");
-  if (n > NT) return fail("laplacian: n=%d > 32 is not built yet (LDS-tile kernel only)", n);
+  if (n > NT) return launch_laplacian_rows(labels, node_mask, B, n, lap_out, static_cast<hipStream_t>(stream));
   hipLaunchKernelGGL(laplacian_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), labels, node_mask, n, lap_out);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail("laplacian: %s", hipGetErrorString(e));
@@ -297,7 +297,7 @@ extern "C" int scgg_adjacency_features(const int8_t* labels, const int8_t* node_
                                        int32_t e_ld, int32_t e_off, float* onehot_out, float* lap_out, void* stream) {
   if (!labels || !node_mask || !x_out || !y_out || !e_out) return fail("adjacency_features: null argument");
   if (B <= 0 || n <= 0) return fail("adjacency_features: bad shape");
-  if (n > NT) return fail("adjacency_features: n=%d > 32 is not built yet (LDS-tile kernel only)", n);
+  if (n > NT) return fail("adjacency_features: n=%d > 32 needs scgg_adjacency_features_tiled (workspace argument)", n);
   if (max_degree < 6 || max_degree > 32 || num_degree + 2 > 64 || C > 64 || Cx > 64 || C < 1 || Cx < 1)
     return fail("adjacency_features: unsupported max_degree=%d num_degree=%d C=%d Cx=%d", max_degree, num_degree, C, Cx);
   if (e_ld < e_off + max_degree + 1 || (onehot_out && e_off < C) || x_ld < x_off + 3 ||

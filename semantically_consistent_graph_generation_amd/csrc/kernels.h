@@ -248,4 +248,7 @@ int launch_row_head(const float* hid, int ldh, const float* W, const float* b, c
 int launch_x_out_residual(const float* mlp, const float* X_in, int dX_in, const uint8_t* mask, float* out,
                           int M, int nout, hipStream_t st);
 
+// padded combinatorial Laplacian for any n (adjacency_tiled.hip); scgg_laplacian uses it beyond the 32-node LDS kernel
+int launch_laplacian_rows(const int8_t* labels, const uint8_t* mask, int B, int n, float* lap_out, hipStream_t st);
+
 }  // namespace scgg

@@ -6,6 +6,10 @@ runs in libscgg.so (``scgg_adjacency_features``) on the int8 edge state.  The ei
 delegates to ``torch.linalg.eigh`` and the feature extraction around it run in ``scgg_eigen_features`` (batched Jacobi,
 one wave per graph): rocSOLVER's eigh costs 50 ms per step at B=512, n=32 (profiles/r01_b).  No host syncs (the
 reference's Python ``max()`` over device tensors, :149/:178, disappears: out-of-range columns are the padding value).
+
+Beyond 32 nodes (vessel graphs, n = 256 / 1024) the adjacency products run as batched fp32 MFMA GEMMs
+(``scgg_adjacency_features_tiled``, workspace owned here), and the eigendecomposition is the library call the reference
+makes (``torch.linalg.eigh`` = rocSOLVER on the device) followed by the reference's own O(B n) tensor bookkeeping.
 """
 from __future__ import annotations
 
@@ -43,6 +47,15 @@ class ExtraFeatures:
         self.cycle_features = bool(_get(cfg, "cycle_features"))
         self.num_eigenvectors = _get(cfg, "num_eigenvectors")
         self.num_eigenvalues = _get(cfg, "num_eigenvalues")
+        self.lds_limit = 32                        # largest n of the one-workgroup kernels (adjacency and Jacobi eigen)
+        self._ws = {}                              # device -> workspace tensor of the tiled adjacency pass
+
+    def _workspace(self, B, n, dev):
+        need = int(_lib.lib().scgg_adjacency_features_workspace_bytes(B, n))
+        ws = self._ws.get(dev)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[dev] = torch.empty(need, dtype=torch.uint8, device=dev)
+        return ws, need
 
     def update_input_dims(self, input_dims):
         """reference :43-58 (mutates and returns input_dims)."""
@@ -72,6 +85,14 @@ class ExtraFeatures:
         if y_dst is None:
             y_dst = torch.empty(B, 4 + self.num_degree + 2 + 1 + C_e, device=dev)
         lap = torch.empty(B, n, n, device=dev) if want_lap else None
+        if n > self.lds_limit:
+            ws, need = self._workspace(B, n, dev)
+            _lib.check(_lib.lib().scgg_adjacency_features_tiled(
+                _lib.ptr(labels), None, _lib.ptr(node_mask.view(torch.uint8)), B, n, C_e, 1, self.num_degree,
+                self.max_degree, int(self.cycle_features), _lib.ptr(x_dst), x_dst.shape[-1], x_off, _lib.ptr(y_dst),
+                y_dst.shape[-1], y_off, _lib.ptr(e_dst), e_dst.shape[-1], e_off, _lib.ptr(e_dst) if want_onehot else None,
+                _lib.ptr(lap), _lib.ptr(ws), need, _lib.stream_ptr()), "adjacency_features_tiled")
+            return x_dst, y_dst, e_dst, lap
         _lib.check(_lib.lib().scgg_adjacency_features(
             _lib.ptr(labels), None, _lib.ptr(node_mask.view(torch.uint8)), B, n, C_e, 1, self.num_degree, self.max_degree,
             int(self.cycle_features), _lib.ptr(x_dst), x_dst.shape[-1], x_off, _lib.ptr(y_dst), y_dst.shape[-1], y_off,
@@ -97,6 +118,9 @@ class ExtraFeatures:
             evl_dst = torch.empty(B, 1 + self.num_eigenvalues, device=dev)
         if evc_dst is None:
             evc_dst = torch.empty(B, n, 1 + self.num_eigenvectors, device=dev)
+        if n > self.lds_limit:
+            w, V = self._eigen_features_library(lap, node_mask, evl_dst, evl_off, evc_dst, evc_off)
+            return (evl_dst, evc_dst, w, V) if want_raw else (evl_dst, evc_dst)
         w = torch.empty(B, n, device=dev) if want_raw else None
         V = torch.empty(B, n, n, device=dev) if want_raw else None
         _lib.check(_lib.lib().scgg_eigen_features(
@@ -104,6 +128,33 @@ class ExtraFeatures:
             _lib.ptr(evl_dst), evl_dst.shape[-1], evl_off, _lib.ptr(evc_dst), evc_dst.shape[-1], evc_off, _lib.ptr(w),
             _lib.ptr(V), _lib.stream_ptr()), "eigen_features")
         return (evl_dst, evc_dst, w, V) if want_raw else (evl_dst, evc_dst)
+
+    def _eigen_features_library(self, lap, node_mask, evl_dst, evl_off, evc_dst, evc_off):
+        """n > 32: ``torch.linalg.eigh`` (rocSOLVER; the reference's own call, :96) and the reference's bookkeeping
+        (:138-195) as device tensor ops without its host syncs: the gather windows are padded by their full width (value 2 /
+        0 beyond column n, as :149-152 / :178-181 pad), and the mode of the rounded first eigenvector (:169-175) is taken
+        over the valid nodes (padded slots get distinct values above every valid one: the limit of the reference's randn
+        padding in which a padded value is never the mode, see oracle/extra_features.py)."""
+        B, n = node_mask.shape
+        dev = node_mask.device
+        m = node_mask.to(lap.dtype)
+        w, V = torch.linalg.eigh(lap)
+        ev = w / m.sum(dim=1, keepdim=True)
+        vec = V * m[:, :, None] * m[:, None, :]
+        ncc = (ev < 1e-5).sum(dim=-1)
+        ke, kv = self.num_eigenvalues, self.num_eigenvectors
+        evp = torch.cat([ev, torch.full((B, ke), 2.0, device=dev)], dim=1)
+        idx = torch.arange(ke, device=dev)[None] + ncc[:, None]
+        evl_dst[:, evl_off] = ncc.to(ev.dtype)
+        evl_dst[:, evl_off + 1: evl_off + 1 + ke] = torch.gather(evp, 1, idx)
+        pad = 1.0e6 + torch.arange(n, device=dev, dtype=lap.dtype)
+        v0 = torch.where(node_mask, torch.round(vec[:, :, 0], decimals=3), pad[None])
+        mode = torch.mode(v0, dim=1).values
+        evc_dst[:, :, evc_off] = ((v0 != mode[:, None]) & node_mask).to(lap.dtype)
+        vp = torch.cat([vec, torch.zeros(B, n, kv, device=dev)], dim=2)
+        idx = (torch.arange(kv, device=dev)[None, None] + ncc[:, None, None]).expand(-1, n, -1)
+        evc_dst[:, :, evc_off + 1: evc_off + 1 + kv] = torch.gather(vp, 2, idx) * m[:, :, None]
+        return w, V
 
     def __call__(self, noisy_data):
         """reference :60-77."""

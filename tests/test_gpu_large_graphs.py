@@ -1,0 +1,184 @@
+"""GPU parity beyond 32 nodes (vessel graphs: n = 40 / 256, BASELINE configs 3 and 5): the tiled MFMA adjacency pass against
+the reference's golden vectors (f5_extra_features_n40 / n256) and against the one-workgroup LDS kernel below 32 nodes, the
+library eigen path against the oracle, and the denoiser at n = 256 with vessel dims against f3_gt_vessel_n256."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, golden_shapes
+from oracle import extra_features as XF
+from oracle import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+
+def make_ef(max_n, cycle=True):
+    from semantically_consistent_graph_generation_amd.extra_features import ExtraFeatures
+    c = SimpleNamespace(model=SimpleNamespace(num_degree=10, max_degree=10, cycle_features=cycle, num_eigenvectors=5,
+                                              num_eigenvalues=9, eigenfeatures=True))
+    return ExtraFeatures(c, SimpleNamespace(max_n_nodes=max_n))
+
+
+def labels8(lab, mask):
+    n = mask.shape[1]
+    live = (mask[:, :, None] & mask[:, None, :]) & ~torch.eye(n, dtype=torch.bool)[None]
+    return torch.where(live, lab.long(), torch.full_like(lab.long(), -1)).to(torch.int8).cuda()
+
+
+@pytest.mark.parametrize("name", ["f5_extra_features_n40", "f5_extra_features_n256"])
+def test_tiled_adjacency_features_match_reference(name):
+    g = load_golden(name)
+    m, C = torch.from_numpy(g["node_mask"]), int(g["C"])
+    B, n = m.shape
+    lab = labels8(torch.from_numpy(g["labels"]), m)
+    ef = make_ef(n)
+    x, y, e, lap = ef.adjacency_features(lab, m.cuda(), C)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(x.cpu().numpy(), g["adj_x"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(y.cpu().numpy(), g["adj_y"], rtol=1e-6, atol=1e-6)
+    rows = g["rows"]
+    tol = 2e-3 if n > 40 else 1e-5                                             # the n256 fixture stores its rows in fp16
+    np.testing.assert_allclose(e[:, rows].cpu().numpy(), g["adj_e_rows"].astype(np.float32), rtol=tol, atol=1e-6 if n <= 40 else 5e-4)
+    # all rows against the CPU oracle (fp32), Laplacian bit-exact, stand-alone Laplacian entry point too
+    E = fx.one_hot_edges(torch.from_numpy(g["labels"]).long(), m, C)
+    ox, oy, oe = XF.adjacency_features(m[..., None].float(), E, m)
+    np.testing.assert_allclose(e.cpu().numpy(), oe.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(e[..., :10].cpu().numpy(), oe[..., :10].numpy())     # reachability is exact
+    L = XF.laplacian_for_eigh(E, m)
+    np.testing.assert_array_equal(lap.cpu().numpy(), L.numpy())
+    np.testing.assert_array_equal(ef.laplacian(lab, m.cuda()).cpu().numpy(), L.numpy())
+
+
+@pytest.mark.parametrize("name", ["f5_extra_features_n40", "f5_extra_features_n256"])
+def test_full_extra_features_beyond_32_nodes(name):
+    """ExtraFeatures.__call__ with the library eigen path: eigenvalue features vs the reference's, LCC flag and eigenvector
+    columns vs the oracle fed with the device's own eigenvectors (sign / degenerate-basis freedom)."""
+    g = load_golden(name)
+    m, C = torch.from_numpy(g["node_mask"]), int(g["C"])
+    B, n = m.shape
+    E = fx.one_hot_edges(torch.from_numpy(g["labels"]).long(), m, C)
+    ef = make_ef(n)
+    d = SimpleNamespace(X=m[..., None].float().cuda(), E=E.cuda(), y=torch.zeros(B, 0, device="cuda"), node_mask=m.cuda())
+    out = ef(d)
+    torch.cuda.synchronize()
+    ky = 4 + 12 + 1 + C
+    np.testing.assert_allclose(out.y[:, 1 + ky:].cpu().numpy(), g["eval_feat"], rtol=1e-4, atol=3e-5)
+    np.testing.assert_allclose(out.y[:, 1:1 + ky].cpu().numpy(), g["adj_y"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(out.X[..., :3].cpu().numpy(), g["adj_x"], rtol=1e-6, atol=1e-6)
+    lab = labels8(torch.from_numpy(g["labels"]), m)
+    lap = ef.laplacian(lab, m.cuda())
+    evl, evc, w, V = ef.eigen_features(lap, m.cuda(), want_raw=True)
+    torch.cuda.synchronize()
+    pad = (1.0e6 + torch.arange(n, dtype=torch.float32))[None].expand(B, -1)
+    oevl, oevc = XF.eigen_features(E, m, pad_noise=pad, eigh=lambda L: (w.cpu(), V.cpu()))
+    np.testing.assert_allclose(evl.cpu().numpy(), oevl.numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(evc.cpu().numpy(), oevc.numpy())
+    np.testing.assert_array_equal(out.X[..., 3:].cpu().numpy(), oevc.numpy())
+    # the decomposition itself
+    Ld, wd, Vd = lap.cpu().double(), w.cpu().double(), V.cpu().double()
+    res = (Ld @ Vd - Vd * wd[:, None, :]).abs().amax(dim=(1, 2)) / Ld.abs().amax(dim=(1, 2)).clamp(min=1.0)
+    assert float(res.max()) < 5e-5
+
+
+@pytest.mark.parametrize("B,n,C,dens,seed", [(33, 32, 14, 0.08, 5), (9, 17, 5, 0.3, 6), (4, 1, 5, 0.5, 7), (3, 100, 5, 0.03, 8)])
+def test_tiled_pass_equals_the_lds_kernel(B, n, C, dens, seed):
+    """Same inputs through scgg_adjacency_features (n <= 32) and scgg_adjacency_features_tiled: integer-valued outputs
+    identical, Adamic-Adar channel to fp32 summation order; beyond 32 nodes the tiled pass against the CPU oracle;
+    outputs land in a strided destination with the one-hot beside them."""
+    gen = torch.Generator().manual_seed(seed)
+    nn_ = torch.randint(1, n + 1, (B,), generator=gen)
+    nn_[0] = n
+    mask = fx.ragged_mask(nn_, n)
+    lab = fx.random_labels(mask, C, dens, seed)
+    lab8 = labels8(lab, mask)
+    mc = mask.cuda()
+    ef_t = make_ef(n)
+    ef_t.lds_limit = 0                                                         # force the tiled pass
+    dst_t = torch.full((B, n, n, C + 11), 7.0, device="cuda")
+    xt, yt, _, lt = ef_t.adjacency_features(lab8, mc, C, e_dst=dst_t, e_off=C, want_onehot=True)
+    torch.cuda.synchronize()
+    E = fx.one_hot_edges(lab.long(), mask, C)
+    np.testing.assert_array_equal(dst_t[..., :C].cpu().numpy(), E.numpy())
+    if n <= 32:
+        ef_l = make_ef(n)
+        dst_l = torch.full((B, n, n, C + 11), 7.0, device="cuda")
+        xl, yl, _, ll = ef_l.adjacency_features(lab8, mc, C, e_dst=dst_l, e_off=C, want_onehot=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(xt.cpu().numpy(), xl.cpu().numpy())
+        np.testing.assert_array_equal(yt.cpu().numpy(), yl.cpu().numpy())
+        np.testing.assert_array_equal(lt.cpu().numpy(), ll.cpu().numpy())
+        np.testing.assert_array_equal(dst_t[..., :C + 10].cpu().numpy(), dst_l[..., :C + 10].cpu().numpy())
+        np.testing.assert_allclose(dst_t[..., C + 10].cpu().numpy(), dst_l[..., C + 10].cpu().numpy(), rtol=1e-6, atol=1e-7)
+    ox, oy, oe = XF.adjacency_features(mask[..., None].float(), E, mask)
+    np.testing.assert_allclose(xt.cpu().numpy(), ox.numpy(), atol=1e-6)
+    np.testing.assert_allclose(yt.cpu().numpy(), oy.numpy(), atol=1e-6)
+    np.testing.assert_allclose(dst_t[..., C:].cpu().numpy(), oe.numpy(), rtol=1e-5, atol=1e-6)
+    # a second call on the same (dirty) workspace with a smaller batch gives the same numbers
+    x2, y2, e2, _ = ef_t.adjacency_features(lab8[:2], mc[:2], C)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(x2.cpu().numpy(), xt[:2].cpu().numpy())
+    np.testing.assert_array_equal(y2.cpu().numpy(), yt[:2].cpu().numpy())
+    np.testing.assert_array_equal(e2.cpu().numpy(), dst_t[:2, ..., C:].cpu().numpy())
+
+
+def test_walk_counts_at_1024_nodes_are_exact():
+    """BASELINE config 5 (B=1, n=1024 vessel tree with a few loops): the per-node cycle counts and the reachability bits of
+    the MFMA products against an integer (int64) matrix-power computation on the host."""
+    n, C = 1024, 5
+    gen = torch.Generator().manual_seed(11)
+    lab = torch.zeros(1, n, n, dtype=torch.long)
+    par = [int(torch.randint(max(0, i - 40), i, (1,), generator=gen)) for i in range(1, n)]   # random tree, short-range parents
+    for i, p in enumerate(par, start=1):
+        c = 1 + int(torch.randint(0, C - 1, (1,), generator=gen))
+        lab[0, i, p] = lab[0, p, i] = c
+    for _ in range(60):                                                        # extra edges: cycles of every length
+        i, j = sorted(int(v) for v in torch.randint(0, n, (2,), generator=gen))
+        if i != j:
+            lab[0, i, j] = lab[0, j, i] = 1
+    mask = torch.ones(1, n, dtype=torch.bool)
+    ef = make_ef(n)
+    x, y, e, lap = ef.adjacency_features(labels8(lab, mask), mask.cuda(), C)
+    torch.cuda.synchronize()
+    A = (lab[0] > 0).to(torch.int64)
+    P, reach, diags = A.clone(), [], [torch.diagonal(A).clone()]
+    reach.append(P != 0)
+    for k in range(2, 11):
+        P = P @ A
+        reach.append(P != 0)
+        if k <= 5:
+            diags.append(torch.diagonal(P).clone())
+    d = A.sum(1)
+    tri = diags[2]
+    c4 = diags[3] - d * (d - 1) - A @ d
+    c5 = diags[4] - 2 * tri * d - A @ tri + tri
+    want_x = torch.stack([tri / 2, c4 / 2, c5 / 2], -1).float().clamp(0, 5) / 5
+    np.testing.assert_array_equal(x[0].cpu().numpy(), want_x.numpy())
+    want_r = torch.stack(reach, -1).float() * 0.2
+    np.testing.assert_array_equal(e[0, ..., :10].cpu().numpy(), want_r.numpy())
+    assert np.float32(y[0, 0].item()) == np.float32(min(float(tri.sum()) / 6, 5.0)) * np.float32(0.2)
+    Ld = torch.diag(d) - A
+    np.testing.assert_array_equal(lap[0].cpu().numpy(), Ld.float().numpy())
+
+
+def test_denoiser_at_256_nodes_vessel_dims():
+    """f3_gt_vessel_n256: the reference's GraphTransformer (vessel dims, de = 64) on 256-node graphs; golden rows of the edge
+    logits, all node logits and the per-graph logit sums."""
+    from semantically_consistent_graph_generation_amd.transformer_model import GraphTransformer, model_input
+    g = load_golden("f3_gt_vessel_n256")
+    m = torch.from_numpy(g["node_mask"])
+    E = fx.one_hot_edges(torch.from_numpy(g["labels"]).long(), m, 5)
+    sd = fx.make_state_dict(golden_shapes(g), int(g["seed"]))
+    model = GraphTransformer(int(g["n_layers"]), fx.dims_ns(1, 5, int(g["y"].shape[1])), fx.VESSEL_DIMS["hidden_mlp_dims"],
+                             fx.VESSEL_DIMS["hidden_dims"], fx.dims_ns(1, 5, 0)).eval()
+    model.load_state_dict(sd)
+    model = model.cuda()
+    out = model(model_input(m[..., None].float().cuda(), E.cuda(), torch.from_numpy(g["y"]).cuda(), m.cuda()))
+    torch.cuda.synchronize()
+    oE = out.E.cpu()
+    scale = float(np.abs(g["outE_rows"]).max())
+    assert float((oE[:, g["rows"]] - torch.from_numpy(g["outE_rows"])).abs().max()) / scale < 1e-4
+    assert float((out.X.cpu() - torch.from_numpy(g["outX"])).abs().max()) / float(np.abs(g["outX"]).max()) < 1e-4
+    np.testing.assert_allclose(oE.double().sum(dim=(1, 2)).numpy(), g["outE_sum"], rtol=1e-4, atol=1e-2)
+    assert torch.equal(oE, oE.transpose(1, 2))
