@@ -190,3 +190,15 @@ def test_pos_follows_the_reference_recentring_per_mask_call():
     gm = torch.from_numpy(g["node_mask"])
     np.testing.assert_allclose(NoiseModel.pos_after_masks(torch.from_numpy(g["pos"]) * gm[..., None], gm, 1).numpy(), g["mpos"],
                                atol=1e-6)
+
+
+def test_package_creates_no_streams_of_its_own():
+    """the only extra stream is the engine's (scgg_denoiser_side_stream, wrapped as an ExternalStream); a
+    third stream created from Python hung the GPU box in round 1."""
+    import pathlib
+    import re
+    root = pathlib.Path(__file__).resolve().parents[1] / "semantically_consistent_graph_generation_amd"
+    offenders = [str(p) for p in root.rglob("*.py") if re.search(r"cuda\.Stream\(|hipStreamCreate", p.read_text())]
+    assert offenders == []
+    csrc = [p for p in (root / "csrc").glob("*.hip") if "hipStreamCreate" in p.read_text()]
+    assert [p.name for p in csrc] == ["denoiser.hip"]
