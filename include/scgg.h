@@ -242,6 +242,28 @@ int scgg_projector_finish(scgg_projector* p, const int32_t* perm_host, int64_t n
 int scgg_projector_export(const scgg_projector* p, int32_t b, int8_t* graph_labels_host, uint8_t* blocked_host);
 int64_t scgg_projector_counter(const scgg_projector* p);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Training pieces (row a11): the dropout of the train-mode forward and the loss of training_step
+ * (src/ConStruct/diffusion_model_discrete_3d.py:215-239).
+ *
+ * scgg_dropout replaces nn.Dropout at the reference's dropout sites (transformer_model.py:88-105 layers, :284-340 in /
+ * out MLPs).  The reference draws from torch's global generator; here the mask of `site` is a pure function of
+ * (seed, site, flat index): Philox4x32-10, counter (index low, index high, site, 0xD0), key = seed, kept iff
+ * u >= (float)p, out = x / (float)(1 - p) (p is a double so that 1 - p rounds as the reference's Python float does).  The backward pass calls it again on the incoming gradient (same seed and site).
+ * x == out is allowed.
+ *
+ * scgg_masked_cross_entropy replaces CrossEntropyMetric (src/ConStruct/metrics/abstract_metrics.py:77-93) inside
+ * TrainLoss.forward (src/ConStruct/metrics/train_metrics.py:25-85): rows of C logits, int8 target per row (< 0: row
+ * masked out, as the reference's boolean row selection :40-47).  partial (optional, scgg_masked_cross_entropy_blocks(rows)
+ * floats) receives per-block sums of the cross entropies (their sum / number of rows that take part = the reference's
+ * loss); grad (optional, [rows, C]) receives (softmax - onehot) * grad_scale[0] on the rows that take part and 0
+ * elsewhere (grad_scale is a device scalar: lambda / count * upstream gradient, so no host sync is needed).
+ * ---------------------------------------------------------------------------------------------------------- */
+int scgg_dropout(const float* x, float* out, int64_t numel, double p, uint64_t seed, uint32_t site, void* stream);
+int64_t scgg_masked_cross_entropy_blocks(int64_t rows);
+int scgg_masked_cross_entropy(const float* logits, const int8_t* target, int64_t rows, int32_t C, float* partial,
+                              float* grad, const float* grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,301 @@
+"""Training step of the reference on the MI355X: drop-in pieces for
+``src/ConStruct/diffusion_model_discrete_3d.py`` ``training_step`` (:215-239) and ``forward`` (:184-201),
+``src/ConStruct/metrics/train_metrics.py`` ``TrainLoss`` (:25-85) and the data-parallel gradient exchange Lightning's DDP
+strategy does for it (src/ConStruct/main.py: ``Trainer(strategy="ddp_find_unused_parameters_true")``).
+
+What runs where (round 2):
+  * ``apply_noise``, the extra features, the dropout masks (``scgg_dropout``: Philox per dropout site, re-derived in the
+    backward pass instead of stored) and the loss with its gradient (``scgg_masked_cross_entropy``) are libscgg.so kernels;
+  * the train-mode forward and backward of the network itself are device tensor ops under autograd (rocBLAS GEMMs) over the
+    same parameter tensors the fused inference engine borrows -- NOT the fused HIP kernels: those have no backward yet.
+    ``GraphTransformer.forward`` dispatches here when the module is in training mode;
+  * ``GradientBuckets`` averages the gradients over the ranks with bucketed ``all_reduce`` (RCCL on the GPUs, gloo in the CPU
+    tests), the only collective of the path.
+
+Dropout of the reference (quirk kept): ``GraphTransformer`` never hands its ``dropout`` argument to its layers, so the
+layers always drop with p = 0.1 in training mode (transformer_model.py:309-317); the constructor argument only reaches the
+in / out MLPs, and only with ``dropout_in_and_out``.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .placeholder import PlaceHolder
+
+
+# ------------------------------------------------------------------------------------------------- kernels under autograd
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, site):
+        ctx.p, ctx.seed, ctx.site = p, seed, site
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        _lib.check(_lib.lib().scgg_dropout(_lib.ptr(x), _lib.ptr(out), x.numel(), p, seed, site, _lib.stream_ptr()), "dropout")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        out = torch.empty_like(g)
+        _lib.check(_lib.lib().scgg_dropout(_lib.ptr(g), _lib.ptr(out), g.numel(), ctx.p, ctx.seed, ctx.site, _lib.stream_ptr()),
+                   "dropout (backward)")
+        return out, None, None, None
+
+
+class DropoutSites:
+    """Numbers the dropout sites in call order, as oracle/training.py does (a site is counted even when p = 0)."""
+
+    def __init__(self, p, seed):
+        self.p, self.seed, self.site = float(p), seed, 0
+
+    def __call__(self, x):
+        s = self.site
+        self.site += 1
+        if self.p <= 0.0 or self.seed is None:
+            return x
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise _lib.ScggError("dropout runs on the MI355X in fp32 only")
+        return _Dropout.apply(x, self.p, int(self.seed), s)
+
+
+class _MaskedCE(torch.autograd.Function):
+    """sum of cross entropies over the rows whose target is >= 0, / their number (CrossEntropyMetric, abstract_metrics.py:77-93)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, count):
+        logits = logits.contiguous()
+        rows, C_ = logits.numel() // logits.shape[-1], logits.shape[-1]
+        nb = int(_lib.lib().scgg_masked_cross_entropy_blocks(rows))
+        partial = torch.empty(max(nb, 1), device=logits.device)
+        _lib.check(_lib.lib().scgg_masked_cross_entropy(_lib.ptr(logits), _lib.ptr(target), rows, C_, _lib.ptr(partial), None, None,
+                                                        _lib.stream_ptr()), "masked_cross_entropy")
+        ctx.save_for_backward(logits, target, count)
+        return partial[:nb].sum() / count
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, count = ctx.saved_tensors
+        rows, C_ = logits.numel() // logits.shape[-1], logits.shape[-1]
+        scale = (g / count).reshape(1).float().contiguous()
+        grad = torch.empty_like(logits)
+        _lib.check(_lib.lib().scgg_masked_cross_entropy(_lib.ptr(logits), _lib.ptr(target), rows, C_, None, _lib.ptr(grad),
+                                                        _lib.ptr(scale), _lib.stream_ptr()), "masked_cross_entropy (backward)")
+        return grad, None, None
+
+
+def masked_cross_entropy(logits, target):
+    """logits [..., C] fp32 on the device, target int8 [...] (-1 = row masked out).  0 when no row takes part."""
+    if not logits.is_cuda:
+        raise _lib.ScggError("masked_cross_entropy runs on the MI355X only")
+    target = target.to(torch.int8).contiguous()
+    count = (target >= 0).sum().clamp(min=1).float()
+    return _MaskedCE.apply(logits.float(), target, count)
+
+
+class TrainLoss(torch.nn.Module):
+    """train_metrics.py:25-85 for the discrete node / edge terms (CoW / ATM setting: no charges, no y, no radius term):
+    ``lambda_train = [X, charges, E, y]``; ``forward(pred, true_X_labels, true_E_labels, node_mask)`` with integer label
+    tensors of the clean data (the reference takes one-hots and argmaxes them, :40-47)."""
+
+    def __init__(self, lambda_train=(1.0, 2.0, 5.0, 0.0)):
+        super().__init__()
+        self.lambda_train = tuple(float(v) for v in lambda_train)
+
+    def forward(self, pred, true_X_labels, true_E_labels, node_mask):
+        n = node_mask.shape[1]
+        eye = torch.eye(n, dtype=torch.bool, device=node_mask.device)[None]
+        live = node_mask[:, :, None] & node_mask[:, None, :] & ~eye
+        tE = torch.where(live, true_E_labels.to(torch.int8), torch.full_like(true_E_labels, -1, dtype=torch.int8))
+        tX = torch.where(node_mask, true_X_labels.to(torch.int8), torch.full_like(true_X_labels, -1, dtype=torch.int8))
+        loss_X = masked_cross_entropy(pred.X, tX)
+        loss_E = masked_cross_entropy(pred.E, tE)
+        return self.lambda_train[0] * loss_X + self.lambda_train[2] * loss_E
+
+
+# ------------------------------------------------------------------------------------------------- train-mode forward
+def _lin(m, x):
+    return F.linear(x, m.weight, m.bias)
+
+
+def _ln(m, x):
+    return F.layer_norm(x, m.normalized_shape, m.weight, m.bias, m.eps)
+
+
+def _mask_xe(X, E, m, offdiag):
+    return X * m[:, :, None], E * (m[:, :, None] * m[:, None, :] * offdiag)[..., None]
+
+
+def _node_stats(X, m):
+    w = m[:, :, None]
+    cnt = w.sum(dim=1)
+    mean = X.sum(dim=1) / cnt
+    big = 1e5 * (1.0 - w)
+    var = (((X - mean[:, None, :]) ** 2) * w).sum(dim=1) / cnt
+    return torch.cat([mean, (X + big).min(dim=1).values, (X - big).max(dim=1).values, var], dim=1)
+
+
+def _edge_stats(E, m):
+    pm = (m[:, :, None] * m[:, None, :])[..., None]
+    cnt = pm.sum(dim=(1, 2))
+    mean = E.sum(dim=(1, 2)) / cnt
+    big = 1e5 * (1.0 - pm)
+    var = (((E - mean[:, None, None, :]) ** 2) * pm).sum(dim=(1, 2)) / cnt
+    return torch.cat([mean, (E + big).amin(dim=(1, 2)), (E - big).amax(dim=(1, 2)), var], dim=1)
+
+
+def _block(a, X, E, y, m, node_mask):
+    """NodeEdgeBlock.forward (transformer_model.py:165-248) on the parameter holder ``a``."""
+    xm = m[:, :, None]
+    pm = (m[:, :, None] * m[:, None, :])[..., None]
+    Q, K, V = _lin(a.q, X) * xm, _lin(a.k, X) * xm, _lin(a.v, X) * xm
+    Y = (Q[:, :, None, :] * K[:, None, :, :]) / math.sqrt(a.df)
+    Y = Y * (_lin(a.e_mul, E) * pm + 1.0) + _lin(a.e_add, E) * pm
+    newE = _lin(a.e_out, _lin(a.y_e_add, y)[:, None, None, :] + (_lin(a.y_e_mul, y)[:, None, None, :] + 1.0) * Y) * pm
+    attn = torch.softmax(Y.masked_fill(~node_mask[:, None, :, None], float("-inf")), dim=2)
+    wV = (attn * V[:, None, :, :]).sum(dim=2)
+    newX = _lin(a.x_out, _lin(a.y_x_add, y)[:, None, :] + (_lin(a.y_x_mul, y)[:, None, :] + 1.0) * wV) * xm
+    new_y = None
+    if a.predicts_y:
+        z = _lin(a.y_y, y) + _lin(a.x_y.lin, _node_stats(X, m)) + _lin(a.e_y.lin, _edge_stats(E, m))
+        new_y = _lin(a.y_out[2], torch.relu(_lin(a.y_out[0], z)))
+    return newX, newE, new_y
+
+
+def train_forward(model, X, E, y, node_mask, seed=None, p_layer=None):
+    """GraphTransformer.forward in training mode (transformer_model.py:344-389 with the dropout sites of :88-105 and
+    :284-340), differentiable.  ``seed`` None: no dropout (the fixtures' setting); ``p_layer`` defaults to the reference's
+    hard-wired 0.1.  Dropout site numbers: in-MLPs 0..5 (E, X, y; two each), layer l: 100 + 16 l + (0..8) in the order
+    X1, X2-inner, X2-outer, E1, E2-inner, E2-outer, y1, y2-inner, y2-outer; out-MLPs 50, 51, 52 (X, E, y)."""
+    if not X.is_cuda:
+        raise _lib.ScggError("the training forward runs on the MI355X only; move the inputs to the GPU")
+    p_layer = 0.1 if p_layer is None else p_layer
+    p_io = model.dropout if model.dropout_in_and_out else 0.0
+    dio, dl = DropoutSites(p_io, seed), DropoutSites(p_layer, seed)
+    node_mask = node_mask.bool()
+    m = node_mask.to(X.dtype)
+    n = X.shape[1]
+    offdiag = (1.0 - torch.eye(n, dtype=X.dtype, device=X.device))[None]
+    oXc = model.out_dim_X + model.out_dim_charges
+
+    def mlp_in(seq, x):
+        return dio(torch.relu(_lin(seq[3], dio(torch.relu(_lin(seq[0], x))))))
+
+    def mlp_out(seq, x):
+        return _lin(seq[3], dio(torch.relu(_lin(seq[0], x))))
+    hE = mlp_in(model.mlp_in_E, E)
+    hE = (hE + hE.transpose(1, 2)) / 2
+    hX = mlp_in(model.mlp_in_X, X)
+    hy = mlp_in(model.mlp_in_y, y)
+    hX, hE = _mask_xe(hX, hE, m, offdiag)
+    for l, layer in enumerate(model.tf_layers):
+        dl.site = 100 + 16 * l
+        newX, newE, new_y = _block(layer.self_attn, hX, hE, hy, m, node_mask)
+        hX = _ln(layer.normX1, hX + dl(newX))
+        hX = _ln(layer.normX2, hX + dl(_lin(layer.linX2, dl(torch.relu(_lin(layer.linX1, hX))))))
+        hE = _ln(layer.normE1, hE + dl(newE))
+        hE = _ln(layer.normE2, hE + dl(_lin(layer.linE2, dl(torch.relu(_lin(layer.linE1, hE))))))
+        hE = 0.5 * (hE + hE.transpose(1, 2))
+        if layer.predicts_y:
+            hy = _ln(layer.norm_y1, hy + dl(new_y))
+            hy = _ln(layer.norm_y2, hy + dl(_lin(layer.lin_y2, dl(torch.relu(_lin(layer.lin_y1, hy))))))
+        else:
+            hy = None
+        hX, hE = _mask_xe(hX, hE, m, offdiag)
+    dio.site = 50
+    oX = mlp_out(model.mlp_out_X, hX) + X[..., :oXc]
+    oE = (mlp_out(model.mlp_out_E, hE) + E[..., : model.out_dim_E]) * offdiag[..., None]
+    oE = 0.5 * (oE + oE.transpose(1, 2))
+    oy = mlp_out(model.mlp_out_y, hy) + y[..., : model.out_dim_y] if model.predicts_final_y else None
+    oX, oE = _mask_xe(oX, oE, m, offdiag)
+    return PlaceHolder(X=oX[..., : model.out_dim_X], charges=oX[..., model.out_dim_X:], E=oE, y=oy, node_mask=node_mask)
+
+
+# ------------------------------------------------------------------------------------------------- the step
+def training_step(model, noise_model, extra_features, dense_data, true_E_labels, loss_fn=None, t_int=None, rng=None,
+                  dropout_seed=None):
+    """diffusion_model_discrete_3d.py:215-239: z_t = apply_noise(x_0), extra features, train-mode forward, TrainLoss.
+    Returns (loss, pred, z_t); the caller does ``loss.backward()`` and the optimizer step (Lightning does in the reference).
+    ``dense_data``: PlaceHolder of the clean batch (one-hot X / E, node_mask, optional pos); ``true_E_labels`` its integer
+    edge classes [B,n,n]."""
+    loss_fn = loss_fn or TrainLoss()
+    z_t = noise_model.apply_noise(dense_data, t_int=t_int, rng=rng)
+    extra = extra_features(z_t)
+    X = torch.cat((z_t.X, z_t.charges, extra.X), dim=2).float()
+    E = torch.cat((z_t.E, extra.E), dim=3).float()
+    y = torch.hstack((z_t.y, extra.y, z_t.t)).float()
+    pred = train_forward(model, X, E, y, z_t.node_mask, seed=dropout_seed)
+    true_X = dense_data.X.argmax(dim=-1)
+    loss = loss_fn(pred, true_X, true_E_labels, z_t.node_mask)
+    return loss, pred, z_t
+
+
+# ------------------------------------------------------------------------------------------------- data-parallel gradients
+class GradientBuckets:
+    """Average the gradients of ``params`` over the ranks of ``group``: parameters in reverse registration order (the order
+    backward produces them) are packed into flat buckets of about ``bucket_mb`` and every bucket is one ``all_reduce``
+    (RCCL over xGMI on the GPUs; the ring is per-link bound, so few large messages -- the default bucket holds the whole
+    4.6 M-parameter ConStruct model, 18 MB).  Parameters without a gradient on this rank contribute zeros (the reference runs
+    DDP with find_unused_parameters: the last layer's y modules have none).  ``hook=True`` starts a bucket's all_reduce from
+    the autograd hook of its last parameter, overlapped with the rest of backward; ``finish()`` waits and unpacks."""
+
+    def __init__(self, params, group=None, bucket_mb=25.0, hook=False):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.params = [p for p in params if p.requires_grad][::-1]
+        self.buckets, cur, size = [], [], 0
+        for p in self.params:
+            cur.append(p)
+            size += p.numel() * 4
+            if size >= bucket_mb * 2 ** 20:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self._flat = [None] * len(self.buckets)
+        self._work = [None] * len(self.buckets)
+        self._pending = None
+        if hook:
+            self._pending = [len(b) for b in self.buckets]
+            for bi, b in enumerate(self.buckets):
+                for p in b:
+                    p.register_post_accumulate_grad_hook(lambda _p, bi=bi: self._ready(bi))
+
+    def world(self):
+        return self.dist.get_world_size(self.group) if self.dist.is_initialized() else 1
+
+    def _launch(self, bi):
+        b = self.buckets[bi]
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in b])
+        self._flat[bi] = flat
+        if self.world() > 1:
+            self._work[bi] = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _ready(self, bi):
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+
+    def finish(self):
+        """Call after ``loss.backward()``: launches what the hooks have not, waits, writes the averaged gradients back."""
+        w = self.world()
+        for bi, b in enumerate(self.buckets):
+            if self._flat[bi] is None:
+                self._launch(bi)
+        for bi, b in enumerate(self.buckets):
+            if self._work[bi] is not None:
+                self._work[bi].wait()
+            flat, off = self._flat[bi] / w, 0
+            for p in b:
+                g = flat[off: off + p.numel()].view_as(p)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += p.numel()
+            self._flat[bi] = self._work[bi] = None
+        if self._pending is not None:
+            self._pending = [len(b) for b in self.buckets]

@@ -172,8 +172,6 @@ class GraphTransformer(nn.Module):
         X, E, y, m = model_input.X, model_input.E, model_input.y, model_input.node_mask
         if not X.is_cuda:
             raise _lib.ScggError("GraphTransformer.forward runs on the MI355X only; move the inputs to the GPU")
-        if self.training and (self.dropout > 0):
-            raise NotImplementedError("training mode (dropout + autograd, SURVEY.md row a11) is not built yet; call .eval()")
         B, n = X.shape[0], X.shape[1]
         if X.shape[2] != self.in_dim_X or E.shape[3] != self.in_dim_E or y.shape[1] != self.in_dim_y:
             raise _lib.ScggError(f"input widths {X.shape[2]},{E.shape[3]},{y.shape[1]} do not match the model "
@@ -191,10 +189,20 @@ class GraphTransformer(nn.Module):
         return torch.cuda.ExternalStream(p, device=device)
 
     # ------------------------------------------------------------------------------------------------- forward
-    @torch.no_grad()
+    dropout_seed = None     # training mode: seed of the Philox dropout masks of the next forward (None: no dropout)
+
     def forward(self, model_input):
         """model_input: object with .X[B,n,dX] .E[B,n,n,dE] .y[B,dy] .node_mask[B,n]  ->  PlaceHolder(X, charges, E,
-        y, node_mask), masked (reference transformer_model.py:344-389)."""
+        y, node_mask), masked (reference transformer_model.py:344-389).  Eval mode: the fused HIP engine, no autograd.
+        Training mode: the differentiable forward of training.py (device tensor ops + the dropout kernel)."""
+        if self.training:
+            from .training import train_forward
+            return train_forward(self, model_input.X.float(), model_input.E.float(), model_input.y.float(),
+                                 model_input.node_mask, seed=self.dropout_seed)
+        return self._forward_eval(model_input)
+
+    @torch.no_grad()
+    def _forward_eval(self, model_input):
         X, E, y, m, B, n = self._inputs(model_input)
         eng = self._ensure_engine(X.device)
         ws, ws_bytes = self._workspace(B, n, X.device)

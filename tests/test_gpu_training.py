@@ -1,0 +1,175 @@
+"""GPU parity of the training step (row a11) against the reference fixture F10 (apply_noise + train-mode forward with dropout
+0 + TrainLoss + backward, recorded from the real reference) and against the oracle's train-mode forward with dropout on."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import denoiser as D
+from oracle import fixtures as fx
+from oracle import training as TR
+from test_host_logic import make_noise_model
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol, atol):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def tiny_model(C, n_layers, seed):
+    from semantically_consistent_graph_generation_amd.transformer_model import GraphTransformer
+    model = GraphTransformer(n_layers, fx.dims_ns(1, C, 1), fx.TINY_DIMS["hidden_mlp_dims"], fx.TINY_DIMS["hidden_dims"], fx.dims_ns(1, C, 0))
+    sd = fx.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed)
+    model.load_state_dict(sd)
+    return model.cuda(), sd
+
+
+@pytest.mark.parametrize("name", ["f10_training_atm_tiny", "f10_training_cow_marg_tiny"])
+def test_training_step_matches_reference(name):
+    """z_t bit-exact, logits 1e-4, loss 1e-5, every parameter gradient 1e-3 (the fixture's own tolerance in the oracle test)."""
+    from semantically_consistent_graph_generation_amd.extra_features import DummyExtraFeatures
+    from semantically_consistent_graph_generation_amd.noise_model import Rng
+    from semantically_consistent_graph_generation_amd.placeholder import PlaceHolder
+    from semantically_consistent_graph_generation_amd.training import training_step, TrainLoss
+    g = load_golden(name)
+    C = int(g["C"])
+    m = torch.from_numpy(g["node_mask"])
+    nm = make_noise_model(str(g["transition"]), C, T=500, top_k=4, e_marg=g["e_marginals"] if g["e_marginals"].size else None)
+    model, sd = tiny_model(C, int(g["n_layers"]), int(g["sd_seed"]))
+    model.train()
+    lab0 = torch.from_numpy(g["labels0"]).long()
+    dense = PlaceHolder(X=m[..., None].float().cuda(), charges=torch.zeros(*m.shape, 0, device="cuda"),
+                        E=fx.one_hot_edges(lab0, m, C).cuda(), y=torch.zeros(m.shape[0], 0, device="cuda"), node_mask=m.cuda(),
+                        pos=torch.from_numpy(g["pos"]).cuda())
+    loss, pred, z_t = training_step(model, nm, DummyExtraFeatures(), dense, lab0.cuda(), loss_fn=TrainLoss((1.0, 2.0, 5.0, 0.0)),
+                                    t_int=torch.from_numpy(g["t_int"]).cuda(), rng=Rng(u0=torch.from_numpy(g["u0"]).cuda()),
+                                    dropout_seed=None)
+    loss.backward()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(z_t.E.cpu().numpy(), g["zt_E"])
+    close(pred.E, g["logits_E"], 1e-4, 1e-5)
+    close(loss, g["loss"], 1e-5, 1e-6)
+    checked = 0
+    for k, p in model.named_parameters():
+        gr = p.grad if p.grad is not None else torch.zeros_like(p)
+        if "grad/" + k in g:
+            close(gr, g["grad/" + k], 1e-3, 2e-6)
+            checked += 1
+        elif "gradhead/" + k in g:
+            close(gr.flatten()[:1024], g["gradhead/" + k], 1e-3, 2e-6)
+            close(gr.double().norm(), g["gradstat/" + k][0], 1e-4, 1e-5)
+            close(gr.double().sum(), g["gradstat/" + k][1], 1e-4, 2e-5 * float(g["gradstat/" + k][0]))   # a cancelling sum of 32768 terms
+            checked += 1
+    assert checked == len(list(model.named_parameters()))
+    # eval mode on the same weights: the fused engine gives the same logits as the differentiable forward
+    from semantically_consistent_graph_generation_amd.transformer_model import model_input
+    model.eval()
+    X = z_t.X.float()
+    E = z_t.E.float()
+    y = z_t.t.float()
+    out = model(model_input(X, E, y, z_t.node_mask))
+    close(out.E, pred.E.detach(), 1e-4, 2e-5)
+
+
+def test_dropout_kernel_is_the_oracle_stream():
+    """scgg_dropout == oracle/training.py:dropout_keep bit for bit (mask and scaling), forward and backward."""
+    from semantically_consistent_graph_generation_amd.training import DropoutSites
+    x = torch.randn(7, 33, 5, generator=torch.Generator().manual_seed(2))
+    for p, seed, site in ((0.1, 12345, 0), (0.5, (7 << 32) | 9, 117), (0.9, 1, 52)):
+        d = DropoutSites(p, seed)
+        d.site = site
+        xc = x.cuda().requires_grad_(True)
+        out = d(xc)
+        out.sum().backward()
+        keep = torch.from_numpy(TR.dropout_keep(seed, site, x.numel(), p)).reshape(x.shape)
+        want = x * keep.to(x.dtype) / (1.0 - p)
+        np.testing.assert_array_equal(out.detach().cpu().numpy(), want.numpy())
+        np.testing.assert_array_equal(xc.grad.cpu().numpy(), (torch.ones_like(x) * keep / (1.0 - p)).numpy())
+        assert abs(float(keep.float().mean()) - (1 - p)) < 0.05
+
+
+def test_train_forward_with_dropout_matches_oracle():
+    """Train-mode forward with the reference's layer dropout (p = 0.1) and in / out dropout on, seeded: the device masks
+    are the oracle's, so the logits agree to the fp32 tolerance; the gradients through the dropped network agree too."""
+    from semantically_consistent_graph_generation_amd.training import train_forward, masked_cross_entropy
+    C, n_layers, seed = 5, 2, 99
+    model, sd = tiny_model(C, n_layers, 21)
+    model.dropout, model.dropout_in_and_out = 0.2, True
+    model.train()
+    m = fx.ragged_mask([9, 4, 11])
+    B, n = m.shape
+    gen = torch.Generator().manual_seed(3)
+    lab = fx.random_labels(m, C, 0.3, 4)
+    E = fx.one_hot_edges(lab, m, C)
+    X = m[..., None].float()
+    y = torch.rand(B, 1, generator=gen)
+    pred = train_forward(model, X.cuda(), E.cuda(), y.cuda(), m.cuda(), seed=seed)
+    live = (m[:, :, None] & m[:, None, :]) & ~torch.eye(n, dtype=torch.bool)[None]
+    tgt = torch.where(live, lab, torch.full_like(lab, -1))
+    loss = masked_cross_entropy(pred.E, tgt.cuda())
+    loss.backward()
+    dd = D.DenoiserDims(n_layers, fx.TINY_DIMS["hidden_dims"]["n_head"], 1, C, 0)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oX, _, oE, _ = TR.graph_transformer_train(leaf, dd, X, E, y, m, p_layer=0.1, p_io=0.2, seed=seed)
+    oloss = torch.nn.functional.cross_entropy(oE[live], lab[live], reduction="sum") / int(live.sum())
+    oloss.backward()
+    close(pred.E, oE.detach(), 1e-4, 1e-5)
+    close(loss, oloss.detach(), 1e-5, 1e-6)
+    for k, p in model.named_parameters():
+        og = leaf[k].grad if leaf[k].grad is not None else torch.zeros_like(leaf[k])
+        close(p.grad if p.grad is not None else torch.zeros_like(p), og, 2e-3, 5e-6)
+    # and the masks matter: another seed gives other logits
+    pred2 = train_forward(model, X.cuda(), E.cuda(), y.cuda(), m.cuda(), seed=seed + 1)
+    assert float((pred2.E - pred.E).abs().max()) > 1e-3
+
+
+def test_masked_cross_entropy_kernel_against_torch():
+    from semantically_consistent_graph_generation_amd.training import masked_cross_entropy
+    gen = torch.Generator().manual_seed(5)
+    for rows, C in ((1, 1), (300, 14), (5000, 5)):
+        z = (3 * torch.randn(rows, C, generator=gen)).cuda().requires_grad_(True)
+        t = torch.randint(-1, C, (rows,), generator=gen)
+        loss = masked_cross_entropy(z, t.cuda())
+        (2.5 * loss).backward()
+        zc = z.detach().cpu().double().requires_grad_(True)
+        keep = t >= 0
+        ref = torch.nn.functional.cross_entropy(zc[keep], t[keep], reduction="sum") / max(int(keep.sum()), 1)
+        (2.5 * ref).backward()
+        close(loss, ref.detach(), 1e-6, 1e-6)
+        close(z.grad, zc.grad, 1e-5, 1e-7)
+
+
+def test_training_step_with_extra_features_runs_and_learns():
+    """The full step at CoW widths with extra features on: a few Adam steps on one batch lower the loss (smoke for the
+    pieces working together: apply_noise -> features -> train forward -> loss -> backward -> engine refresh in eval)."""
+    from types import SimpleNamespace
+    from semantically_consistent_graph_generation_amd.extra_features import ExtraFeatures
+    from semantically_consistent_graph_generation_amd.noise_model import Rng
+    from semantically_consistent_graph_generation_amd.placeholder import PlaceHolder
+    from semantically_consistent_graph_generation_amd.training import training_step
+    from semantically_consistent_graph_generation_amd.transformer_model import GraphTransformer
+    C = 14
+    cfg = SimpleNamespace(model=SimpleNamespace(num_degree=10, max_degree=10, cycle_features=True, num_eigenvectors=5, num_eigenvalues=9,
+                                                eigenfeatures=True))
+    ef = ExtraFeatures(cfg, SimpleNamespace(max_n_nodes=16))
+    in_dims = ef.update_input_dims(fx.dims_ns(1, C, 1))
+    torch.manual_seed(0)
+    model = GraphTransformer(2, in_dims, fx.TINY_DIMS["hidden_mlp_dims"], fx.TINY_DIMS["hidden_dims"], fx.dims_ns(1, C, 0)).cuda().train()
+    nm = make_noise_model("absorbing_edges", C, T=50, top_k=4)
+    m = fx.ragged_mask([16, 9, 12, 5])
+    lab0 = fx.random_labels(m, C, 0.15, 8)
+    dense = PlaceHolder(X=m[..., None].float().cuda(), charges=torch.zeros(*m.shape, 0, device="cuda"), E=fx.one_hot_edges(lab0, m, C).cuda(),
+                        y=torch.zeros(m.shape[0], 0, device="cuda"), node_mask=m.cuda(), pos=None)
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-3)
+    losses = []
+    for it in range(12):
+        opt.zero_grad()
+        loss, _, _ = training_step(model, nm, ef, dense, lab0.cuda(), t_int=torch.full((4, 1), 25, device="cuda"),
+                                   rng=Rng(seed=3, step=0), dropout_seed=100 + it)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < 0.8 * losses[0], losses

@@ -115,3 +115,50 @@ def test_bench_refuses_a_world_that_contradicts_gpus():
     rc, line, err = _bench(["--gpus", "4", "--batch", "2", "--steps", "1", "--warmup", "0"],
                            env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
     assert rc != 0 and line is None and "WORLD_SIZE=1" in err
+
+
+def _ddp_worker(rank, world, port, out):
+    import os
+    import torch
+    import torch.distributed as dist
+    from semantically_consistent_graph_generation_amd.training import GradientBuckets
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    unused = torch.nn.Linear(4, 4)                                   # no gradient on any rank (find_unused_parameters)
+    params = list(net.parameters()) + list(unused.parameters())
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(8, 6, generator=g)
+    Y = torch.randn(8, 3, generator=g)
+    for hook in (False, True):
+        for p in params:
+            p.grad = None
+        gb = GradientBuckets(params, bucket_mb=0.0001, hook=hook)     # several small buckets
+        assert len(gb.buckets) > 2
+        sl = slice(rank * 4, rank * 4 + 4)                           # this rank's half of the global batch
+        ((net(X[sl]) - Y[sl]) ** 2).mean().backward()
+        gb.finish()
+        out[(rank, hook)] = [p.grad.clone() for p in params]
+    if rank == 0:
+        for p in params:
+            p.grad = None
+        ((net(X) - Y) ** 2).mean().backward()                        # the same global batch in one process
+        out["full"] = [(p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for p in params]
+    dist.destroy_process_group()
+
+
+def test_gradient_buckets_average_equals_single_process_gradient():
+    """World size 2 on gloo: the bucketed all-reduce of two half batches == the gradient of the whole batch in one process
+    (mean loss, equal shard sizes), with and without the backward hooks; parameters without a gradient come back as zeros."""
+    import torch
+    import torch.multiprocessing as mp
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_ddp_worker, args=(2, port, out), nprocs=2, join=True)
+        full = out["full"]
+        for hook in (False, True):
+            for r in range(2):
+                for a, b in zip(out[(r, hook)], full):
+                    torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
