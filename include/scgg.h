@@ -264,6 +264,29 @@ int64_t scgg_masked_cross_entropy_blocks(int64_t rows);
 int scgg_masked_cross_entropy(const float* logits, const int8_t* target, int64_t rows, int32_t C, float* partial,
                               float* grad, const float* grad_scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Stress configuration (BASELINE.json configs[4]): NodeEdgeBlock.forward (transformer_model.py:165-248, without the y
+ * update) on a bf16 edge tensor, de = 128 (or 64), dx = 256, n <= 1024.
+ *   E_in / newE: bf16 [B,n,n,de] (raw 16-bit words, torch.bfloat16 storage).  Q / K / V: fp32 rows with stride ldqkv,
+ *   already masked (:181-183).  film: fp32 [B, 4 dx] = [y_e_add | y_e_mul + 1 | y_x_add | y_x_mul + 1](y).
+ *   image: scgg_edge_block_bf16_image_bytes(dx, de) bytes filled by scgg_edge_block_bf16_pack from e_mul / e_add / e_out
+ *   (weights rounded to bf16, biases fp32).  units / unit_count: row * ceil(n/16) + chunk of every (valid row, 16-key chunk
+ *   with a valid key) and their number (device scalar).  newE gets e_out(...) * m_i m_j on those rows (rows of padded nodes
+ *   are not written: zero the buffer first); attn_part [B*n*ceil(n/16), 3, dx] gets the per-unit softmax partials, which
+ *   scgg_attn_merge turns into newX_pre = y_x_add + (y_x_mul + 1) * weighted V for the rows listed in rows / row_count.
+ * Arithmetic: one bf16 MFMA per product, fp32 accumulation: results agree with the fp32 reference to bf16 rounding of
+ * E, the weights and the FiLM'ed Y (tests/test_gpu_stress_bf16.py states the bound).
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t scgg_edge_block_bf16_image_bytes(int32_t dx, int32_t de);
+int scgg_edge_block_bf16_pack(const float* W_mul, const float* b_mul, const float* W_add, const float* b_add,
+                              const float* W_out, int32_t dx, int32_t de, void* image, void* stream);
+int scgg_edge_block_bf16(const uint16_t* E_in, uint16_t* newE, const uint8_t* node_mask, const float* Q, const float* K,
+                         const float* V, int32_t ldqkv, const float* film, const void* image, const float* b_out,
+                         float* attn_part, const int32_t* units, const int32_t* unit_count, int32_t B, int32_t n,
+                         int32_t dx, int32_t de, int32_t n_head, void* stream);
+int scgg_attn_merge(const float* attn_part, const uint8_t* node_mask, const float* film, float* newX_pre,
+                    const int32_t* rows, const int32_t* row_count, int32_t max_rows, int32_t n, int32_t dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,8 +13,8 @@
 //   2 adj_scale      Wc = A diag(c), Wr = diag(c) A^T with c_j = 1/sqrt(log deg_j) (0 when deg_j <= 1); Laplacian
 //   3 adj_gemm x K-1 P_k = P_{k-1} A; epilogue: diag(P_k) for k <= 6, reach bit k-1 = (P_k != 0)
 //     adj_gemm       S = Wc Wr
-//   4 adj_node       per-node 3/4/5-cycle counts, the graph-level sums (in fp64: exact wherever the reference's fp32 sums
-//                    are), histograms
+//   4 adj_rows       one wave per row: per-node 3/4/5-cycle counts, the row's terms of the graph-level sums (fp64: exact
+//                    wherever the reference's fp32 sums are), histogram votes;  adj_graph: one workgroup per graph sums them
 //   5 adj_pair       pair rows [one-hot | reach bits 0..K-1 | Adamic-Adar], contiguous stores
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -34,8 +34,9 @@ struct TiledPlanes {                   // carved out of the workspace by plan()
   uint32_t* reach;                     // [B,np,np] bit k-1 = (A^k)_ij != 0
   float* diag;                         // [6][B][np] diagonals of A^1..A^6
   float* deg;                          // [B][np]
-  int* hist;                           // [B][64] edge-class counts over live ordered pairs
+  int* hist;                           // [3][B][64] edge-class counts over live ordered pairs | degree histogram | node-class histogram
   int* nvalid;                         // [B]
+  double* rowpart;                     // [B][np][12] per-row terms of the graph-level sums
   size_t bytes;
 };
 
@@ -51,8 +52,9 @@ static TiledPlanes plan(void* ws, int B, int np) {
   p.reach = (uint32_t*)take(plane);
   p.diag = (float*)take((size_t)6 * B * np * sizeof(float));
   p.deg = (float*)take((size_t)B * np * sizeof(float));
-  p.hist = (int*)take((size_t)B * 64 * sizeof(int));
+  p.hist = (int*)take((size_t)3 * B * 64 * sizeof(int));
   p.nvalid = (int*)take((size_t)B * sizeof(int));
+  p.rowpart = (double*)take((size_t)B * np * 12 * sizeof(double));
   p.bytes = off;
   return p;
 }
@@ -168,13 +170,14 @@ __global__ __launch_bounds__(256) void adj_gemm_kernel(const float* __restrict__
   }
 }
 
-// ---- 4: one workgroup per graph
+// ---- 4a: one wave per (row, graph): per-node cycle counts, the row's terms of the graph-level sums, histogram votes
 struct TiledNodeArgs {
   const float *A, *A2, *A3, *diag, *deg;
-  const int* hist;
+  int* hist;                           // [3][B][64]
   const int* nvalid;
   const uint8_t* mask;
   const int8_t* node_labels;
+  double* rowpart;
   float *x_out, *y_out;
   int B, n, np, C, Cx, num_degree, cycle_features, x_ld, x_off, y_ld, y_off;
 };
@@ -185,75 +188,73 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void adj_node_kernel(TiledNodeArgs a) {
-  __shared__ double red[4][12];
-  __shared__ int dh[64];
-  __shared__ int xh[64];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = a.n, np = a.np;
+__global__ __launch_bounds__(256) void adj_rows_kernel(TiledNodeArgs a) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6), n = a.n, np = a.np;
+  if (i >= n) return;
   const long long pl = (long long)b * np * np;
-  const float* A = a.A + pl;
-  const float* A2 = a.A2 + pl;
-  const float* A3 = a.A3 + pl;
+  const float* A = a.A + pl + (long long)i * np;
+  const float* A2 = a.A2 + pl + (long long)i * np;
+  const float* A3 = a.A3 + pl + (long long)i * np;
   const float* deg = a.deg + (long long)b * np;
   const long long dstride = (long long)a.B * np;
-  const float* dg = a.diag + (long long)b * np;          // + (k-1)*dstride
-  const uint8_t* m = a.mask + (long long)b * n;
-  if (tid < 64) { dh[tid] = 0; xh[tid] = 0; }
-  __syncthreads();
-  // per-node counts; lane 0 of each wave accumulates the graph-level terms
-  double s3 = 0, s4 = 0, s5 = 0, t1 = 0, t2 = 0, t4 = 0, t5 = 0, t7 = 0, t9 = 0, t10 = 0;
-  for (int i = wave; i < n; i += 4) {
-    float Ad = 0.f, At = 0.f;
-    for (int j = lane; j < n; j += 64) {
-      const float v = A[(long long)i * np + j];
-      Ad += v * deg[j];
-      At += v * dg[2 * dstride + j];
-    }
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) { Ad += __shfl_xor(Ad, s); At += __shfl_xor(At, s); }
-    if (lane == 0) {
-      const float d = deg[i], d2 = dg[dstride + i], d3 = dg[2 * dstride + i], d4 = dg[3 * dstride + i],
-                  d5 = dg[4 * dstride + i], d6 = dg[5 * dstride + i];
-      const float c3 = d3, c4 = d4 - d * (d - 1.f) - Ad, c5 = d5 - 2.f * d3 * d - At + d3;
-      float* x = a.x_out + ((long long)b * n + i) * a.x_ld + a.x_off;
-      const float keep = (m[i] && a.cycle_features) ? 1.f : 0.f;
-      x[0] = clamp05t(c3 * 0.5f) * keep;
-      x[1] = clamp05t(c4 * 0.5f) * keep;
-      x[2] = clamp05t(c5 * 0.5f) * keep;
-      s3 += c3; s4 += c4; s5 += c5; t1 += d6; t2 += (double)d3 * d3; t4 += (double)d2 * d4; t5 += d4;
-      t7 += (double)d2 * d2 * d2; t9 += (double)d2 * d2; t10 += d2;
-      if (m[i]) {
-        int di = (int)d;
-        if (di > a.num_degree) di = a.num_degree + 1;
-        atomicAdd(&dh[di], 1);
-        const int xc = a.node_labels ? a.node_labels[(long long)b * n + i] : 0;
-        if (xc >= 0 && xc < 64) atomicAdd(&xh[xc], 1);
-      }
-    }
-  }
-  // sum(A^3) and sum(A o (A^2)^2) over the n x n block
+  const float* dg = a.diag + (long long)b * np;
+  float Ad = 0.f, At = 0.f;
   double sA3 = 0, sAA = 0;
-  for (long long idx = tid; idx < (long long)n * n; idx += 256) {
-    const int i = (int)(idx / n), j = (int)(idx - (long long)i * n);
-    const long long o = (long long)i * np + j;
-    const float a2 = A2[o];
-    sA3 += A3[o];
-    sAA += (double)A[o] * a2 * a2;
+  for (int j = lane; j < n; j += 64) {
+    const float v = A[j], a2 = A2[j];
+    Ad += v * deg[j];
+    At += v * dg[2 * dstride + j];
+    sA3 += A3[j];
+    sAA += (double)v * a2 * a2;
   }
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) { Ad += __shfl_xor(Ad, s); At += __shfl_xor(At, s); }
   sA3 = wave_sum_d(sA3);
   sAA = wave_sum_d(sAA);
-  if (lane == 0) {
-    double* r = red[wave];
-    r[0] = s3; r[1] = s4; r[2] = s5; r[3] = t1; r[4] = t2; r[5] = t4; r[6] = t5; r[7] = t7; r[8] = t9; r[9] = t10;
-    r[10] = sA3; r[11] = sAA;
+  if (lane != 0) return;
+  const uint8_t* m = a.mask + (long long)b * n;
+  const float d = deg[i], d2 = dg[dstride + i], d3 = dg[2 * dstride + i], d4 = dg[3 * dstride + i], d5 = dg[4 * dstride + i],
+              d6 = dg[5 * dstride + i];
+  const float c3 = d3, c4 = d4 - d * (d - 1.f) - Ad, c5 = d5 - 2.f * d3 * d - At + d3;
+  float* x = a.x_out + ((long long)b * n + i) * a.x_ld + a.x_off;
+  const float keep = (m[i] && a.cycle_features) ? 1.f : 0.f;
+  x[0] = clamp05t(c3 * 0.5f) * keep;
+  x[1] = clamp05t(c4 * 0.5f) * keep;
+  x[2] = clamp05t(c5 * 0.5f) * keep;
+  double* r = a.rowpart + ((long long)b * np + i) * 12;
+  r[0] = c3; r[1] = c4; r[2] = c5; r[3] = d6; r[4] = (double)d3 * d3; r[5] = (double)d2 * d4; r[6] = d4;
+  r[7] = (double)d2 * d2 * d2; r[8] = (double)d2 * d2; r[9] = d2; r[10] = sA3; r[11] = sAA;
+  if (m[i]) {
+    int di = (int)d;
+    if (di > a.num_degree) di = a.num_degree + 1;
+    atomicAdd(&a.hist[((long long)a.B + b) * 64 + di], 1);
+    const int xc = a.node_labels ? a.node_labels[(long long)b * n + i] : 0;
+    if (xc >= 0 && xc < 64) atomicAdd(&a.hist[((long long)2 * a.B + b) * 64 + xc], 1);
   }
+}
+
+// ---- 4b: one workgroup per graph: the row terms summed in a fixed order, graph-level features and histograms
+__global__ __launch_bounds__(256) void adj_graph_kernel(TiledNodeArgs a) {
+  __shared__ double red[4][12];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = a.n, np = a.np;
+  double q[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) q[k] = 0;
+  for (int i = tid; i < n; i += 256) {
+    const double* r = a.rowpart + ((long long)b * np + i) * 12;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) q[k] += r[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) q[k] = wave_sum_d(q[k]);
+  if (lane == 0)
+    for (int k = 0; k < 12; ++k) red[wave][k] = q[k];
   __syncthreads();
   float* y = a.y_out + (long long)b * a.y_ld + a.y_off;
   const int nv = a.nvalid[b];
   const float nvf = (float)nv;
   if (tid == 0) {
-    double q[12];
-    for (int k = 0; k < 12; ++k) q[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    for (int k = 0; k < 12; ++k) q[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
     const double c6 = q[3] - 3.0 * q[4] + 9.0 * q[11] - 6.0 * q[5] + 6.0 * q[6] - 4.0 * q[0] + 4.0 * q[7] + 3.0 * q[10] -
                       12.0 * q[8] + 4.0 * q[9];
     const float on = a.cycle_features ? 1.f : 0.f;
@@ -262,8 +263,9 @@ __global__ __launch_bounds__(256) void adj_node_kernel(TiledNodeArgs a) {
     y[2] = clamp05t((float)q[2] / 10.f) * on;
     y[3] = clamp05t((float)c6 / 12.f) * on;
   }
-  if (tid < a.num_degree + 2) y[4 + tid] = nv > 0 ? (float)dh[tid] / nvf : 0.f;
-  if (tid >= 64 && tid < 64 + a.Cx) y[4 + a.num_degree + 2 + (tid - 64)] = nv > 0 ? (float)xh[tid - 64] / nvf : 0.f;
+  if (tid < a.num_degree + 2) y[4 + tid] = nv > 0 ? (float)a.hist[((long long)a.B + b) * 64 + tid] / nvf : 0.f;
+  if (tid >= 64 && tid < 64 + a.Cx)
+    y[4 + a.num_degree + 2 + (tid - 64)] = nv > 0 ? (float)a.hist[((long long)2 * a.B + b) * 64 + (tid - 64)] / nvf : 0.f;
   if (tid >= 128 && tid < 128 + a.C) {
     const float tot = nvf * (nvf - 1.f);
     y[4 + a.num_degree + 2 + a.Cx + (tid - 128)] = tot > 0.f ? (float)a.hist[b * 64 + (tid - 128)] / tot : 0.f;
@@ -368,7 +370,7 @@ extern "C" int scgg_adjacency_features_tiled(const int8_t* labels, const int8_t*
     return fail("adjacency_features_tiled: workspace %zu < %zu bytes", workspace_bytes, p.bytes);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long bnp = (long long)B * np;
-  if (hipMemsetAsync(p.hist, 0, (size_t)B * 64 * sizeof(int), st) != hipSuccess) return fail("adjacency_features_tiled: memset");
+  if (hipMemsetAsync(p.hist, 0, (size_t)3 * B * 64 * sizeof(int), st) != hipSuccess) return fail("adjacency_features_tiled: memset");
   hipLaunchKernelGGL(adj_build_kernel, dim3((np + 15) / 16, B), dim3(256), 0, st, labels, node_mask, n, np, p.A, p.reach,
                      p.deg, p.diag, p.hist, p.nvalid);
   const unsigned eb = (unsigned)(((long long)np * np + 255) / 256);
@@ -383,9 +385,10 @@ extern "C" int scgg_adjacency_features_tiled(const int8_t* labels, const int8_t*
     prev = out;
   }
   hipLaunchKernelGGL(adj_gemm_kernel, gg, dim3(256), 0, st, p.Wc, p.Wr, p.S, np, (float*)nullptr, (uint32_t*)nullptr, 0u);
-  TiledNodeArgs na{p.A, p.A2, p.A3, p.diag, p.deg, p.hist, p.nvalid, node_mask, node_labels, x_out, y_out,
+  TiledNodeArgs na{p.A, p.A2, p.A3, p.diag, p.deg, p.hist, p.nvalid, node_mask, node_labels, p.rowpart, x_out, y_out,
                    B, n, np, C, Cx, num_degree, cycle_features, x_ld, x_off, y_ld, y_off};
-  hipLaunchKernelGGL(adj_node_kernel, dim3(B), dim3(256), 0, st, na);
+  hipLaunchKernelGGL(adj_rows_kernel, dim3((n + 3) / 4, B), dim3(256), 0, st, na);
+  hipLaunchKernelGGL(adj_graph_kernel, dim3(B), dim3(256), 0, st, na);
   TiledPairArgs pa{labels, node_mask, p.reach, p.S, p.nvalid, e_out, n, np, C, max_degree, onehot_out ? C : 0, e_ld, e_off,
                    cycle_features, (long long)B * n * n * ((onehot_out ? C : 0) + max_degree + 1)};
   const long long pb = (pa.total + 255) / 256;

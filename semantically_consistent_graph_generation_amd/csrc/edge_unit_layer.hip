@@ -1775,4 +1775,345 @@ int launch_edge_layer(const EdgeLayerArgs& a, int dx, int de, int ffe, hipStream
   return -1;
 }
 
+// =========================================================================================================
+// Stress configuration (BASELINE.json configs[4]): the NodeEdgeBlock alone on a bf16 edge tensor.
+//
+//   E_in / newE are stored as bf16 [B,n,n,de]; Q, K, V, the FiLM vectors and every accumulator are fp32; weights are
+//   rounded to bf16 once at pack time; each product is ONE v_mfma_f32_16x16x32_bf16 (no three-term split).  The tile of a
+//   lane is read from HBM already in MFMA operand form (two 8-byte loads per 32-channel chunk) and newE leaves as 8-byte
+//   stores: 2 de bytes in and 2 de bytes out per pair -- the "E-tensor HBM stream" of the north star: 4 de B per pair
+//   against 6 de dx flop per pair (196 608 flop / 512 B at de = 128, dx = 256: 384 flop/B, above the bf16 ridge of ~310).
+//   Semantics = NodeEdgeBlock.forward (transformer_model.py:165-248) without the y update: newE = e_out(...) * m_i m_j
+//   (the diagonal is NOT removed there), attention partials per (unit, channel) as in the layer kernels.  The input is
+//   used as given (the block of the reference does not symmetrise).  Same units, lanes, phases and LDS-DMA double buffer as
+//   edge_unit_layer_x3_kernel, channel-block phases only.
+// =========================================================================================================
+template <int NXB, int NEB>
+struct BlockGeomBF {
+  static constexpr int DX = 32 * NXB, DE = 32 * NEB, IBE = DE / 16, QE = NEB;
+  static constexpr int B_CB = 4 * QE + IBE;                  // e_mul, e_add (q-major, two row blocks each), e_out slice
+  static constexpr int BIAS_F4 = 64;
+  static constexpr int PH_F4 = BIAS_F4 + B_CB * 64;          // one bf16 block = 64 lanes x 16 B
+  static constexpr size_t lds_bytes(int nw) { return (size_t)2 * PH_F4 * 16 + (size_t)nw * 3 * DX * 4; }
+};
+
+__device__ __forceinline__ unsigned bf16_rn(float x) {       // round to nearest even, as torch's .to(bfloat16)
+  const unsigned u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN stays NaN
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+struct EdgeBlockPackArgs { const float *W_mul, *b_mul, *W_add, *b_add, *W_out; u32x4* img; };
+
+template <int NXB, int NEB>
+__global__ __launch_bounds__(512) void edge_block_pack_bf16_kernel(EdgeBlockPackArgs a) {
+  using G = BlockGeomBF<NXB, NEB>;
+  constexpr int DX = G::DX, DE = G::DE, IBE = G::IBE, QE = G::QE;
+  const int cb = blockIdx.x;
+  u32x4* img = a.img + (size_t)cb * G::PH_F4;
+  for (int idx = threadIdx.x; idx < G::PH_F4; idx += blockDim.x) {
+    u32x4 out = {0u, 0u, 0u, 0u};
+    if (idx >= G::BIAS_F4) {
+      const int bi = idx - G::BIAS_F4, t = bi >> 6, l = bi & 63;
+      const float* W; int row0, col0, K;
+      if (t < 4 * QE) {
+        W = t < 2 * QE ? a.W_mul : a.W_add;
+        const int rem = t % (2 * QE);
+        row0 = 32 * cb + 16 * (rem & 1); col0 = 32 * (rem >> 1); K = DE;
+      } else { W = a.W_out; row0 = 16 * (t - 4 * QE); col0 = 32 * cb; K = DX; }
+      const int o = row0 + (l & 15), g = l >> 4;
+      unsigned hw[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) hw[i] = bf16_rn(W[(size_t)o * K + col0 + (i < 4 ? 4 * g + i : 16 + 4 * g + i - 4)]);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) out[d] = hw[2 * d] | (hw[2 * d + 1] << 16);
+    } else if (idx < 16) {
+      const int fo = idx * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        out[e] = __float_as_uint(fo < 32 ? a.b_mul[32 * cb + fo + e] + 1.0f : a.b_add[32 * cb + fo - 32 + e]);
+    }
+    img[idx] = out;
+  }
+}
+
+struct EdgeBlockArgs {
+  const unsigned short* E_in;   // bf16 [B,n,n,de]
+  unsigned short* E_out;        // bf16 [B,n,n,de]: newE of the valid rows' pairs (0 beyond the valid keys); other rows untouched
+  const uint8_t* mask;
+  const float *Q, *K, *V;       // [B,n,dx] with row stride ldqkv, masked by the caller as the reference does (:181-183)
+  int ldqkv;
+  const float* film;            // [B, 4 dx] = [y_e_add | y_e_mul+1 | y_x_add | y_x_mul+1]
+  const f32x4* phase_img;
+  const float* b_out;           // e_out.bias
+  float* attn_part;             // [B*n*nch, 3, dx]
+  const int* units;
+  const int* unit_count;
+  float inv_sqrt_df;
+  int B, n;
+};
+
+template <int NXB, int NEB, int NW>
+__global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs a) {
+  using G = BlockGeomBF<NXB, NEB>;
+  constexpr int DX = G::DX, DE = G::DE, IBE = G::IBE, QE = G::QE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* wbuf = reinterpret_cast<f32x4*>(smem);
+  float* fl = reinterpret_cast<float*>(wbuf + 2 * G::PH_F4);
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* vecw = fl + wave * (3 * DX);
+  const int n = a.n, nch = (n + 15) >> 4;
+  const int count = *a.unit_count;
+  const int per_iter = NW * gridDim.x;
+  const int iters = (count + per_iter - 1) / per_iter;
+  constexpr float LOG2E = 1.4426950408889634f;
+  typedef const char* cptr;
+  auto ldo = [](cptr base, unsigned off) { return *reinterpret_cast<const f32x4*>(base + off); };
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#define SCGG_BF(v) __builtin_bit_cast(bf16x8, v)
+
+  stage_phase_unit<G::PH_F4, NW>(a.phase_img, wbuf, wave, lane);
+  int cur = 0;
+  for (int it = 0; it < iters; ++it) {
+    const int uidx = (it * (int)gridDim.x + (int)blockIdx.x) * NW + wave;
+    const bool active = uidx < count;
+    const int u = active ? __builtin_amdgcn_readfirstlane(a.units[uidx]) : 0;
+    const int row = u / nch, j0 = (u - row * nch) * 16, b = row / n;
+    const int j = j0 + p;
+    const bool inb = j < n;
+    const int jj = inb ? j : 0;
+    const bool vj = active && inb && a.mask[b * n + jj] != 0;
+    u32x4 eq[QE];
+    f32x4 accO[IBE];
+    if (active) {
+      // row vectors: Q_i / sqrt(df) | y_e_add | y_e_mul + 1 (this wave's LDS), then the E tile in operand form
+      const cptr qrow = reinterpret_cast<cptr>(a.Q + (long long)row * a.ldqkv);
+      const cptr film = reinterpret_cast<cptr>(a.film + (long long)b * (4 * DX));
+      for (int c = lane * 4; c < 3 * DX; c += 256) {
+        f32x4 v = c < DX ? ldo(qrow, 4u * c) * a.inv_sqrt_df : ldo(film, 4u * (c - DX));
+        *reinterpret_cast<f32x4*>(vecw + c) = v;
+      }
+      const unsigned short* e = a.E_in + ((long long)row * n + jj) * DE + 4 * g;
+#pragma unroll
+      for (int q = 0; q < QE; ++q) {
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(e + 32 * q), hi = *reinterpret_cast<const u32x2*>(e + 32 * q + 16);
+        eq[q] = vj ? u32x4{lo[0], lo[1], hi[0], hi[1]} : u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int eb = 0; eb < IBE; ++eb) accO[eb] = ld4(a.b_out + 16 * eb + 4 * g);
+    }
+    const cptr kbase = reinterpret_cast<cptr>(a.K + (long long)b * n * a.ldqkv);
+    const cptr vbase = reinterpret_cast<cptr>(a.V + (long long)b * n * a.ldqkv);
+    const unsigned kvoff = 4u * (jj * a.ldqkv + 4 * g);
+#pragma unroll 1
+    for (int cb = 0; cb < NXB; ++cb) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the phase image (and the unit's loads) has landed
+      __syncthreads();
+      stage_phase_unit<G::PH_F4, NW>(a.phase_img + (size_t)((cb + 1) % NXB) * G::PH_F4, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
+      const float* bias = reinterpret_cast<const float*>(wbuf + cur * G::PH_F4);
+      const u32x4* W = reinterpret_cast<const u32x4*>(wbuf + cur * G::PH_F4 + G::BIAS_F4);
+      if (active) {
+        f32x4 k[2], vn[2], a1[2], a2[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          k[blk] = ldo(kbase, kvoff + 4u * (32 * cb + 16 * blk));
+          vn[blk] = ldo(vbase, kvoff + 4u * (32 * cb + 16 * blk));
+          a1[blk] = ld4(bias + 16 * blk + 4 * g);
+          a2[blk] = ld4(bias + 32 + 16 * blk + 4 * g);
+        }
+#pragma unroll
+        for (int t = 0; t < 4 * QE; ++t) {                       // e_mul then e_add: blocks (q, ob), q-major
+          const int rem = t % (2 * QE), q = rem >> 1, ob = rem & 1;
+          const u32x4 w = W[t * 64 + lane];
+          if (t < 2 * QE) a1[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(w), SCGG_BF(eq[q]), a1[ob], 0, 0, 0);
+          else a2[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(w), SCGG_BF(eq[q]), a2[ob], 0, 0, 0);
+        }
+        f32x4 y[2], v[2], z[2];
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          const int co = 32 * cb + 16 * blk + 4 * g;
+          const f32x4 q = ld4(vecw + co), yea = ld4(vecw + DX + co), yem = ld4(vecw + 2 * DX + co);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float kk = vj ? k[blk][r] : 0.f;
+            const float yy = (q[r] * kk) * a1[blk][r] + a2[blk][r];
+            z[blk][r] = yea[r] + yem[r] * yy;
+            y[blk][r] = vj ? yy : -INFINITY;
+            v[blk][r] = vj ? vn[blk][r] : 0.f;
+            mloc = fmaxf(mloc, y[blk][r]);
+          }
+        }
+        {
+          u32x4 zb;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const float x0 = d < 2 ? z[0][2 * d] : z[1][2 * d - 4], x1 = d < 2 ? z[0][2 * d + 1] : z[1][2 * d - 3];
+            zb[d] = bf16_rn(x0) | (bf16_rn(x1) << 16);
+          }
+#pragma unroll
+          for (int eb = 0; eb < IBE; ++eb) {
+            const u32x4 w = W[(4 * QE + eb) * 64 + lane];
+            accO[eb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(w), SCGG_BF(zb), accO[eb], 0, 0, 0);
+          }
+        }
+        const float M = row_max16_fused(mloc);
+        const float nM = M == -INFINITY ? 0.f : -M * LOG2E;
+        f32x4 cm[2], cs[2], ca[2];
+        bool under = false;
+        {
+          float red[16];
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pe = __builtin_amdgcn_exp2f(fmaf(y[blk][r], LOG2E, nM));
+              red[4 * blk + r] = pe;
+              red[8 + 4 * blk + r] = pe * v[blk][r];
+            }
+          row_sum16_many<16>(red);
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              cs[blk][r] = red[4 * blk + r];
+              ca[blk][r] = red[8 + 4 * blk + r];
+              cm[blk][r] = M;
+              under |= cs[blk][r] == 0.f;
+            }
+        }
+        if (__any(under && M > -INFINITY)) {
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float yy = y[blk][r];
+              const float mx = row_max16(yy);
+              const float ex = yy == -INFINITY ? 0.f : __expf(yy - mx);
+              cm[blk][r] = mx;
+              cs[blk][r] = row_sum16(ex);
+              ca[blk][r] = row_sum16(ex * v[blk][r]);
+            }
+        }
+        if (p == 0) {
+          float* dst = a.attn_part + (long long)u * (3 * DX) + 32 * cb + 4 * g;
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk) {
+            *reinterpret_cast<f32x4*>(dst + 16 * blk) = cm[blk];
+            *reinterpret_cast<f32x4*>(dst + DX + 16 * blk) = cs[blk];
+            *reinterpret_cast<f32x4*>(dst + 2 * DX + 16 * blk) = ca[blk];
+          }
+        }
+      }
+      cur ^= 1;
+    }
+    if (active && inb) {
+      unsigned short* dst = a.E_out + ((long long)row * n + jj) * DE + 4 * g;
+#pragma unroll
+      for (int eb = 0; eb < IBE; ++eb) {
+        u32x2 o = {0u, 0u};
+        if (vj) o = u32x2{bf16_rn(accO[eb][0]) | (bf16_rn(accO[eb][1]) << 16), bf16_rn(accO[eb][2]) | (bf16_rn(accO[eb][3]) << 16)};
+        *reinterpret_cast<u32x2*>(dst + 16 * eb) = o;
+      }
+    }
+  }
+#undef SCGG_BF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the wave ends
+}
+
+// newX_pre[row] = y_x_add + (y_x_mul + 1) * softmax-weighted V merged over the row's units, up to 64 key chunks (n <= 1024)
+__global__ __launch_bounds__(256) void attn_merge64_kernel(const float* attn_part, const uint8_t* mask, const float* film_all,
+                                                           float* newX_pre, const int* rows, const int* row_count, int n, int DX) {
+  __shared__ unsigned long long cv;
+  const int ridx = blockIdx.x;
+  if (ridx >= *row_count) return;
+  const int row = rows[ridx], nch = (n + 15) >> 4, b = row / n;
+  if (threadIdx.x == 0) {
+    unsigned long long bits = 0;
+    for (int jc = 0; jc < nch; ++jc) {
+      bool any = false;
+      for (int j = jc * 16; j < min(n, jc * 16 + 16); ++j) any |= mask[b * n + j] != 0;
+      bits |= any ? (1ull << jc) : 0ull;
+    }
+    cv = bits;
+  }
+  __syncthreads();
+  const unsigned long long bits = cv;
+  const float* film = film_all + (long long)b * (4 * DX);
+  for (int c = threadIdx.x; c < DX; c += blockDim.x) {
+    float M = -INFINITY, S = 0.f, A = 0.f;
+    for (int jc = 0; jc < nch; ++jc) {
+      if (!((bits >> jc) & 1ull)) continue;
+      const float* pt = attn_part + ((long long)row * nch + jc) * (3 * DX) + c;
+      const float m = pt[0], s = pt[DX], ac = pt[2 * DX];
+      const float mn = fmaxf(M, m);
+      const float fo = M == -INFINITY ? 0.f : __expf(M - mn), fn = m == -INFINITY ? 0.f : __expf(m - mn);
+      S = S * fo + s * fn; A = A * fo + ac * fn; M = mn;
+    }
+    newX_pre[(long long)row * DX + c] = film[2 * DX + c] + film[3 * DX + c] * (A / S);
+  }
+}
+
 }  // namespace scgg
+
+using namespace scgg;
+
+extern "C" size_t scgg_edge_block_bf16_image_bytes(int32_t dx, int32_t de) {
+  if (dx == 256 && de == 128) return (size_t)8 * BlockGeomBF<8, 4>::PH_F4 * 16;
+  if (dx == 256 && de == 64) return (size_t)8 * BlockGeomBF<8, 2>::PH_F4 * 16;
+  return 0;
+}
+
+extern "C" int scgg_edge_block_bf16_pack(const float* W_mul, const float* b_mul, const float* W_add, const float* b_add,
+                                         const float* W_out, int32_t dx, int32_t de, void* image, void* stream) {
+  if (!W_mul || !b_mul || !W_add || !b_add || !W_out || !image) return fail("edge_block_bf16_pack: null argument");
+  EdgeBlockPackArgs a{W_mul, b_mul, W_add, b_add, W_out, static_cast<u32x4*>(image)};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dx == 256 && de == 128) hipLaunchKernelGGL((edge_block_pack_bf16_kernel<8, 4>), dim3(8), dim3(512), 0, st, a);
+  else if (dx == 256 && de == 64) hipLaunchKernelGGL((edge_block_pack_bf16_kernel<8, 2>), dim3(8), dim3(512), 0, st, a);
+  else return fail("edge_block_bf16_pack: unsupported dims dx=%d de=%d (built: 256/128, 256/64)", dx, de);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail("edge_block_bf16_pack: %s", hipGetErrorString(e));
+}
+
+template <int NXB, int NEB>
+static int launch_edge_block_bf16(const EdgeBlockArgs& a, hipStream_t st) {
+  constexpr int NW = 12;
+  const int n_cu = device_cu_count();
+  if (n_cu <= 0) return fail("edge_block_bf16: device query failed");
+  static LdsAttrOnce attr;
+  auto kern = edge_block_bf16_kernel<NXB, NEB, NW>;
+  const size_t lds = BlockGeomBF<NXB, NEB>::lds_bytes(NW);
+  if (set_max_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds)) return fail("edge_block_bf16: LDS attribute");
+  hipLaunchKernelGGL(kern, dim3(n_cu), dim3(NW * 64), lds, st, a);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail("edge_block_bf16: %s", hipGetErrorString(e));
+}
+
+extern "C" int scgg_edge_block_bf16(const uint16_t* E_in, uint16_t* newE, const uint8_t* node_mask, const float* Q,
+                                    const float* K, const float* V, int32_t ldqkv, const float* film, const void* image,
+                                    const float* b_out, float* attn_part, const int32_t* units, const int32_t* unit_count,
+                                    int32_t B, int32_t n, int32_t dx, int32_t de, int32_t n_head, void* stream) {
+  if (!E_in || !newE || !node_mask || !Q || !K || !V || !film || !image || !b_out || !attn_part || !units || !unit_count)
+    return fail("edge_block_bf16: null argument");
+  if (B <= 0 || n <= 0 || n > 1024 || n_head <= 0 || dx % n_head) return fail("edge_block_bf16: bad shape");
+  if (ldqkv % 4 != 0) return fail("edge_block_bf16: ldqkv must be a multiple of 4");
+  EdgeBlockArgs a{E_in, newE, node_mask, Q, K, V, ldqkv, film, static_cast<const f32x4*>(image), b_out, attn_part, units,
+                  unit_count, 1.0f / sqrtf((float)(dx / n_head)), B, n};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dx == 256 && de == 128) return launch_edge_block_bf16<8, 4>(a, st);
+  if (dx == 256 && de == 64) return launch_edge_block_bf16<8, 2>(a, st);
+  return fail("edge_block_bf16: unsupported dims dx=%d de=%d (built: 256/128, 256/64)", dx, de);
+}
+
+extern "C" int scgg_attn_merge(const float* attn_part, const uint8_t* node_mask, const float* film, float* newX_pre,
+                               const int32_t* rows, const int32_t* row_count, int32_t max_rows, int32_t n, int32_t dx,
+                               void* stream) {
+  if (!attn_part || !node_mask || !film || !newX_pre || !rows || !row_count) return fail("attn_merge: null argument");
+  if (n <= 0 || n > 1024 || max_rows <= 0) return fail("attn_merge: bad shape");
+  hipLaunchKernelGGL(attn_merge64_kernel, dim3(max_rows), dim3(256), 0, static_cast<hipStream_t>(stream), attn_part, node_mask,
+                     film, newX_pre, rows, row_count, n, dx);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail("attn_merge: %s", hipGetErrorString(e));
+}

@@ -18,11 +18,40 @@
 
 namespace scgg {
 
-constexpr int YG = 1;          // graphs per workgroup
-constexpr int YT = 256;        // threads per workgroup
+#ifndef SCGG_YG
+#define SCGG_YG 1
+#endif
+constexpr int YG = SCGG_YG;    // graphs per workgroup
+#ifndef SCGG_YT
+#define SCGG_YT 256
+#endif
+constexpr int YT = SCGG_YT;        // threads per workgroup
 constexpr int YW = 256;        // max width of the y vectors (dy); the FFN hidden width dim_ffy has its own buffer
 
 typedef float yf4 __attribute__((ext_vector_type(4)));
+
+
+// acc[g] += sum_{k0 <= k < k1} Wt[k][o4] * in[g][k], the weight float4s requested YD at a time (the loop is a chain of L2
+// round trips otherwise: ~130 ns per iteration measured, i.e. no overlap at all with the compiler's own unrolling)
+constexpr int YD = 16;
+__device__ __forceinline__ void y_dot(yf4 (&acc)[YG], const yf4* __restrict__ w4, int N4, int o4, const float* in, int ldin,
+                                      int k0, int k1) {
+  int k = k0;
+  for (; k + YD <= k1; k += YD) {
+    yf4 w[YD];
+#pragma unroll
+    for (int u = 0; u < YD; ++u) w[u] = w4[(size_t)(k + u) * N4 + o4];
+#pragma unroll
+    for (int u = 0; u < YD; ++u)
+#pragma unroll
+      for (int g = 0; g < YG; ++g) acc[g] += w[u] * in[g * ldin + k + u];
+  }
+  for (; k < k1; ++k) {
+    const yf4 w = w4[(size_t)k * N4 + o4];
+#pragma unroll
+    for (int g = 0; g < YG; ++g) acc[g] += w * in[g * ldin + k];
+  }
+}
 
 // out[g][o] = act(bias[o] + sum_k Wt[k][o] in[g][k]) for o < N, g < YG.  in / out: LDS [YG][ld]; red: LDS scratch of
 // YT * YG float4.  Contains barriers: call from uniform control flow.  On return `out` is complete and synchronised.
@@ -36,12 +65,7 @@ __device__ __forceinline__ void y_dense(const float* __restrict__ Wt, const floa
       const yf4 bv = *reinterpret_cast<const yf4*>(bias + 4 * o4);
 #pragma unroll
       for (int g = 0; g < YG; ++g) acc[g] = bv;
-#pragma unroll 4
-      for (int k = 0; k < K; ++k) {
-        const yf4 w = w4[(size_t)k * N4 + o4];
-#pragma unroll
-        for (int g = 0; g < YG; ++g) acc[g] += w * in[g * ldin + k];
-      }
+      y_dot(acc, w4, N4, o4, in, ldin, 0, K);
 #pragma unroll
       for (int g = 0; g < YG; ++g) {
         yf4 v = acc[g];
@@ -56,12 +80,7 @@ __device__ __forceinline__ void y_dense(const float* __restrict__ Wt, const floa
     yf4 acc[YG];
 #pragma unroll
     for (int g = 0; g < YG; ++g) acc[g] = yf4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int k = k0; k < k1; ++k) {
-      const yf4 w = w4[(size_t)k * N4 + o4];
-#pragma unroll
-      for (int g = 0; g < YG; ++g) acc[g] += w * in[g * ldin + k];
-    }
+    y_dot(acc, w4, N4, o4, in, ldin, k0, k1);
 #pragma unroll
     for (int g = 0; g < YG; ++g) red[g * YT + tid] = acc[g];
     __syncthreads();
@@ -170,12 +189,7 @@ __global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
       if (quarter == 1 || quarter == 3) bv += 1.0f;
 #pragma unroll
       for (int g = 0; g < YG; ++g) acc[g] = bv;
-#pragma unroll 4
-      for (int k = 0; k < dy; ++k) {
-        const yf4 w = w4[(size_t)k * N4 + o4];
-#pragma unroll
-        for (int g = 0; g < YG; ++g) acc[g] += w * yv[g * ldy + k];
-      }
+      y_dot(acc, w4, N4, o4, yv, ldy, 0, dy);
 #pragma unroll
       for (int g = 0; g < YG; ++g)
         if (b0 + g < a.B) *reinterpret_cast<yf4*>(a.film + (size_t)(b0 + g) * 4 * a.dx + 4 * o4) = acc[g];
@@ -188,7 +202,7 @@ static size_t y_layer_lds(int dy, int ffy, int kcat) {
 }
 
 bool y_layer_supported(int dy, int ffy, int kcat) {
-  return dy % 4 == 0 && ffy % 4 == 0 && kcat % 4 == 0 && dy <= YW && y_layer_lds(dy, ffy, kcat) <= 64 * 1024;
+  return dy % 4 == 0 && ffy % 4 == 0 && kcat % 4 == 0 && dy <= YW && y_layer_lds(dy, ffy, kcat) <= 96 * 1024;
 }
 
 int launch_y_layer(const YLayerArgs& a, hipStream_t st) {

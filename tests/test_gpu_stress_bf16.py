@@ -1,0 +1,81 @@
+"""GPU parity of the bf16 NodeEdgeBlock (BASELINE configs[4]) against the fp32 oracle block.
+
+Stated bound (north_star: "a stated looser bound for bf16"): with E, the e_mul / e_add / e_out weights and the FiLM'ed Y
+rounded to bf16 (8 mantissa bits, relative 2^-9 each) and fp32 accumulation, newE agrees with the fp32 oracle on the SAME
+bf16-rounded E to 2e-2 of the tensor's scale; the output itself is stored as bf16 (another 2^-9).  newX (softmax-weighted V
+through x_out, all fp32 after the bf16 Y) to 2e-2 as well."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import denoiser as D
+from oracle import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+
+def make_block(dx, de, dy, n_head, seed):
+    from semantically_consistent_graph_generation_amd.transformer_model import NodeEdgeBlock
+    blk = NodeEdgeBlock(dx, de, dy, n_head)
+    sd = fx.make_state_dict({k: tuple(v.shape) for k, v in blk.state_dict().items()}, seed)
+    blk.load_state_dict(sd)
+    return blk, sd
+
+
+@pytest.mark.parametrize("de,n_nodes", [(128, [40, 23, 1, 36]), (64, [33, 48]), (128, [130])])
+def test_bf16_block_matches_fp32_oracle(de, n_nodes):
+    from semantically_consistent_graph_generation_amd.stress import NodeEdgeBlockBF16
+    dx, dy, n_head = 256, 64, 8
+    blk, sd = make_block(dx, de, dy, n_head, 3)
+    m = fx.ragged_mask(n_nodes)
+    B, n = m.shape
+    g = torch.Generator().manual_seed(4)
+    X = torch.randn(B, n, dx, generator=g) * m[..., None]
+    E = torch.randn(B, n, n, de, generator=g)
+    E = 0.5 * (E + E.transpose(1, 2)) * (m[:, :, None] & m[:, None, :])[..., None] * (~torch.eye(n, dtype=torch.bool))[None, :, :, None]
+    Eb = E.to(torch.bfloat16)
+    y = torch.randn(B, dy, generator=g)
+    newX, newE, _ = D.node_edge_block({k: v for k, v in sd.items()}, "", n_head, X, Eb.float(), y, m, predicts_y=False)
+    op = NodeEdgeBlockBF16(blk.cuda())
+    gX, gE = op(X.cuda(), Eb.cuda(), y.cuda(), m.cuda())
+    torch.cuda.synchronize()
+    gE, gX = gE.float().cpu(), gX.cpu()
+    assert bool(torch.isfinite(gE).all()) and bool(torch.isfinite(gX).all())
+    sE, sX = float(newE.abs().max()), float(newX.abs().max())
+    assert float((gE - newE).abs().max()) / sE < 2e-2
+    assert float((gX - newX).abs().max()) / sX < 2e-2
+    # typical error is far below the bound
+    assert float((gE - newE).abs().mean()) / sE < 2e-3
+    # masking as the reference block: m_i m_j (diagonal kept), nothing on padded rows / keys
+    pm = (m[:, :, None] & m[:, None, :])
+    assert float(gE[~pm].abs().max() if (~pm).any() else 0.0) == 0.0
+    assert float(gX[~m].abs().max() if (~m).any() else 0.0) == 0.0
+
+
+def test_bf16_block_at_1024_nodes_properties():
+    """The stress size itself (B = 1, n = 1024, de = 128): finite, masked, permutation-equivariant under a relabelling of the
+    nodes (a size-independent property of the block), and equal to the oracle on a strided sample of rows."""
+    from semantically_consistent_graph_generation_amd.stress import NodeEdgeBlockBF16
+    dx, de, dy, n_head, n = 256, 128, 64, 8, 1024
+    blk, sd = make_block(dx, de, dy, n_head, 5)
+    g = torch.Generator().manual_seed(6)
+    m = torch.ones(1, n, dtype=torch.bool)
+    X = torch.randn(1, n, dx, generator=g)
+    E = torch.randn(1, n, n, de, generator=g)
+    E = (0.5 * (E + E.transpose(1, 2))) * (~torch.eye(n, dtype=torch.bool))[None, :, :, None]
+    Eb = E.to(torch.bfloat16)
+    y = torch.randn(1, dy, generator=g)
+    op = NodeEdgeBlockBF16(blk.cuda())
+    gX, gE = op(X.cuda(), Eb.cuda(), y.cuda(), m.cuda())
+    perm = torch.randperm(n, generator=g)
+    pX, pE = op(X[:, perm].cuda(), Eb[:, perm][:, :, perm].contiguous().cuda(), y.cuda(), m.cuda())
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(gE.float()).all())
+    # newE is a per-pair function of (Q_i, K_j, E_ij, y): exactly equivariant; newX sums over keys in another order
+    assert torch.equal(pE.cpu(), gE.cpu()[:, perm][:, :, perm])
+    np.testing.assert_allclose(pX.cpu().numpy(), gX.cpu()[:, perm].numpy(), rtol=2e-4, atol=2e-4)
+    rows = torch.arange(0, n, 97)
+    newX, newE, _ = D.node_edge_block(sd, "", n_head, X, Eb.float(), y, m, predicts_y=False)
+    sE = float(newE.abs().max())
+    assert float((gE.float().cpu()[:, rows] - newE[:, rows]).abs().max()) / sE < 2e-2
+    assert float((gX.cpu() - newX).abs().max()) / float(newX.abs().max()) < 2e-2
