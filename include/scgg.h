@@ -105,6 +105,49 @@ int scgg_denoiser_profile(scgg_denoiser* h, int32_t every_n_forwards, int32_t ma
 int scgg_denoiser_profile_read(scgg_denoiser* h, int32_t* n_launches, double* total_ms);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Position-aware denoiser: Graph3DTransformer (src/ConStruct/models/pos_transformer_model.py:338-493; block :33-209,
+ * layer :212-303; EtoX src/ConStruct/models/layers.py:55-71) and, with `equivariant` set, EquivariantGraph3DTransformer
+ * (src/ConStruct/models/equivariant_pos_transformer_model.py:334-486: same block, node features from mlp_in_X and the
+ * node head on the hidden X).  Constructed at diffusion_model_discrete_3d.py:111-132 and called at :201; it is the model
+ * the shipped driver instantiates.  Same life cycle as scgg_denoiser: create, set_param per state_dict name, finalize.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct scgg_denoiser3d scgg_denoiser3d;
+
+typedef struct scgg_denoiser3d_config {
+  int32_t n_layers;
+  int32_t in_X, in_E, in_y;            /* input_dims.X + input_dims.charges, .E, .y                                */
+  int32_t out_X, out_E;                /* output_dims.X + output_dims.charges, .E  (output_dims.y must be 0: neither
+                                          class has an mlp_out_y, pos_transformer_model.py:479-481)                */
+  int32_t hid_X, hid_E, hid_y;         /* hidden_mlp_dims                                                          */
+  int32_t dx, de, dy, n_head;          /* hidden_dims                                                              */
+  int32_t dim_ffX, dim_ffE, dim_ffy;   /* dim_ffy: the layer's real lin_y1 width (2048: :223-225 default, not passed) */
+  int32_t equivariant;                 /* 0: Graph3DTransformer, 1: EquivariantGraph3DTransformer                  */
+} scgg_denoiser3d_config;
+
+scgg_denoiser3d* scgg_denoiser3d_create(const scgg_denoiser3d_config* cfg);   /* NULL on unsupported dims */
+void scgg_denoiser3d_destroy(scgg_denoiser3d* h);
+int scgg_denoiser3d_set_param(scgg_denoiser3d* h, const char* name, const float* data, int64_t numel);
+int scgg_denoiser3d_finalize(scgg_denoiser3d* h, void* stream);   /* also re-packs after the weights changed */
+size_t scgg_denoiser3d_workspace_bytes(const scgg_denoiser3d* h, int32_t B, int32_t n);
+
+/* replaces Graph3DTransformer.forward (:433-493) / EquivariantGraph3DTransformer.forward (:428-486), eval mode.
+ *   X[B,n,in_X] E[B,n,n,in_E] y[B,in_y] pos[B,n,3] (raw: masking and the re-centring of PlaceHolder.mask,
+ *   utils.py:160-164, once on entry and once after every layer, happen inside) node_mask[B,n]
+ *   out_X[B,n,out_X] (X and charges, masked; may be NULL when out_X == 0), out_E[B,n,n,out_E] (symmetric, zero
+ *   diagonal, masked), out_radius[B,n,n] (same; NULL = the radius head is not run, as when model_input.radius is None).
+ *   Distances are taken from coordinate differences at every n (the reference's torch.cdist switches to the expanded
+ *   form above 25 points, where the distance of a node to itself is rounding noise). */
+int scgg_denoiser3d_forward(scgg_denoiser3d* h, const float* X, const float* E, const float* y, const float* pos,
+                            const uint8_t* node_mask, int32_t B, int32_t n, float* out_X, float* out_E,
+                            float* out_radius, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Debug / test tap: hidden state after the input MLPs and the first n_run_layers layers, as the reference holds it:
+ * hid_X[B,n,dx], hid_E[B,n,n,de] (symmetrised, masked), hid_y[B,dy].  Any output pointer may be NULL. */
+int scgg_denoiser3d_forward_hidden(scgg_denoiser3d* h, const float* X, const float* E, const float* y, const float* pos,
+                                   const uint8_t* node_mask, int32_t B, int32_t n, int32_t n_run_layers, float* hid_X,
+                                   float* hid_E, float* hid_y, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Reverse step: NoiseModel.sample_zs_from_zt_and_pred (src/ConStruct/diffusion/noise_model.py:342-447) with
  * sample_discrete_features (src/ConStruct/diffusion/diffusion_utils.py:200-285).  Called at
  * diffusion_model_discrete_3d.py:749.

@@ -676,9 +676,85 @@ def gen_graph_transformer_large(R):
          shape_keys=np.array(sorted(shapes)), shape_vals=np.array([",".join(map(str, shapes[k])) for k in sorted(shapes)]))
 
 
+def gen_graph3d(R):
+    """G1/G3: the position-aware denoiser the shipped driver instantiates: one 3D NodeEdgeBlock with and
+    without the y branch, Graph3DTransformer and EquivariantGraph3DTransformer forwards (eval).  Padded nodes carry
+    non-zero positions on purpose (the model has to mask them), and the batches are ragged (the re-centring quirk of
+    PlaceHolder.mask only shows with padding)."""
+    from src.ConStruct.models import pos_transformer_model as P3
+    from src.ConStruct.models import equivariant_pos_transformer_model as EQ
+    torch.manual_seed(41)
+    dx, de, dy, h = 32, 32, 16, 4
+    mask = fx.ragged_mask([7, 4, 1], 7)
+    B, n = mask.shape
+    X = torch.randn(B, n, dx)
+    E = torch.randn(B, n, n, de)
+    E = 0.5 * (E + E.transpose(1, 2))
+    y = torch.randn(B, dy)
+    pos = torch.randn(B, n, 3)
+    ph = R.U.PlaceHolder(X=X, E=E, y=y, node_mask=mask).mask()
+    X, E = ph.X, ph.E
+    for predicts_y in (True, False):
+        blk = P3.NodeEdgeBlock(dx, de, dy, h, predicts_y=predicts_y).eval()
+        sd = fx.make_state_dict({k: v.shape for k, v in blk.state_dict().items()}, seed=42)
+        blk.load_state_dict(sd)
+        with torch.no_grad():
+            nX, nE, ny = blk(X, E, y, pos, mask)
+        save(f"g1_block3d_y{int(predicts_y)}", X=X, E=E, y=y, pos=pos, node_mask=mask, n_head=h, newX=nX, newE=nE,
+             new_y=ny if ny is not None else np.zeros(0), **sd_arrays(sd))
+
+    def case(name, cls, dims, in_dims, out_dims, n_layers, n_nodes, seed, store_weights, onehot_C=None, radius=True,
+             rows=None):
+        torch.manual_seed(seed)
+        mask = fx.ragged_mask(n_nodes)
+        B, n = mask.shape
+        model = cls(n_layers=n_layers, input_dims=fx.dims_ns(*in_dims), hidden_mlp_dims=dims["hidden_mlp_dims"],
+                    hidden_dims=dims["hidden_dims"], output_dims=fx.dims_ns(*out_dims), dropout=0.1).eval()
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        sd = fx.make_state_dict(shapes, seed=seed)
+        model.load_state_dict(sd)
+        X = torch.randn(B, n, in_dims[0] + in_dims[3])
+        E = torch.randn(B, n, n, in_dims[1])
+        E = 0.5 * (E + E.transpose(1, 2))
+        if onehot_C is not None:
+            E[..., :onehot_C] = fx.one_hot_edges(fx.random_labels(mask, onehot_C, 0.15, seed), mask, onehot_C)
+        y = torch.rand(B, in_dims[2])
+        pos = torch.randn(B, n, 3) * 1.7 + 0.4
+        rad = torch.zeros(B, n, n, 1) if radius else None
+        with torch.no_grad():
+            out = model(R.U.PlaceHolder(X=X, E=E, y=y, pos=pos, radius=rad, node_mask=mask))
+        arrays = dict(X=X, E=E, y=y, pos=pos, node_mask=mask, outX=out.X, out_charges=out.charges, out_pos=out.pos,
+                      n_layers=n_layers, seed=seed, in_dims=np.array(in_dims), out_dims=np.array(out_dims),
+                      shape_keys=np.array(sorted(shapes)),
+                      shape_vals=np.array([",".join(map(str, shapes[k])) for k in sorted(shapes)]))
+        if rows is None:
+            arrays.update(outE=out.E, out_radius=out.radius if radius else np.zeros(0))
+        else:
+            arrays.update(rows=rows, outE_rows=out.E[:, rows], out_radius_rows=out.radius[:, rows],
+                          outE_sum=out.E.double().sum(dim=(1, 2)), outE_abs_sum=out.E.double().abs().sum(dim=(1, 2)))
+            del arrays["E"]
+            arrays["labels"] = E[..., :onehot_C].argmax(-1).to(torch.int8)
+        assert out.y is None
+        if store_weights:
+            arrays.update(sd_arrays(sd))
+        save(name, **arrays)
+
+    # (X, E, y, charges) widths
+    case("g3_g3d_tiny", P3.Graph3DTransformer, fx.TINY_DIMS, (3, 9, 4, 2), (2, 4, 0, 1), 2, [9, 5, 2], 43, True)
+    case("g3_g3d_tiny_equivariant", EQ.EquivariantGraph3DTransformer, fx.TINY_DIMS, (3, 9, 4, 2), (2, 4, 0, 1), 3,
+         [6, 10, 3, 1], 44, True, radius=False)
+    # the shipped vessel configuration (discrete_vessels.yaml): no extra features, y = t; CoW (14 edge classes) and ATM (5)
+    case("g3_g3d_vessel_cow", P3.Graph3DTransformer, fx.VESSEL_DIMS, (1, 14, 1, 0), (1, 14, 0, 0), 5, [12, 7, 20], 45, False,
+         onehot_C=14)
+    case("g3_g3d_vessel_n40", P3.Graph3DTransformer, fx.VESSEL_DIMS, (1, 5, 1, 0), (1, 5, 0, 0), 2, [40, 33], 46, False,
+         onehot_C=5)
+    case("g3_g3d_vessel_equivariant", EQ.EquivariantGraph3DTransformer, fx.VESSEL_DIMS, (1, 5, 1, 0), (1, 5, 0, 0), 5, [17, 32], 47,
+         False, onehot_C=5)
+
+
 def main():
     R = import_reference()
-    extra = {"training": gen_training, "extra_large": gen_extra_features_large, "gt_large": gen_graph_transformer_large}
+    extra = {"graph3d": gen_graph3d, "training": gen_training, "extra_large": gen_extra_features_large, "gt_large": gen_graph_transformer_large}
     if len(sys.argv) == 2 and sys.argv[1] in extra:
         return extra[sys.argv[1]](R)
     if sys.argv[1:] == ["projector"]:
@@ -698,6 +774,7 @@ def main():
     gen_training(R)
     gen_extra_features_large(R)
     gen_graph_transformer_large(R)
+    gen_graph3d(R)
 
 
 if __name__ == "__main__":

@@ -19,6 +19,12 @@ class DenoiserConfig(C.Structure):
         "dx", "de", "dy", "n_head", "dim_ffX", "dim_ffE", "dim_ffy")]
 
 
+class Denoiser3DConfig(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in (
+        "n_layers", "in_X", "in_E", "in_y", "out_X", "out_E", "hid_X", "hid_E", "hid_y",
+        "dx", "de", "dy", "n_head", "dim_ffX", "dim_ffE", "dim_ffy", "equivariant")]
+
+
 class Rng(C.Structure):
     _fields_ = [("u0", C.c_void_p), ("uk", C.c_void_p), ("seed", C.c_uint64), ("step", C.c_uint32),
                 ("graph_id_base", C.c_uint32)]
@@ -40,6 +46,13 @@ SIGNATURES = {
     "scgg_denoiser_side_stream": (C.c_void_p, [_vp]),
     "scgg_denoiser_profile": (C.c_int, [_vp, _i32, _i32]),
     "scgg_denoiser_profile_read": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "scgg_denoiser3d_create": (_vp, [C.POINTER(Denoiser3DConfig)]),
+    "scgg_denoiser3d_destroy": (None, [_vp]),
+    "scgg_denoiser3d_set_param": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),
+    "scgg_denoiser3d_finalize": (C.c_int, [_vp, _vp]),
+    "scgg_denoiser3d_workspace_bytes": (_sz, [_vp, _i32, _i32]),
+    "scgg_denoiser3d_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "scgg_denoiser3d_forward_hidden": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "scgg_reverse_step_edges": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                                           C.POINTER(Rng), _vp, _vp, _vp, _vp]),
     "scgg_sample_edges_from_probs": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(Rng), _vp, _vp, _vp]),

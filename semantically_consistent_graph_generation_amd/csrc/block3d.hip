@@ -1,0 +1,635 @@
+// Position-aware NodeEdgeBlock + XEy E path of Graph3DTransformer, gfx950, fp32 on
+// v_mfma_f32_16x16x4_f32, 16-key units in C16 layout (c16.h).
+//
+//   NodeEdgeBlock.forward          src/ConStruct/models/pos_transformer_model.py:106-209
+//   XEyTransformerLayer E path     src/ConStruct/models/pos_transformer_model.py:278-290
+//   EtoX / Etoy pooling            src/ConStruct/models/layers.py:55-71, :24-43
+//   PlaceHolder.mask on pos        src/ConStruct/utils.py:160-164
+//
+// Unlike the 2D block (edge_unit_layer.hip) every Linear of this block is de x de or de x ffE, so the whole layer's edge
+// weights fit LDS at once in fp32 (4 de^2 + 2 de ffE + 2*16 de + 16 dx floats = 148 KB at the shipped vessel dims): a
+// persistent workgroup stages them once and its waves then stream units with no barrier and no weight traffic at all.
+//
+// Per unit (valid query row i, 16 keys j), all in registers:
+//   x      = 0.5 (E_ij + E_ji) off the diagonal, 0 on it                      (sym-load of the producer's tile)
+//   dist1  = relu(w_d |p_i - p_j| + w_c cos(p_i, p_j) + w_1 |p_i| + w_2 |p_j| + b)               :122-132
+//   Y      = in_E(x) . x_e_mul1_j . x_e_mul2_i;  Y = Y + dist_add(dist1) + Y dist_mul(dist1)     :137-147
+//   E1     = Y + y_e_add + Y y_e_mul;  newE = e_out(E1)                                          :150-155
+//   a^T    = K_j . (W_a (.) Q_i) / sqrt(de), times (1 + e_att_mul(E1)) (1 + pos_att_mul(dist1))  :159-171
+//            evaluated TRANSPOSED (keys as MFMA rows): lane (head, key group) holds 4 keys, which is the B operand of
+//            the weighted-V product  wV^T[d][h] = sum_key V[key][d] p[key][h]  without any lane movement
+//   E_out  = LN2(E' + linE2 relu linE1 E'),  E' = LN1(x + newE)                                  :278-288
+// and per unit the partial results the row / graph merges need: softmax (max, sum, sum p V) per head, and per channel
+// (mean, M2, min, max) of Y and of dist1 over the unit's valid keys (exact two-pass inside the unit, Chan merge later).
+#include <stdlib.h>
+
+#include "mfma_chain.h"
+#include "c16.h"
+#include "kernels.h"
+
+namespace scgg {
+
+template <int DEB, int FFB, int DXB>
+struct Geom3D {
+  static constexpr int DE = 16 * DEB, FFE = 16 * FFB, DX = 16 * DXB;
+  static constexpr int SQ = DEB * DEB * 64;                       // float4s of a de x de fragment set
+  static constexpr int W_IN = 0, W_DADD = SQ, W_DMUL = 2 * SQ, W_EOUT = 3 * SQ;
+  static constexpr int W_FF1 = 4 * SQ;                            // (hidden block, input block)
+  static constexpr int W_FF2 = W_FF1 + FFB * DEB * 64;            // (output block, hidden block)
+  static constexpr int W_EATT = W_FF2 + DEB * FFB * 64;           // 16 rows (heads, zero padded) x de
+  static constexpr int W_PATT = W_EATT + DEB * 64;
+  static constexpr int W_A = W_PATT + DEB * 64;                   // 16 rows (heads) x dx
+  static constexpr int VEC = W_A + DXB * 64;
+  enum { B_IN = 0, B_DADD, B_DMUL, B_EOUT, B_FF2, LN1G, LN1B, LN2G, LN2B, WD0, WD1, BD, WN1, WN2, NVEC_DE };
+  static constexpr int V_FF1 = NVEC_DE * DE;
+  static constexpr int V_EATT = V_FF1 + FFE;
+  static constexpr int V_PATT = V_EATT + 16;
+  static constexpr int V_FLOATS = V_PATT + 16;
+  static constexpr int IMG_F4 = VEC + (V_FLOATS + 3) / 4;
+  static_assert(DEB % 2 == 0 && FFB % 4 == 0, "de: multiple of 32, dim_ffE: multiple of 64");
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS image.  Fragment (ob, ib) of W[N][K], lane l: W[16 ob + (l & 15)][16 ib + 4 (l >> 4) + 0..3], zero outside.
+// ---------------------------------------------------------------------------------------------------------
+template <int DEB, int FFB, int DXB>
+__global__ __launch_bounds__(256) void block3d_pack_kernel(Block3DPackArgs a) {
+  using G = Geom3D<DEB, FFB, DXB>;
+  constexpr int DE = G::DE, FFE = G::FFE, DX = G::DX;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < G::IMG_F4; idx += gridDim.x * 256) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (idx < G::VEC) {
+      const float* W;
+      int N, K, KBLK, off;
+      if (idx < G::W_FF1) {
+        const int m = idx / G::SQ;
+        W = m == 0 ? a.W_in : m == 1 ? a.W_dadd : m == 2 ? a.W_dmul : a.W_eout;
+        N = DE; K = DE; KBLK = DEB; off = m * G::SQ;
+      } else if (idx < G::W_FF2) { W = a.W_ff1; N = FFE; K = DE; KBLK = DEB; off = G::W_FF1; }
+      else if (idx < G::W_EATT) { W = a.W_ff2; N = DE; K = FFE; KBLK = FFB; off = G::W_FF2; }
+      else if (idx < G::W_PATT) { W = a.W_eatt; N = a.n_head; K = DE; KBLK = DEB; off = G::W_EATT; }
+      else if (idx < G::W_A) { W = a.W_patt; N = a.n_head; K = DE; KBLK = DEB; off = G::W_PATT; }
+      else { W = a.W_a; N = a.n_head; K = DX; KBLK = DXB; off = G::W_A; }
+      const int t = (idx - off) >> 6, l = idx & 63;
+      const int ob = t / KBLK, ib = t - ob * KBLK;
+      const int row = 16 * ob + (l & 15);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = 16 * ib + 4 * (l >> 4) + e;
+        if (row < N && col < K) v[e] = W[(size_t)row * K + col];
+      }
+    } else {
+      const int f0 = (idx - G::VEC) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int f = f0 + e;
+        float x = 0.f;
+        if (f < G::V_FF1) {
+          const int which = f / DE, c = f - which * DE;
+          switch (which) {
+            case G::B_IN: x = a.b_in[c]; break;
+            case G::B_DADD: x = a.b_dadd[c]; break;
+            case G::B_DMUL: x = a.b_dmul[c]; break;
+            case G::B_EOUT: x = a.b_eout[c]; break;
+            case G::B_FF2: x = a.b_ff2[c]; break;
+            case G::LN1G: x = a.ln1g[c]; break;
+            case G::LN1B: x = a.ln1b[c]; break;
+            case G::LN2G: x = a.ln2g[c]; break;
+            case G::LN2B: x = a.ln2b[c]; break;
+            case G::WD0: x = a.W_dist[2 * c]; break;          // lin_dist1.weight [de, 2]: distance column
+            case G::WD1: x = a.W_dist[2 * c + 1]; break;      //                           cosine column
+            case G::BD: x = (a.b_dist[c] + a.b_n1[c]) + a.b_n2[c]; break;
+            case G::WN1: x = a.W_n1[c]; break;                // lin_norm_pos1.weight [de, 1] (follows the query row i)
+            case G::WN2: x = a.W_n2[c]; break;                // lin_norm_pos2 (follows the key j)
+          }
+        } else if (f < G::V_EATT) x = a.b_ff1[f - G::V_FF1];
+        else if (f < G::V_PATT) x = (f - G::V_EATT) < a.n_head ? a.b_eatt[f - G::V_EATT] : 0.f;
+        else if (f < G::V_FLOATS) x = (f - G::V_PATT) < a.n_head ? a.b_patt[f - G::V_PATT] : 0.f;
+        v[e] = x;
+      }
+    }
+    a.img[idx] = v;
+  }
+}
+
+__device__ __forceinline__ float row_min16(float v) { return -row_max16(-v); }
+__device__ __forceinline__ float groups_max(float v) {          // across the four lane rows (same lane & 15)
+  v = swap_rows16_max(v);
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// two accumulators, two fragments, two inputs
+__device__ __forceinline__ void mfma4x2d(f32x4& acc0, f32x4& acc1, const f32x4& f0, const f32x4& f1, const f32x4& x0,
+                                         const f32x4& x1) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f0[r], x0[r], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f1[r], x1[r], acc1, 0, 0, 0);
+  }
+}
+
+template <int DEB, int FFB, int DXB, int NW>
+__global__ __launch_bounds__(NW * 64) void block3d_edge_kernel(Block3DArgs a) {
+  using G = Geom3D<DEB, FFB, DXB>;
+  constexpr int DE = G::DE, DX = G::DX;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* img = reinterpret_cast<f32x4*>(smem);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  for (int idx = tid; idx < G::IMG_F4; idx += NW * 64) img[idx] = a.img[idx];
+  __syncthreads();
+  const float* vec = reinterpret_cast<const float*>(img + G::VEC);
+  const int n = a.n, nch = (n + 15) >> 4;
+  const int count = *a.unit_count;
+  const int AP = a.n_head * DX + 32;
+
+  for (int uidx = blockIdx.x * NW + wave; uidx < count; uidx += gridDim.x * NW) {
+    const int u = a.units[uidx];
+    const int row = u / nch, jc = u - row * nch;
+    const int b = row / n, i = row - b * n;
+    const int j = jc * 16 + p;
+    const bool inb = j < n;
+    const int jj = inb ? j : 0;
+    const long long rj = (long long)b * n + jj;
+    const bool vj = inb && a.mask[rj] != 0;                            // the query row is valid by construction
+    const bool offd = vj && j != i;
+    const unsigned keymask = (unsigned)(__ballot(vj) & 0xffffull);     // lanes 0..15 carry keys 0..15 of the unit
+    const long long pij = ((long long)row * n + jj) * DE, pji = (rj * n + i) * DE;
+    const float* nl_i = a.nodelin + (long long)row * a.ldn;
+    const float* nl_j = a.nodelin + rj * a.ldn;
+
+    f32x4 x[DEB];
+#pragma unroll
+    for (int ib = 0; ib < DEB; ++ib) {
+      x[ib] = splat4(0.f);
+      if (offd) x[ib] = 0.5f * (ld4(a.E_in + pij + 16 * ib + 4 * g) + ld4(a.E_in + pji + 16 * ib + 4 * g));
+    }
+    // ---- distance features
+    f32x4 d1[DEB];
+    {
+      const f32x4 pi = ld4(a.pos4 + (long long)row * 4), pj = ld4(a.pos4 + rj * 4);
+      const float ex = pi[0] - pj[0], ey = pi[1] - pj[1], ez = pi[2] - pj[2];
+      const float dist = sqrtf(ex * ex + ey * ey + ez * ez);
+      const float di = pi[3] + 1e-7f, dj = pj[3] + 1e-7f;
+      const float cs = (pi[0] / di) * (pj[0] / dj) + (pi[1] / di) * (pj[1] / dj) + (pi[2] / di) * (pj[2] / dj);
+#pragma unroll
+      for (int ib = 0; ib < DEB; ++ib) {
+        const int c = 16 * ib + 4 * g;
+        const f32x4 w0 = ld4(vec + G::WD0 * DE + c), w1 = ld4(vec + G::WD1 * DE + c), bd = ld4(vec + G::BD * DE + c);
+        const f32x4 n1 = ld4(vec + G::WN1 * DE + c), n2 = ld4(vec + G::WN2 * DE + c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = dist * w0[r] + cs * w1[r] + bd[r] + n1[r] * pi[3] + n2[r] * pj[3];
+          d1[ib][r] = vj ? fmaxf(t, 0.f) : 0.f;
+        }
+      }
+    }
+    // ---- Y = in_E(x) . x_e_mul1_j . x_e_mul2_i, then the distance FiLM
+    f32x4 Y[DEB];
+#pragma unroll
+    for (int ob = 0; ob < DEB; ob += 2) {
+      f32x4 a0 = ld4(vec + G::B_IN * DE + 16 * ob + 4 * g), a1 = ld4(vec + G::B_IN * DE + 16 * (ob + 1) + 4 * g);
+#pragma unroll
+      for (int ib = 0; ib < DEB; ++ib)
+        mfma4x2(a0, a1, img[G::W_IN + (ob * DEB + ib) * 64 + lane], img[G::W_IN + ((ob + 1) * DEB + ib) * 64 + lane], x[ib]);
+      const f32x4 m10 = ld4(nl_j + 3 * DX + 16 * ob + 4 * g), m11 = ld4(nl_j + 3 * DX + 16 * (ob + 1) + 4 * g);
+      const f32x4 m20 = ld4(nl_i + 3 * DX + DE + 16 * ob + 4 * g), m21 = ld4(nl_i + 3 * DX + DE + 16 * (ob + 1) + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Y[ob][r] = vj ? a0[r] * m10[r] * m20[r] : 0.f;
+        Y[ob + 1][r] = vj ? a1[r] * m11[r] * m21[r] : 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int ob = 0; ob < DEB; ++ob) {
+      f32x4 da = ld4(vec + G::B_DADD * DE + 16 * ob + 4 * g), dm = ld4(vec + G::B_DMUL * DE + 16 * ob + 4 * g);
+#pragma unroll
+      for (int ib = 0; ib < DEB; ++ib)
+        mfma4x2(da, dm, img[G::W_DADD + (ob * DEB + ib) * 64 + lane], img[G::W_DMUL + (ob * DEB + ib) * 64 + lane], d1[ib]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Y[ob][r] = vj ? (Y[ob][r] + da[r]) + Y[ob][r] * dm[r] : 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- pooled statistics of Y and dist1 over this unit's valid keys
+    if (a.need_attn) {
+      const float inv = 1.0f / (float)__popc(keymask);
+      float* sp = a.stat_part + (long long)u * (8 * DE);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ob = 0; ob < DEB; ++ob) {
+          const f32x4 val = t == 0 ? Y[ob] : d1[ob];
+          float s[4], q[4];
+          f32x4 mean, m2, mn, mx;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[r] = vj ? val[r] : 0.f;
+          row_sum16_many<4>(s);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            mean[r] = s[r] * inv;
+            const float dv = vj ? val[r] - mean[r] : 0.f;
+            q[r] = dv * dv;
+          }
+          row_sum16_many<4>(q);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            m2[r] = q[r];
+            mn[r] = row_min16(vj ? val[r] : INFINITY);
+            mx[r] = row_max16(vj ? val[r] : -INFINITY);
+          }
+          if (p == 0) {
+            float* d = sp + t * 4 * DE + 16 * ob + 4 * g;
+            *reinterpret_cast<f32x4*>(d) = mean;
+            *reinterpret_cast<f32x4*>(d + DE) = m2;
+            *reinterpret_cast<f32x4*>(d + 2 * DE) = mn;
+            *reinterpret_cast<f32x4*>(d + 3 * DE) = mx;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- y FiLM (E1 replaces Y), newE = e_out(E1)
+    {
+      const float* fl = a.film + (long long)b * a.ldf;
+#pragma unroll
+      for (int ob = 0; ob < DEB; ++ob) {
+        const f32x4 ya = ld4(fl + 16 * ob + 4 * g), ym = ld4(fl + DE + 16 * ob + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Y[ob][r] = vj ? (Y[ob][r] + ya[r]) + Y[ob][r] * ym[r] : 0.f;
+      }
+    }
+    f32x4 nE[DEB];
+#pragma unroll
+    for (int ob = 0; ob < DEB; ob += 2) {
+      f32x4 a0 = ld4(vec + G::B_EOUT * DE + 16 * ob + 4 * g), a1 = ld4(vec + G::B_EOUT * DE + 16 * (ob + 1) + 4 * g);
+#pragma unroll
+      for (int ib = 0; ib < DEB; ++ib)
+        mfma4x2(a0, a1, img[G::W_EOUT + (ob * DEB + ib) * 64 + lane], img[G::W_EOUT + ((ob + 1) * DEB + ib) * 64 + lane], Y[ib]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        nE[ob][r] = vj ? a0[r] : 0.f;
+        nE[ob + 1][r] = vj ? a1[r] : 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- attention, transposed: lane (head p, key group g) register r <-> key 4 g + r
+    if (a.need_attn) {
+      f32x4 la0 = splat4(0.f), la1 = splat4(0.f);
+#pragma unroll
+      for (int db = 0; db < DXB; db += 2) {
+        f32x4 k0 = splat4(0.f), k1 = splat4(0.f);
+        if (vj) {
+          k0 = ld4(nl_j + DX + 16 * db + 4 * g);
+          k1 = ld4(nl_j + DX + 16 * (db + 1) + 4 * g);
+        }
+        const f32x4 q0 = ld4(nl_i + 16 * db + 4 * g) * a.inv_sqrt_de, q1 = ld4(nl_i + 16 * (db + 1) + 4 * g) * a.inv_sqrt_de;
+        const f32x4 w0 = img[G::W_A + db * 64 + lane] * q0, w1 = img[G::W_A + (db + 1) * 64 + lane] * q1;
+        mfma4x2d(la0, la1, k0, k1, w0, w1);                               // A = K tile (keys as rows), B = W_a (.) Q_i
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      f32x4 fe = splat4(vec[G::V_EATT + p]), fp = splat4(vec[G::V_PATT + p]);
+#pragma unroll
+      for (int ib = 0; ib < DEB; ++ib)
+        mfma4x2d(fe, fp, Y[ib], d1[ib], img[G::W_EATT + ib * 64 + lane], img[G::W_PATT + ib * 64 + lane]);
+      __builtin_amdgcn_sched_barrier(0);
+      float lg[4], mloc = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool kv = (keymask >> (4 * g + r)) & 1u;
+        float t = kv ? la0[r] + la1[r] : 0.f;
+        t = t + fe[r] * t;
+        t = t + fp[r] * t;
+        lg[r] = kv ? t : -INFINITY;
+        mloc = fmaxf(mloc, lg[r]);
+      }
+      const float M = groups_max(mloc);                                   // finite: a unit holds at least one valid key
+      f32x4 pe;
+      float sl = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pe[r] = lg[r] == -INFINITY ? 0.f : __expf(lg[r] - M);
+        sl += pe[r];
+      }
+      const float S = groups_sum(sl);
+      float* ap = a.attn_part + (long long)u * AP;
+      const long long vbase = (long long)b * n;
+      const float* vrow[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vrow[r] = a.nodelin + (vbase + min(jc * 16 + 4 * g + r, n - 1)) * a.ldn + 2 * DX + p;
+#pragma unroll
+      for (int db = 0; db < DXB; ++db) {
+        f32x4 acc = splat4(0.f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)                                       // A = V^T (channel on the row), B = p
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[r][16 * db], pe[r], acc, 0, 0, 0);
+        if (p < a.n_head) *reinterpret_cast<f32x4*>(ap + p * DX + 16 * db + 4 * g) = acc;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (g == 0 && p < a.n_head) {
+        ap[a.n_head * DX + p] = M;
+        ap[a.n_head * DX + 16 + p] = S;
+      }
+    }
+    // ---- E' = LN1(x + newE); E_out = LN2(E' + linE2 relu linE1 E')
+#pragma unroll
+    for (int ib = 0; ib < DEB; ++ib) x[ib] += nE[ib];
+    layernorm_c16<DEB>(x, vec + G::LN1G * DE, vec + G::LN1B * DE, g);
+    f32x4 o2[DEB];
+#pragma unroll
+    for (int ob = 0; ob < DEB; ++ob) o2[ob] = ld4(vec + G::B_FF2 * DE + 16 * ob + 4 * g);
+#pragma unroll
+    for (int f = 0; f < FFB / 4; ++f) {
+      f32x4 hid[4];
+#pragma unroll
+      for (int hb = 0; hb < 4; hb += 2) {
+        const int h0 = 4 * f + hb;
+        f32x4 a0 = ld4(vec + G::V_FF1 + 16 * h0 + 4 * g), a1 = ld4(vec + G::V_FF1 + 16 * (h0 + 1) + 4 * g);
+#pragma unroll
+        for (int ib = 0; ib < DEB; ++ib)
+          mfma4x2(a0, a1, img[G::W_FF1 + (h0 * DEB + ib) * 64 + lane], img[G::W_FF1 + ((h0 + 1) * DEB + ib) * 64 + lane], x[ib]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          hid[hb][r] = fmaxf(a0[r], 0.f);
+          hid[hb + 1][r] = fmaxf(a1[r], 0.f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int ob = 0; ob < DEB; ob += 2) {
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb)
+          mfma4x2(o2[ob], o2[ob + 1], img[G::W_FF2 + (ob * FFB + 4 * f + hb) * 64 + lane],
+                  img[G::W_FF2 + ((ob + 1) * FFB + 4 * f + hb) * 64 + lane], hid[hb]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int ib = 0; ib < DEB; ++ib) x[ib] += o2[ib];
+    layernorm_c16<DEB>(x, vec + G::LN2G * DE, vec + G::LN2B * DE, g);
+    if (inb) {
+      float* dst = a.E_out + pij + 4 * g;
+#pragma unroll
+      for (int ib = 0; ib < DEB; ++ib) *reinterpret_cast<f32x4*>(dst + 16 * ib) = vj ? x[ib] : splat4(0.f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Row merge: one wave per valid row.  Softmax partials of the row's units -> normalised weighted V per head
+// ([h][dx], the input of `out`, :179-180); statistic partials -> the row's (mean, M2, min, max) of Y and dist1 over its
+// valid keys (for the graph merge) and the EtoX inputs [mean|min|max|var] of E1 = Y + y_e_add + Y y_e_mul (exact
+// per-channel affine map of the statistics of Y) and of dist1 (:183-187, layers.py:60-69).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void block3d_row_merge_kernel(RowMerge3DArgs a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ridx = blockIdx.x * 4 + wave;
+  if (ridx >= *a.row_count) return;
+  const int row = a.rows[ridx];
+  const int n = a.n, nch = (n + 15) >> 4, b = row / n;
+  const int H = a.n_head, DX = a.dx, DE = a.de, AP = H * DX + 32;
+  const int* cc = a.chunk_cnt + b * nch;
+  const float* ap0 = a.attn_part + (long long)row * nch * AP;
+  for (int t = lane; t < H * DX; t += 64) {
+    const int h = t / DX;
+    float M = -INFINITY;
+    for (int c = 0; c < nch; ++c)
+      if (cc[c] > 0) M = fmaxf(M, ap0[(long long)c * AP + H * DX + h]);
+    float S = 0.f, acc = 0.f;
+    for (int c = 0; c < nch; ++c)
+      if (cc[c] > 0) {
+        const float* ap = ap0 + (long long)c * AP;
+        const float w = __expf(ap[H * DX + h] - M);
+        S += ap[H * DX + 16 + h] * w;
+        acc += ap[t] * w;
+      }
+    a.wvcat[(long long)row * (H * DX) + t] = acc / S;
+  }
+  const float* sp0 = a.stat_part + (long long)row * nch * (8 * DE);
+  const float* fl = a.film + (long long)b * a.ldf;
+  for (int t = lane; t < 2 * DE; t += 64) {
+    const int which = t / DE, ch = t - which * DE;
+    float N = 0.f, mean = 0.f, m2 = 0.f, mn = INFINITY, mx = -INFINITY;
+    for (int c = 0; c < nch; ++c)
+      if (cc[c] > 0) {
+        const float* sp = sp0 + (long long)c * (8 * DE) + which * 4 * DE + ch;
+        const float k = (float)cc[c], dl = sp[0] - mean, nn = N + k;
+        mean += dl * (k / nn);
+        m2 += sp[DE] + dl * dl * (N * k / nn);
+        mn = fminf(mn, sp[2 * DE]);
+        mx = fmaxf(mx, sp[3 * DE]);
+        N = nn;
+      }
+    float* ag = a.rowagg + (long long)row * (8 * DE) + which * 4 * DE + ch;
+    ag[0] = mean; ag[DE] = m2; ag[2 * DE] = mn; ag[3 * DE] = mx;
+    float* rs = a.rowstat + (long long)row * (8 * DE) + which * 4 * DE + ch;
+    if (which == 0) {
+      const float ya = fl[ch], ym = fl[DE + ch], s = 1.0f + ym;
+      const float lo = (mn + ya) + mn * ym, hi = (mx + ya) + mx * ym;
+      rs[0] = (mean + ya) + mean * ym;
+      rs[DE] = fminf(lo, hi);
+      rs[2 * DE] = fmaxf(lo, hi);
+      rs[3 * DE] = (m2 / N) * s * s;
+    } else {
+      rs[0] = mean; rs[DE] = mn; rs[2 * DE] = mx; rs[3 * DE] = m2 / N;
+    }
+  }
+}
+
+// newX = wV (y_x_mul + 1) + y_x_add with wV = out(.) FiLMed by the two EtoX vectors (:180-192).  Padded rows: out, ex, px
+// are zero there (row-masked products), so newX = y_x_add, as in the reference.
+__global__ __launch_bounds__(256) void block3d_newx_kernel(const float* __restrict__ outv, const float* __restrict__ ex,
+                                                           const float* __restrict__ px, const float* __restrict__ film, int ldf,
+                                                           int film_off, float* __restrict__ newX, long long total, int n, int dx) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % dx);
+  const long long row = idx / dx;
+  const float* fl = film + (row / n) * ldf + film_off;
+  float w = outv[idx];
+  w = w + ex[idx] * w;
+  w = w + px[idx] * w;
+  newX[idx] = w * (fl[dx + c] + 1.0f) + fl[c];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Graph merge: one workgroup per graph.  Etoy inputs of Y and dist1 from the row aggregates (every valid row holds the
+// same number of keys), Xtoy inputs of the UNMASKED newX (layers.py:15: the mean's numerator runs over every row of the
+// padded batch, the divisor, minimum, maximum and variance over the valid ones) -> zcat[b] columns [dy, dy + 4dx + 8de).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void block3d_graph_merge_kernel(GraphMerge3DArgs a) {
+  const int b = blockIdx.x, n = a.n, DE = a.de, DX = a.dx;
+  const uint8_t* m = a.mask + (long long)b * n;
+  float* z = a.zcat + (long long)b * a.ldz + a.dy;
+  __shared__ int s_nv;
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int i = 0; i < n; ++i) c += m[i] != 0;
+    s_nv = c;
+  }
+  __syncthreads();
+  const int nv = s_nv;
+  if (nv == 0) return;
+  for (int t = threadIdx.x; t < DX; t += 256) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += a.newX[((long long)b * n + i) * DX + t];
+    const float mean = s / (float)nv;
+    float q = 0.f, mn = INFINITY, mx = -INFINITY;
+    for (int i = 0; i < n; ++i)
+      if (m[i]) {
+        const float v = a.newX[((long long)b * n + i) * DX + t], d = v - mean;
+        q += d * d;
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+      }
+    z[t] = mean; z[DX + t] = mn; z[2 * DX + t] = mx; z[3 * DX + t] = q / (float)nv;
+  }
+  for (int t = threadIdx.x; t < 2 * DE; t += 256) {
+    const int which = t / DE, ch = t - which * DE;
+    float N = 0.f, mean = 0.f, m2 = 0.f, mn = INFINITY, mx = -INFINITY;
+    const float k = (float)nv;
+    for (int i = 0; i < n; ++i)
+      if (m[i]) {
+        const float* ag = a.rowagg + ((long long)b * n + i) * (8 * DE) + which * 4 * DE + ch;
+        const float dl = ag[0] - mean, nn = N + k;
+        mean += dl * (k / nn);
+        m2 += ag[DE] + dl * dl * (N * k / nn);
+        mn = fminf(mn, ag[2 * DE]);
+        mx = fmaxf(mx, ag[3 * DE]);
+        N = nn;
+      }
+    float* zz = z + 4 * DX + which * 4 * DE + ch;
+    zz[0] = mean; zz[DE] = mn; zz[2 * DE] = mx; zz[3 * DE] = m2 / N;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Positions every layer sees (utils.py:160-164 applied at :461 and after every layer, :301): P <- m (P - mean_n P),
+// starting from P = m pos.  pos4[l][b*n+i] = (P_l, |P_l|).  One wave per graph; valid nodes of one graph <= 64 * 64.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void block3d_pos_kernel(const float* __restrict__ pos, const uint8_t* __restrict__ mask, int n,
+                                                         int n_layers, float* __restrict__ pos4, long long layer_stride) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* P = pos + (long long)b * n * 3;
+  const uint8_t* m = mask + (long long)b * n;
+  float* out = pos4 + (long long)b * n * 4;
+  // state lives in the output buffer of the previous layer (layer 0 reads the input)
+  for (int l = 0; l < n_layers; ++l) {
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    const float* prev = l == 0 ? nullptr : out + (l - 1) * layer_stride;
+    for (int i = lane; i < n; i += 64)
+      if (m[i]) {
+        sx += prev ? prev[i * 4] : P[i * 3];
+        sy += prev ? prev[i * 4 + 1] : P[i * 3 + 1];
+        sz += prev ? prev[i * 4 + 2] : P[i * 3 + 2];
+      }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      sx += __shfl_xor(sx, o);
+      sy += __shfl_xor(sy, o);
+      sz += __shfl_xor(sz, o);
+    }
+    const float mx = sx / (float)n, my = sy / (float)n, mz = sz / (float)n;
+    float* cur = out + l * layer_stride;
+    for (int i = lane; i < n; i += 64) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m[i]) {
+        v[0] = (prev ? prev[i * 4] : P[i * 3]) - mx;
+        v[1] = (prev ? prev[i * 4 + 1] : P[i * 3 + 1]) - my;
+        v[2] = (prev ? prev[i * 4 + 2] : P[i * 3 + 2]) - mz;
+        v[3] = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      }
+      *reinterpret_cast<f32x4*>(cur + i * 4) = v;
+    }
+    __syncthreads();   // one wave: orders this layer's stores before the next layer's loads
+  }
+}
+
+// valid keys per (graph, 16-key chunk)
+__global__ void block3d_chunk_count_kernel(const uint8_t* mask, int B, int n, int nch, int* cnt) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * nch) return;
+  const int b = idx / nch, c = idx - b * nch;
+  int k = 0;
+  for (int j = 16 * c; j < min(n, 16 * c + 16); ++j) k += mask[(long long)b * n + j] != 0;
+  cnt[idx] = k;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+#define SCGG_B3D_CASES CASE(4, 8, 8) CASE(4, 8, 16) CASE(2, 4, 2)   /* (de/16, dim_ffE/16, dx/16) */
+
+long long block3d_img_f4(int dx, int de, int ffe) {
+#define CASE(DEB, FFB, DXB) \
+  if (de == 16 * DEB && ffe == 16 * FFB && dx == 16 * DXB) return Geom3D<DEB, FFB, DXB>::IMG_F4;
+  SCGG_B3D_CASES
+#undef CASE
+  return -1;
+}
+
+int launch_block3d_pack(const Block3DPackArgs& a, int dx, int de, int ffe, hipStream_t st) {
+  if (a.n_head < 1 || a.n_head > 16) return -1;
+#define CASE(DEB, FFB, DXB)                                                                           \
+  if (de == 16 * DEB && ffe == 16 * FFB && dx == 16 * DXB) {                                          \
+    hipLaunchKernelGGL((block3d_pack_kernel<DEB, FFB, DXB>), dim3(64), dim3(256), 0, st, a);          \
+    return 0;                                                                                         \
+  }
+  SCGG_B3D_CASES
+#undef CASE
+  return -1;
+}
+
+template <int DEB, int FFB, int DXB>
+static int launch_b3d(const Block3DArgs& a, hipStream_t st) {
+  constexpr int NW = 8;
+  const int n_cu = device_cu_count();
+  if (n_cu <= 0) return -2;
+  static LdsAttrOnce attr;
+  void (*kern)(Block3DArgs) = block3d_edge_kernel<DEB, FFB, DXB, NW>;
+  const size_t lds = (size_t)Geom3D<DEB, FFB, DXB>::IMG_F4 * 16;
+  if (set_max_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds)) return -2;
+  hipLaunchKernelGGL(kern, dim3(n_cu), dim3(NW * 64), lds, st, a);
+  return 0;
+}
+
+int launch_block3d_edge(const Block3DArgs& a, int dx, int de, int ffe, hipStream_t st) {
+  if (a.n_head < 1 || a.n_head > 16 || a.ldn % 4 != 0 || a.ldf % 4 != 0) return -1;
+#define CASE(DEB, FFB, DXB) \
+  if (de == 16 * DEB && ffe == 16 * FFB && dx == 16 * DXB) return launch_b3d<DEB, FFB, DXB>(a, st);
+  SCGG_B3D_CASES
+#undef CASE
+  return -1;
+}
+
+int launch_block3d_row_merge(const RowMerge3DArgs& a, int M, hipStream_t st) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(block3d_row_merge_kernel, dim3((M + 3) / 4), dim3(256), 0, st, a);
+  return 0;
+}
+
+int launch_block3d_newx(const float* outv, const float* ex, const float* px, const float* film, int ldf, int film_off,
+                        float* newX, int M, int n, int dx, hipStream_t st) {
+  const long long total = (long long)M * dx;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(block3d_newx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, outv, ex, px, film, ldf,
+                     film_off, newX, total, n, dx);
+  return 0;
+}
+
+int launch_block3d_graph_merge(const GraphMerge3DArgs& a, int B, hipStream_t st) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(block3d_graph_merge_kernel, dim3(B), dim3(256), 0, st, a);
+  return 0;
+}
+
+int launch_block3d_pos(const float* pos, const uint8_t* mask, int B, int n, int n_layers, float* pos4, hipStream_t st) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(block3d_pos_kernel, dim3(B), dim3(64), 0, st, pos, mask, n, n_layers, pos4, (long long)B * n * 4);
+  return 0;
+}
+
+int launch_block3d_chunk_count(const uint8_t* mask, int B, int n, int* cnt, hipStream_t st) {
+  const int nch = (n + 15) / 16, tot = B * nch;
+  if (tot <= 0) return 0;
+  hipLaunchKernelGGL(block3d_chunk_count_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, mask, B, n, nch, cnt);
+  return 0;
+}
+
+}  // namespace scgg

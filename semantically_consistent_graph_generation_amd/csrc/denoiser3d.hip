@@ -1,0 +1,451 @@
+// Host-side engine behind scgg_denoiser3d_* (include/scgg.h): Graph3DTransformer / EquivariantGraph3DTransformer of the
+// reference (src/ConStruct/models/pos_transformer_model.py:338-493, equivariant_pos_transformer_model.py:334-486), eval
+// mode, on ONE stream.  The edge path of every layer is one fused kernel (block3d.hip); the node and global paths, which
+// are O(B n d^2) and small next to it, run as fp32-MFMA GEMM launches (node_kernels.hip) between small merge kernels.
+// No torch types, no synchronisation, no allocation after finalize.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/scgg.h"
+#include "kernels.h"
+
+namespace scgg {
+namespace {
+
+struct Param3 { const float* p; int64_t numel; };
+static inline size_t align_up3(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Bump {   // two-pass bump allocator (base == nullptr: measuring pass)
+  char* base;
+  size_t off = 0;
+  explicit Bump(char* b) : base(b) {}
+  template <typename T>
+  T* take(size_t count) {
+    off = align_up3(off, 256);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+struct Layer3 {
+  bool predicts_y = true;
+  f32x4_t* img = nullptr;        // block3d_edge_kernel's LDS image
+  float *Wnl, *bnl;              // [3dx+2de, dx]: q | k | v | x_e_mul1 | x_e_mul2
+  float *Wfilm, *bfilm;          // [2de+2dx, dy]: y_e_add | y_e_mul | y_x_add | y_x_mul
+  float *Wycat, *bycat;          // [dy, dy+4dx+8de]: y_y | x_y.lin | e_y.lin | dist_y.lin, summed biases
+};
+
+__global__ void vec_sum4_kernel(const float* a, const float* b, const float* c, const float* d, float* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = ((a[i] + b[i]) + c[i]) + d[i];
+}
+
+}  // namespace
+}  // namespace scgg
+
+using namespace scgg;
+
+struct scgg_denoiser3d {
+  scgg_denoiser3d_config c;
+  std::map<std::string, Param3> params;
+  bool finalized = false;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  f32x4_t *in_E_img = nullptr, *out_E_img = nullptr, *rad_img = nullptr;
+  std::vector<Layer3> layers;
+};
+
+namespace {
+
+const Param3* find3(const scgg_denoiser3d* h, const std::string& name, int64_t numel) {
+  auto it = h->params.find(name);
+  if (it == h->params.end()) { fail("missing parameter '%s'", name.c_str()); return nullptr; }
+  if (it->second.numel != numel) {
+    fail("parameter '%s' has %lld elements, expected %lld", name.c_str(), (long long)it->second.numel, (long long)numel);
+    return nullptr;
+  }
+  return &it->second;
+}
+
+int check3(const char* what) {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail("%s: %s", what, hipGetErrorString(e));
+}
+
+// dst[N, ldd] columns [col0, col0+K) <- W[N,K]
+int put3(scgg_denoiser3d* h, const std::string& name, int N, int K, float* dst, int ldd, int col0, hipStream_t st) {
+  const Param3* w = find3(h, name, (int64_t)N * K);
+  if (!w) return -1;
+  launch_copy_cols(w->p, K, dst + col0, ldd, N, K, st);
+  return 0;
+}
+
+int build3(scgg_denoiser3d* h, bool fill, hipStream_t st) {
+  const scgg_denoiser3d_config& c = h->c;
+  Bump ar(fill ? h->arena : nullptr);
+  const int dx = c.dx, de = c.de, dy = c.dy, H = c.n_head;
+  {
+    const long long n_in = edge_mlp_img_f4(c.in_E, c.hid_E, de), n_out = edge_mlp_img_f4(de, c.hid_E, c.out_E),
+                    n_rad = edge_mlp_img_f4(de, c.hid_E, 1);
+    if (n_in < 0 || n_out < 0 || n_rad < 0) return fail("edge MLP kernels have no build for hid_E=%d", c.hid_E);
+    h->in_E_img = ar.take<f32x4_t>((size_t)n_in);
+    h->out_E_img = ar.take<f32x4_t>((size_t)n_out);
+    h->rad_img = ar.take<f32x4_t>((size_t)n_rad);
+    if (fill) {
+      const Param3 *w0 = find3(h, "mlp_in_E.0.weight", (int64_t)c.hid_E * c.in_E), *b0 = find3(h, "mlp_in_E.0.bias", c.hid_E);
+      const Param3 *w3 = find3(h, "mlp_in_E.3.weight", (int64_t)de * c.hid_E), *b3 = find3(h, "mlp_in_E.3.bias", de);
+      const Param3 *v0 = find3(h, "mlp_out_E.0.weight", (int64_t)c.hid_E * de), *d0 = find3(h, "mlp_out_E.0.bias", c.hid_E);
+      const Param3 *v3 = find3(h, "mlp_out_E.3.weight", (int64_t)c.out_E * c.hid_E), *d3 = find3(h, "mlp_out_E.3.bias", c.out_E);
+      const Param3 *r0 = find3(h, "mlp_out_radius.0.weight", (int64_t)c.hid_E * de), *e0 = find3(h, "mlp_out_radius.0.bias", c.hid_E);
+      const Param3 *r3 = find3(h, "mlp_out_radius.3.weight", c.hid_E), *e3 = find3(h, "mlp_out_radius.3.bias", 1);
+      if (!w0 || !b0 || !w3 || !b3 || !v0 || !d0 || !v3 || !d3 || !r0 || !e0 || !r3 || !e3) return -1;
+      EdgeMlpPackArgs pi{w0->p, b0->p, w3->p, b3->p, h->in_E_img, c.in_E, c.hid_E, de};
+      EdgeMlpPackArgs po{v0->p, d0->p, v3->p, d3->p, h->out_E_img, de, c.hid_E, c.out_E};
+      EdgeMlpPackArgs pr{r0->p, e0->p, r3->p, e3->p, h->rad_img, de, c.hid_E, 1};
+      if (launch_edge_mlp_pack(pi, st) || launch_edge_mlp_pack(po, st) || launch_edge_mlp_pack(pr, st))
+        return fail("edge MLP pack: unsupported dims in_E=%d hid_E=%d de=%d out_E=%d", c.in_E, c.hid_E, de, c.out_E);
+    }
+  }
+  h->layers.resize(c.n_layers);
+  const int NL = 3 * dx + 2 * de, FL = 2 * de + 2 * dx, kcat = dy + 4 * dx + 8 * de;
+  for (int l = 0; l < c.n_layers; ++l) {
+    Layer3& L = h->layers[l];
+    L.predicts_y = l != c.n_layers - 1;
+    const std::string p = "tf_layers." + std::to_string(l) + ".", sa = p + "self_attn.";
+    const long long nimg = block3d_img_f4(dx, de, c.dim_ffE);
+    if (nimg < 0) return fail("3D edge kernel has no build for dx=%d de=%d dim_ffE=%d", dx, de, c.dim_ffE);
+    L.img = ar.take<f32x4_t>((size_t)nimg);
+    L.Wnl = ar.take<float>((size_t)NL * dx);
+    L.bnl = ar.take<float>((size_t)NL);
+    L.Wfilm = ar.take<float>((size_t)FL * dy);
+    L.bfilm = ar.take<float>((size_t)FL);
+    L.Wycat = ar.take<float>((size_t)dy * kcat);
+    L.bycat = ar.take<float>((size_t)dy);
+    if (!fill) continue;
+    {
+      auto W = [&](const std::string& nm, int64_t numel) { const Param3* q = find3(h, nm, numel); return q ? q->p : nullptr; };
+      Block3DPackArgs a;
+      a.W_in = W(sa + "in_E.weight", (int64_t)de * de);            a.b_in = W(sa + "in_E.bias", de);
+      a.W_dadd = W(sa + "dist_add_e.weight", (int64_t)de * de);    a.b_dadd = W(sa + "dist_add_e.bias", de);
+      a.W_dmul = W(sa + "dist_mul_e.weight", (int64_t)de * de);    a.b_dmul = W(sa + "dist_mul_e.bias", de);
+      a.W_eout = W(sa + "e_out.weight", (int64_t)de * de);         a.b_eout = W(sa + "e_out.bias", de);
+      a.W_ff1 = W(p + "linE1.weight", (int64_t)c.dim_ffE * de);    a.b_ff1 = W(p + "linE1.bias", c.dim_ffE);
+      a.W_ff2 = W(p + "linE2.weight", (int64_t)de * c.dim_ffE);    a.b_ff2 = W(p + "linE2.bias", de);
+      a.W_eatt = W(sa + "e_att_mul.weight", (int64_t)H * de);      a.b_eatt = W(sa + "e_att_mul.bias", H);
+      a.W_patt = W(sa + "pos_att_mul.weight", (int64_t)H * de);    a.b_patt = W(sa + "pos_att_mul.bias", H);
+      a.W_a = W(sa + "a.weight", (int64_t)H * dx);
+      a.ln1g = W(p + "normE1.weight", de);  a.ln1b = W(p + "normE1.bias", de);
+      a.ln2g = W(p + "normE2.weight", de);  a.ln2b = W(p + "normE2.bias", de);
+      a.W_dist = W(sa + "lin_dist1.weight", (int64_t)de * 2);      a.b_dist = W(sa + "lin_dist1.bias", de);
+      a.W_n1 = W(sa + "lin_norm_pos1.weight", de);                 a.b_n1 = W(sa + "lin_norm_pos1.bias", de);
+      a.W_n2 = W(sa + "lin_norm_pos2.weight", de);                 a.b_n2 = W(sa + "lin_norm_pos2.bias", de);
+      a.img = L.img;
+      a.n_head = H;
+      const float* all[] = {a.W_in, a.b_in, a.W_dadd, a.b_dadd, a.W_dmul, a.b_dmul, a.W_eout, a.b_eout, a.W_ff1, a.b_ff1,
+                            a.W_ff2, a.b_ff2, a.W_eatt, a.b_eatt, a.W_patt, a.b_patt, a.W_a, a.ln1g, a.ln1b, a.ln2g, a.ln2b,
+                            a.W_dist, a.b_dist, a.W_n1, a.b_n1, a.W_n2, a.b_n2};
+      for (const float* q : all)
+        if (!q) return -1;
+      if (launch_block3d_pack(a, dx, de, c.dim_ffE, st)) return fail("3D edge pack failed");
+    }
+    const char* nl[5] = {"q", "k", "v", "x_e_mul1", "x_e_mul2"};
+    int r0 = 0;
+    for (int t = 0; t < 5; ++t) {
+      const int N = t < 3 ? dx : de;
+      if (put3(h, sa + nl[t] + ".weight", N, dx, L.Wnl + (size_t)r0 * dx, dx, 0, st)) return -1;
+      if (put3(h, sa + nl[t] + ".bias", 1, N, L.bnl + r0, N, 0, st)) return -1;
+      r0 += N;
+    }
+    const char* fl[4] = {"y_e_add", "y_e_mul", "y_x_add", "y_x_mul"};
+    r0 = 0;
+    for (int t = 0; t < 4; ++t) {
+      const int N = t < 2 ? de : dx;
+      if (put3(h, sa + fl[t] + ".weight", N, dy, L.Wfilm + (size_t)r0 * dy, dy, 0, st)) return -1;
+      if (put3(h, sa + fl[t] + ".bias", 1, N, L.bfilm + r0, N, 0, st)) return -1;
+      r0 += N;
+    }
+    if (L.predicts_y) {
+      if (put3(h, sa + "y_y.weight", dy, dy, L.Wycat, kcat, 0, st)) return -1;
+      if (put3(h, sa + "x_y.lin.weight", dy, 4 * dx, L.Wycat, kcat, dy, st)) return -1;
+      if (put3(h, sa + "e_y.lin.weight", dy, 4 * de, L.Wycat, kcat, dy + 4 * dx, st)) return -1;
+      if (put3(h, sa + "dist_y.lin.weight", dy, 4 * de, L.Wycat, kcat, dy + 4 * dx + 4 * de, st)) return -1;
+      const Param3 *b0 = find3(h, sa + "y_y.bias", dy), *b1 = find3(h, sa + "x_y.lin.bias", dy),
+                   *b2 = find3(h, sa + "e_y.lin.bias", dy), *b3 = find3(h, sa + "dist_y.lin.bias", dy);
+      if (!b0 || !b1 || !b2 || !b3) return -1;
+      hipLaunchKernelGGL(vec_sum4_kernel, dim3((dy + 255) / 256), dim3(256), 0, st, b0->p, b1->p, b2->p, b3->p, L.bycat, dy);
+    }
+    if (check3("3D weight concatenation")) return -1;
+  }
+  h->arena_bytes = align_up3(ar.off, 256);
+  return 0;
+}
+
+struct Work3 {
+  float *X, *X1, *nodelin, *film, *pos4, *E0, *E1, *attn, *stat, *wvcat, *rowstat, *rowagg, *t_out, *t_ex, *t_px, *newX, *t_ff,
+      *y, *y1, *zcat, *yt1, *yt2, *hidX, *hidy, *xo;
+  int *rows, *row_count, *units, *unit_count, *goff, *chunk_cnt;
+  size_t bytes;
+};
+
+Work3 carve3(const scgg_denoiser3d_config& c, int B, int n, char* base) {
+  Bump ar(base);
+  Work3 w;
+  const size_t M = (size_t)B * n, P = M * n, nch = (size_t)(n + 15) / 16;
+  const int dx = c.dx, de = c.de, dy = c.dy;
+  const int wideX = std::max(std::max(c.dim_ffX, c.hid_X), dx);
+  w.X = ar.take<float>(M * dx);
+  w.X1 = ar.take<float>(M * dx);
+  w.nodelin = ar.take<float>(M * (3 * dx + 2 * de));
+  w.film = ar.take<float>((size_t)B * (2 * de + 2 * dx));
+  w.pos4 = ar.take<float>((size_t)c.n_layers * M * 4);
+  w.E0 = ar.take<float>(P * de);
+  w.E1 = ar.take<float>(P * de);
+  w.attn = ar.take<float>(M * nch * ((size_t)c.n_head * dx + 32));
+  w.stat = ar.take<float>(M * nch * 8 * de);
+  w.wvcat = ar.take<float>(M * (size_t)c.n_head * dx);
+  w.rowstat = ar.take<float>(M * 8 * de);
+  w.rowagg = ar.take<float>(M * 8 * de);
+  w.t_out = ar.take<float>(M * dx);
+  w.t_ex = ar.take<float>(M * dx);
+  w.t_px = ar.take<float>(M * dx);
+  w.newX = ar.take<float>(M * dx);
+  w.t_ff = ar.take<float>(M * wideX);
+  w.hidX = ar.take<float>(M * wideX);
+  w.xo = ar.take<float>(M * (size_t)std::max(c.out_X, 1));
+  const int ywide = std::max(std::max(c.dim_ffy, c.hid_y), dy);
+  w.y = ar.take<float>((size_t)B * dy);
+  w.y1 = ar.take<float>((size_t)B * dy);
+  w.zcat = ar.take<float>((size_t)B * (dy + 4 * dx + 8 * de));
+  w.yt1 = ar.take<float>((size_t)B * ywide);
+  w.yt2 = ar.take<float>((size_t)B * ywide);
+  w.hidy = ar.take<float>((size_t)B * ywide);
+  w.rows = ar.take<int>(M);
+  w.row_count = ar.take<int>(64);
+  w.units = ar.take<int>(M * nch);
+  w.unit_count = ar.take<int>(64);
+  w.goff = ar.take<int>((size_t)2 * B);
+  w.chunk_cnt = ar.take<int>((size_t)B * nch);
+  w.bytes = align_up3(ar.off, 256);
+  return w;
+}
+
+int gemm3(scgg_denoiser3d* h, const float* A, int lda, const std::string& name, float* C, int ldc, int M, int N, int K, int flags,
+          const uint8_t* rowmask, hipStream_t st) {
+  const Param3 *W = find3(h, name + ".weight", (int64_t)N * K), *b = find3(h, name + ".bias", N);
+  if (!W || !b) return -1;
+  GemmArgs g{A, W->p, b->p, C, rowmask, M, N, K, lda, K, ldc, flags, 0, 0, 0, 0};
+  return launch_gemm(g, st);
+}
+int gemm3_raw(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, int flags,
+              const uint8_t* rowmask, hipStream_t st) {
+  GemmArgs g{A, W, bias, C, rowmask, M, N, K, lda, K, ldc, flags, 0, 0, 0, 0};
+  return launch_gemm(g, st);
+}
+int ln3(scgg_denoiser3d* h, const float* x, const float* r, const std::string& name, const uint8_t* rowmask, float* out, int M, int D,
+        hipStream_t st) {
+  const Param3 *g = find3(h, name + ".weight", D), *b = find3(h, name + ".bias", D);
+  if (!g || !b) return -1;
+  AddLnArgs a{x, r, g->p, b->p, rowmask, out, M, D, nullptr, nullptr};
+  return launch_add_layernorm(a, st);
+}
+
+// sym + mask copy of an unsymmetrised hidden E into a caller buffer (debug tap)
+__global__ void sym_copy3_kernel(const float* E, const uint8_t* mask, float* out, int B, int n, int de) {
+  const long long idx = blockIdx.x * 256ll + threadIdx.x;
+  const long long total = (long long)B * n * n * de;
+  if (idx >= total) return;
+  const int c = idx % de;
+  const long long pr = idx / de;
+  const int j = pr % n;
+  const long long bi = pr / n;
+  const int i = bi % n, b = bi / n;
+  const bool live = i != j && mask[b * n + i] && mask[b * n + j];
+  out[idx] = live ? 0.5f * (E[idx] + E[(((long long)b * n + j) * n + i) * de + c]) : 0.f;
+}
+
+#define TRY(x) do { if ((x) != 0) return -1; } while (0)
+
+int run3(scgg_denoiser3d* h, const float* X, const float* E, const float* y, const float* pos, const uint8_t* mask, int B, int n,
+         int n_run_layers, bool tap, float* o1, float* o2, float* o3, void* workspace, size_t ws_bytes, hipStream_t st) {
+  if (!h || !h->finalized) return fail("denoiser3d not finalized");
+  if (B <= 0 || n <= 0) return fail("bad batch shape B=%d n=%d", B, n);
+  if (!X || !E || !y || !pos || !mask) return fail("denoiser3d: null input");
+  const scgg_denoiser3d_config& c = h->c;
+  if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) return fail("workspace must be 256-byte aligned");
+  Work3 w = carve3(c, B, n, static_cast<char*>(workspace));
+  if (ws_bytes < w.bytes) return fail("workspace too small: %zu < %zu", ws_bytes, w.bytes);
+  const int M = B * n, dx = c.dx, de = c.de, dy = c.dy, H = c.n_head;
+  const int NL = 3 * dx + 2 * de, FL = 2 * de + 2 * dx, kcat = dy + 4 * dx + 8 * de;
+  const bool eq = c.equivariant != 0;
+
+  TRY(launch_build_lists(mask, B, n, w.goff, w.rows, w.row_count, w.units, w.unit_count, st));
+  TRY(launch_block3d_chunk_count(mask, B, n, w.chunk_cnt, st));
+  TRY(launch_block3d_pos(pos, mask, B, n, c.n_layers, w.pos4, st));
+  // ---- input MLPs (:451-461).  Hidden E is stored unsymmetrised; every consumer symmetrises and masks on load.
+  {
+    EdgeMlpUnitArgs a{E, nullptr, mask, h->in_E_img, w.E0, w.units, w.unit_count, B, n, c.in_E, 0};
+    if (launch_edge_mlp_in(a, c.in_E, c.hid_E, de, st)) return fail("edge input MLP: unsupported dims");
+  }
+  TRY(gemm3(h, y, c.in_y, "mlp_in_y.0", w.hidy, c.hid_y, B, c.hid_y, c.in_y, GEMM_RELU, nullptr, st));
+  TRY(gemm3(h, w.hidy, c.hid_y, "mlp_in_y.3", w.y, dy, B, dy, c.hid_y, GEMM_RELU, nullptr, st));
+  if (eq) {
+    TRY(gemm3(h, X, c.in_X, "mlp_in_X.0", w.hidX, c.hid_X, M, c.hid_X, c.in_X, GEMM_RELU, nullptr, st));
+    TRY(gemm3(h, w.hidX, c.hid_X, "mlp_in_X.3", w.X, dx, M, dx, c.hid_X, GEMM_RELU | GEMM_ROWMASK, mask, st));
+  } else {
+    TRY(gemm3(h, pos, 3, "mlp_in_pos_high_dim.0", w.hidX, c.hid_X, M, c.hid_X, 3, GEMM_RELU, nullptr, st));
+    TRY(gemm3(h, w.hidX, c.hid_X, "mlp_in_pos_high_dim.3", w.X, dx, M, dx, c.hid_X, GEMM_RELU | GEMM_ROWMASK, mask, st));
+    if (!tap && c.out_X > 0) {   // :467: the node head never sees the layers
+      TRY(gemm3(h, X, c.in_X, "mlp_in_X.0", w.hidX, c.hid_X, M, c.hid_X, c.in_X, GEMM_RELU, nullptr, st));
+      TRY(gemm3(h, w.hidX, c.hid_X, "mlp_in_X.3", w.t_ff, dx, M, dx, c.hid_X, GEMM_RELU, nullptr, st));
+      TRY(gemm3(h, w.t_ff, dx, "mlp_out_X.0", w.hidX, c.hid_X, M, c.hid_X, dx, GEMM_RELU, nullptr, st));
+      TRY(gemm3(h, w.hidX, c.hid_X, "mlp_out_X.3", w.xo, c.out_X, M, c.out_X, c.hid_X, 0, nullptr, st));
+      TRY(launch_x_out_residual(w.xo, X, c.in_X, mask, o1, M, c.out_X, st));
+    }
+  }
+  float *Ecur = w.E0, *Enext = w.E1;
+  const int L_run = tap ? n_run_layers : c.n_layers;
+  for (int l = 0; l < L_run; ++l) {
+    const Layer3& L = h->layers[l];
+    const std::string p = "tf_layers." + std::to_string(l) + ".", sa = p + "self_attn.";
+    const bool need_x = l != c.n_layers - 1 || eq || tap;      // the last layer's X feeds nothing in Graph3DTransformer
+    TRY(gemm3_raw(w.X, dx, L.Wnl, L.bnl, w.nodelin, NL, M, NL, dx, GEMM_ROWMASK, mask, st));
+    TRY(gemm3_raw(w.y, dy, L.Wfilm, L.bfilm, w.film, FL, B, FL, dy, 0, nullptr, st));
+    {
+      Block3DArgs a;
+      a.E_in = Ecur; a.E_out = Enext; a.mask = mask; a.nodelin = w.nodelin; a.ldn = NL; a.film = w.film; a.ldf = FL;
+      a.pos4 = w.pos4 + (size_t)l * M * 4; a.img = L.img; a.attn_part = w.attn; a.stat_part = w.stat;
+      a.units = w.units; a.unit_count = w.unit_count; a.B = B; a.n = n; a.n_head = H; a.need_attn = need_x ? 1 : 0;
+      a.inv_sqrt_de = 1.0f / sqrtf((float)de);
+      if (launch_block3d_edge(a, dx, de, c.dim_ffE, st)) return fail("3D edge kernel: unsupported dims");
+    }
+    if (need_x) {
+      RowMerge3DArgs r{w.attn, w.stat, w.chunk_cnt, w.film, FL, w.wvcat, w.rowstat, w.rowagg, w.rows, w.row_count, n, H, dx, de};
+      TRY(launch_block3d_row_merge(r, M, st));
+      TRY(gemm3(h, w.wvcat, H * dx, sa + "out", w.t_out, dx, M, dx, H * dx, GEMM_ROWMASK, mask, st));
+      TRY(gemm3(h, w.rowstat, 8 * de, sa + "e_x_mul.lin", w.t_ex, dx, M, dx, 4 * de, GEMM_ROWMASK, mask, st));
+      TRY(gemm3(h, w.rowstat + 4 * de, 8 * de, sa + "pos_x_mul.lin", w.t_px, dx, M, dx, 4 * de, GEMM_ROWMASK, mask, st));
+      TRY(launch_block3d_newx(w.t_out, w.t_ex, w.t_px, w.film, FL, 2 * de, w.newX, M, n, dx, st));
+      if (L.predicts_y) {
+        GraphMerge3DArgs g{w.rowagg, mask, w.newX, w.zcat, kcat, n, dx, de, dy};
+        TRY(launch_block3d_graph_merge(g, B, st));
+        TRY(launch_copy_cols(w.y, dy, w.zcat, kcat, B, dy, st));
+        TRY(gemm3_raw(w.zcat, kcat, L.Wycat, L.bycat, w.yt1, dy, B, dy, kcat, 0, nullptr, st));
+        TRY(gemm3(h, w.yt1, dy, sa + "y_out.0", w.yt2, dy, B, dy, dy, GEMM_RELU, nullptr, st));
+        TRY(gemm3(h, w.yt2, dy, sa + "y_out.2", w.yt1, dy, B, dy, dy, 0, nullptr, st));
+        TRY(ln3(h, w.y, w.yt1, p + "norm_y1", nullptr, w.y1, B, dy, st));
+        TRY(gemm3(h, w.y1, dy, p + "lin_y1", w.hidy, c.dim_ffy, B, c.dim_ffy, dy, GEMM_RELU, nullptr, st));
+        TRY(gemm3(h, w.hidy, c.dim_ffy, p + "lin_y2", w.yt2, dy, B, dy, c.dim_ffy, 0, nullptr, st));
+      }
+      TRY(gemm3(h, w.newX, dx, sa + "x_out", w.t_out, dx, M, dx, dx, GEMM_ROWMASK, mask, st));
+      TRY(ln3(h, w.X, w.t_out, p + "normX1", nullptr, w.X1, M, dx, st));
+      TRY(gemm3(h, w.X1, dx, p + "linX1", w.t_ff, c.dim_ffX, M, c.dim_ffX, dx, GEMM_RELU, nullptr, st));
+      TRY(gemm3(h, w.t_ff, c.dim_ffX, p + "linX2", w.t_out, dx, M, dx, c.dim_ffX, 0, nullptr, st));
+      TRY(ln3(h, w.X1, w.t_out, p + "normX2", mask, w.X, M, dx, st));
+      if (L.predicts_y) TRY(ln3(h, w.y1, w.yt2, p + "norm_y2", nullptr, w.y, B, dy, st));   // after film(l) and Xtoy were taken
+    }
+    float* t = Ecur; Ecur = Enext; Enext = t;
+  }
+  if (tap) {
+    if (o1) (void)hipMemcpyAsync(o1, w.X, (size_t)M * dx * 4, hipMemcpyDeviceToDevice, st);
+    if (o2) {
+      const long long total = (long long)M * n * de;
+      hipLaunchKernelGGL(sym_copy3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Ecur, mask, o2, B, n, de);
+    }
+    if (o3) (void)hipMemcpyAsync(o3, w.y, (size_t)B * dy * 4, hipMemcpyDeviceToDevice, st);
+    return check3("denoiser3d tap");
+  }
+  if (eq && c.out_X > 0) {
+    TRY(gemm3(h, w.X, dx, "mlp_out_X.0", w.hidX, c.hid_X, M, c.hid_X, dx, GEMM_RELU, nullptr, st));
+    TRY(gemm3(h, w.hidX, c.hid_X, "mlp_out_X.3", w.xo, c.out_X, M, c.out_X, c.hid_X, 0, nullptr, st));
+    TRY(launch_x_out_residual(w.xo, X, c.in_X, mask, o1, M, c.out_X, st));
+  }
+  // ---- edge heads (:468-487): logits with the residual to the input classes, radius without one
+  if (hipMemsetAsync(o2, 0, (size_t)M * n * c.out_E * 4, st) != hipSuccess) return fail("memset failed");
+  {
+    EdgeMlpUnitArgs a{Ecur, E, mask, h->out_E_img, o2, w.units, w.unit_count, B, n, c.in_E, c.out_E};
+    if (launch_edge_mlp_out(a, de, c.hid_E, c.out_E, st)) return fail("edge output MLP: unsupported dims");
+  }
+  if (o3) {
+    if (hipMemsetAsync(o3, 0, (size_t)M * n * 4, st) != hipSuccess) return fail("memset failed");
+    EdgeMlpUnitArgs a{Ecur, nullptr, mask, h->rad_img, o3, w.units, w.unit_count, B, n, c.in_E, 1};
+    if (launch_edge_mlp_out(a, de, c.hid_E, 1, st)) return fail("radius MLP: unsupported dims");
+  }
+  return check3("denoiser3d forward");
+}
+
+}  // namespace
+
+extern "C" scgg_denoiser3d* scgg_denoiser3d_create(const scgg_denoiser3d_config* cfg) {
+  if (!cfg) { fail("null config"); return nullptr; }
+  const scgg_denoiser3d_config& c = *cfg;
+  if (c.n_layers < 1 || c.n_head < 1 || c.n_head > 16 || c.dx % c.n_head != 0) { fail("bad n_layers / n_head"); return nullptr; }
+  if (c.in_X < 1 || c.in_E < 1 || c.in_y < 1 || c.out_E < 1 || c.out_E > c.in_E || c.out_X > c.in_X || c.out_X < 0) {
+    fail("bad input / output widths"); return nullptr;
+  }
+  if (block3d_img_f4(c.dx, c.de, c.dim_ffE) < 0) {
+    fail("3D edge kernel has no build for dx=%d de=%d dim_ffE=%d (built: 128/64/128, 256/64/128, 32/32/64)", c.dx, c.de, c.dim_ffE);
+    return nullptr;
+  }
+  if (edge_mlp_img_f4(c.in_E, c.hid_E, c.de) < 0 || edge_mlp_img_f4(c.de, c.hid_E, c.out_E) < 0) {
+    fail("edge MLP kernels have no build for in_E=%d hid_E=%d de=%d out_E=%d", c.in_E, c.hid_E, c.de, c.out_E);
+    return nullptr;
+  }
+  if (c.dy % 4 != 0 || c.dx % 4 != 0) { fail("dx, dy must be multiples of 4"); return nullptr; }
+  scgg_denoiser3d* h = new scgg_denoiser3d();
+  h->c = c;
+  return h;
+}
+
+extern "C" void scgg_denoiser3d_destroy(scgg_denoiser3d* h) {
+  if (!h) return;
+  if (h->arena) (void)hipFree(h->arena);
+  delete h;
+}
+
+extern "C" int scgg_denoiser3d_set_param(scgg_denoiser3d* h, const char* name, const float* data, int64_t numel) {
+  if (!h || !name || !data) return fail("set_param: null argument");
+  h->params[name] = Param3{data, numel};
+  return 0;
+}
+
+extern "C" int scgg_denoiser3d_finalize(scgg_denoiser3d* h, void* stream) {
+  if (!h) return fail("finalize: null handle");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (h->arena == nullptr) {
+    if (build3(h, false, st)) return -1;
+    if (hipMalloc(reinterpret_cast<void**>(&h->arena), h->arena_bytes) != hipSuccess) return fail("arena allocation failed");
+    if (hipMemsetAsync(h->arena, 0, h->arena_bytes, st) != hipSuccess) return fail("arena memset failed");
+  }
+  if (build3(h, true, st)) return -1;
+  h->finalized = true;
+  return 0;
+}
+
+extern "C" size_t scgg_denoiser3d_workspace_bytes(const scgg_denoiser3d* h, int32_t B, int32_t n) {
+  if (!h || B <= 0 || n <= 0) return 0;
+  return carve3(h->c, B, n, nullptr).bytes;
+}
+
+extern "C" int scgg_denoiser3d_forward(scgg_denoiser3d* h, const float* X, const float* E, const float* y, const float* pos,
+                                       const uint8_t* node_mask, int32_t B, int32_t n, float* out_X, float* out_E,
+                                       float* out_radius, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!out_E || (h && h->c.out_X > 0 && !out_X)) return fail("denoiser3d_forward: null output");
+  return run3(h, X, E, y, pos, node_mask, B, n, 0, false, out_X, out_E, out_radius, workspace, workspace_bytes,
+              static_cast<hipStream_t>(stream));
+}
+
+extern "C" int scgg_denoiser3d_forward_hidden(scgg_denoiser3d* h, const float* X, const float* E, const float* y, const float* pos,
+                                              const uint8_t* node_mask, int32_t B, int32_t n, int32_t n_run_layers, float* hid_X,
+                                              float* hid_E, float* hid_y, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!h) return fail("null handle");
+  if (n_run_layers < 0 || n_run_layers > h->c.n_layers) return fail("n_run_layers out of range");
+  return run3(h, X, E, y, pos, node_mask, B, n, n_run_layers, true, hid_X, hid_E, hid_y, workspace, workspace_bytes,
+              static_cast<hipStream_t>(stream));
+}

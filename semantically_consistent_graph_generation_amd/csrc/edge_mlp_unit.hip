@@ -166,7 +166,8 @@ __global__ __launch_bounds__(512) void edge_mlp_unit_kernel(EdgeMlpUnitArgs a) {
             const int c = 16 * ob + 4 * g + r;
             if (c < a.C) {
               float val = 0.f;
-              if (live) val = 0.5f * ((o[ob][r] + a.E_in[pij * a.dE_in + c]) + (o[ob][r] + a.E_in[pji * a.dE_in + c]));
+              if (live) val = a.E_in == nullptr ? o[ob][r]     // no residual (radius head, pos_transformer_model.py:470-487)
+                                                : 0.5f * ((o[ob][r] + a.E_in[pij * a.dE_in + c]) + (o[ob][r] + a.E_in[pji * a.dE_in + c]));
               dst[c] = val;
             }
           }
@@ -323,7 +324,8 @@ __global__ __launch_bounds__(512) void edge_mlp_unit_x3_kernel(EdgeMlpUnitArgs a
             const int c = 16 * ob + 4 * g + r;
             if (c < a.C) {
               float val = 0.f;
-              if (live) val = 0.5f * ((o[ob][r] + a.E_in[pij * a.dE_in + c]) + (o[ob][r] + a.E_in[pji * a.dE_in + c]));
+              if (live) val = a.E_in == nullptr ? o[ob][r]     // no residual (radius head, pos_transformer_model.py:470-487)
+                                                : 0.5f * ((o[ob][r] + a.E_in[pij * a.dE_in + c]) + (o[ob][r] + a.E_in[pji * a.dE_in + c]));
               dst[c] = val;
             }
           }

@@ -49,7 +49,7 @@ struct EdgeMlpPackArgs {  // raw (torch layout) two-layer MLP -> LDS image of ed
 
 struct EdgeMlpUnitArgs {  // mlp_in_E / mlp_out_E over the 16-key units
   const float* src;       // in: model input E [B,n,n,dE_in]; out: hidden E [B,n,n,de] (unsymmetrised)
-  const float* E_in;      // out only: model input E (residual uses channels [0,C))
+  const float* E_in;      // out only: model input E (residual uses channels [0,C)); null: no residual
   const uint8_t* mask;
   const f32x4_t* img;
   float* dst;             // in: hidden E [B,n,n,de]; out: logits [B,n,n,C] (zero-filled by the caller beforehand)
@@ -250,5 +250,63 @@ int launch_x_out_residual(const float* mlp, const float* X_in, int dX_in, const 
 
 // padded combinatorial Laplacian for any n (adjacency_tiled.hip); scgg_laplacian uses it beyond the 32-node LDS kernel
 int launch_laplacian_rows(const int8_t* labels, const uint8_t* mask, int B, int n, float* lap_out, hipStream_t st);
+
+// ---- position-aware block of Graph3DTransformer (block3d.hip) ---------------------------------------------
+struct Block3DPackArgs {  // raw (torch layout) weights of one 3D layer's edge path -> LDS image of block3d_edge_kernel
+  const float *W_in, *b_in, *W_dadd, *b_dadd, *W_dmul, *b_dmul, *W_eout, *b_eout;   // in_E, dist_add_e, dist_mul_e, e_out [de,de]
+  const float *W_ff1, *b_ff1, *W_ff2, *b_ff2;                                       // linE1 [ffE,de], linE2 [de,ffE]
+  const float *W_eatt, *b_eatt, *W_patt, *b_patt;                                   // e_att_mul, pos_att_mul [n_head,de]
+  const float* W_a;                                                                 // a [n_head,dx], no bias
+  const float *ln1g, *ln1b, *ln2g, *ln2b;                                           // normE1, normE2
+  const float *W_dist, *b_dist, *W_n1, *b_n1, *W_n2, *b_n2;                         // lin_dist1 [de,2], lin_norm_pos1/2 [de,1]
+  f32x4_t* img;
+  int n_head;
+};
+struct Block3DArgs {
+  const float* E_in;      // [B,n,n,de] unsymmetrised producer output
+  float* E_out;
+  const uint8_t* mask;
+  const float* nodelin;   // [B*n, ldn] masked rows: q | k | v | x_e_mul1 | x_e_mul2
+  int ldn;
+  const float* film;      // [B, ldf]: y_e_add | y_e_mul | y_x_add | y_x_mul
+  int ldf;
+  const float* pos4;      // [B*n, 4]: masked, re-centred positions of this layer and their norms
+  const f32x4_t* img;
+  float* attn_part;       // [B*n*nch][n_head*dx + 32]: sum p V per head | max (16) | sum p (16)
+  float* stat_part;       // [B*n*nch][8*de]: Y: mean | M2 | min | max, dist1: the same, over the unit's valid keys
+  const int* units;
+  const int* unit_count;
+  int B, n, n_head, need_attn;
+  float inv_sqrt_de;
+};
+struct RowMerge3DArgs {
+  const float* attn_part;
+  const float* stat_part;
+  const int* chunk_cnt;   // [B, nch] valid keys per chunk
+  const float* film;
+  int ldf;
+  float* wvcat;           // [B*n, n_head*dx]
+  float* rowstat;         // [B*n, 8*de]: EtoX inputs of E1 | of dist1  ([mean|min|max|var] each)
+  float* rowagg;          // [B*n, 8*de]: (mean, M2, min, max) of Y | of dist1 over the row's valid keys
+  const int* rows;
+  const int* row_count;
+  int n, n_head, dx, de;
+};
+struct GraphMerge3DArgs {
+  const float* rowagg;
+  const uint8_t* mask;
+  const float* newX;      // [B,n,dx], padded rows included
+  float* zcat;            // [B, ldz]: columns [dy, dy+4dx) Xtoy, [.., +4de) Etoy(Y), [.., +4de) Etoy(dist1)
+  int ldz, n, dx, de, dy;
+};
+long long block3d_img_f4(int dx, int de, int ffe);      // -1 if unsupported
+int launch_block3d_pack(const Block3DPackArgs& a, int dx, int de, int ffe, hipStream_t st);
+int launch_block3d_edge(const Block3DArgs& a, int dx, int de, int ffe, hipStream_t st);
+int launch_block3d_row_merge(const RowMerge3DArgs& a, int M, hipStream_t st);
+int launch_block3d_newx(const float* outv, const float* ex, const float* px, const float* film, int ldf, int film_off,
+                        float* newX, int M, int n, int dx, hipStream_t st);
+int launch_block3d_graph_merge(const GraphMerge3DArgs& a, int B, hipStream_t st);
+int launch_block3d_pos(const float* pos, const uint8_t* mask, int B, int n, int n_layers, float* pos4, hipStream_t st);
+int launch_block3d_chunk_count(const uint8_t* mask, int B, int n, int* cnt, hipStream_t st);
 
 }  // namespace scgg

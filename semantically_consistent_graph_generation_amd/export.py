@@ -7,9 +7,8 @@
   orientations of an undirected edge, as in the reference), cell arrays ``edge_type`` and, with ``use_radius``, ``radius``.
   Graphs without edges are skipped and do not consume an index (:287-289).  Byte-for-byte equality with pyvista's writer
   is not claimed (parity unpinned: pyvista is not in this image); the CPU tests parse the file back.
-* ``lightning_state_dict(ckpt)`` -- the ``model.`` prefix of a Lightning checkpoint of the reference
-  (``Discrete3dDenoisingDiffusion.model``, diffusion_model_discrete_3d.py:111-132) stripped, so that
-  ``GraphTransformer.load_state_dict`` takes it; other entries (metrics, noise tables, EMA copies) are dropped.
+The Lightning checkpoint key mapping (``model.`` prefix) is ``transformer_model.load_lightning_checkpoint``; it serves
+``GraphTransformer`` and the two position-aware classes of ``pos_transformer_model`` alike.
 """
 from __future__ import annotations
 
@@ -69,12 +68,3 @@ def save_graphs(samples, save_dir, use_radius=False):
             idx += 1
     return written
 
-
-def lightning_state_dict(ckpt, prefix="model."):
-    """``ckpt``: a state_dict or a Lightning checkpoint dict (``{"state_dict": ...}``), already loaded with a safe loader
-    (``torch.load(..., weights_only=True)``).  Returns the denoiser's own state_dict."""
-    sd = ckpt.get("state_dict", ckpt) if isinstance(ckpt, dict) else ckpt
-    out = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix) and isinstance(v, torch.Tensor)}
-    if not out:
-        raise KeyError(f"no '{prefix}*' tensors in the checkpoint")
-    return out

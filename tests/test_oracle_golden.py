@@ -275,3 +275,43 @@ def test_dropout_stream_is_a_pure_function_of_its_counter():
     a = TR.dropout_keep(7, 3, 4096, 0.3)
     assert np.array_equal(a, TR.dropout_keep(7, 3, 4096, 0.3)) and not np.array_equal(a, TR.dropout_keep(7, 4, 4096, 0.3))
     assert abs(a.mean() - 0.7) < 0.03 and np.array_equal(a[:100], TR.dropout_keep(7, 3, 100, 0.3))
+
+
+# ---- row f1: the position-aware denoiser (oracle/denoiser3d.py) against the reference's own outputs
+from oracle import denoiser3d as D3   # noqa: E402
+
+G3D_CASES = [("g3_g3d_tiny", fx.TINY_DIMS, False), ("g3_g3d_tiny_equivariant", fx.TINY_DIMS, True),
+             ("g3_g3d_vessel_cow", fx.VESSEL_DIMS, False), ("g3_g3d_vessel_n40", fx.VESSEL_DIMS, False),
+             ("g3_g3d_vessel_equivariant", fx.VESSEL_DIMS, True)]
+
+
+@pytest.mark.parametrize("py", [1, 0])
+def test_block3d(py):
+    g = load_golden(f"g1_block3d_y{py}")
+    nX, nE, ny = D3.node_edge_block_3d(golden_sd(g), "", int(g["n_head"]), T(g["X"]), T(g["E"]), T(g["y"]), T(g["pos"]),
+                                       T(g["node_mask"]), bool(py))
+    close(nX, g["newX"], 1e-5, 1e-5)
+    close(nE, g["newE"], 1e-5, 1e-5)
+    if py:
+        close(ny, g["new_y"], 1e-5, 3e-5)
+    else:
+        assert ny is None
+
+
+@pytest.mark.parametrize("name,dims,equivariant", G3D_CASES)
+def test_graph3d_transformer(name, dims, equivariant):
+    g = load_golden(name)
+    od = [int(v) for v in g["out_dims"]]
+    dd = D.DenoiserDims(int(g["n_layers"]), dims["hidden_dims"]["n_head"], od[0], od[1], od[2], od[3])
+    radius = g["out_radius"].size > 0
+    (oX, oc, oE, rad), hidden = D3.graph3d_transformer_forward(gt_state_dict(g), dd, T(g["X"]), T(g["E"]), T(g["y"]), T(g["pos"]),
+                                                               T(g["node_mask"]), with_radius=radius, equivariant=equivariant,
+                                                               return_hidden=True)
+    close(oX, g["outX"], 1e-4, 1e-5)
+    close(oc, g["out_charges"], 1e-4, 1e-5)
+    close(oE, g["outE"], 1e-4, 1e-5)
+    if radius:
+        close(rad, g["out_radius"], 1e-4, 1e-5)
+    # the positions handed back are the model's input through one mask() (:455, :492), not the layers' drifting copy
+    close(D3.recentre(T(g["pos"]), T(g["node_mask"])), g["out_pos"], 1e-5, 1e-6)
+    assert (hidden[-1][3] - hidden[0][3]).abs().max() > 1e-3      # ragged batch: the layers did see shifted positions
