@@ -32,6 +32,8 @@ class DiscreteSampler:
         self.extra_features = extra_features if extra_features is not None else DummyExtraFeatures()
         self.T = noise_model.T
         self.faster_sampling = faster_sampling
+        # position-aware denoisers (pos_transformer_model.py) also read z_t.pos and, for the radius head, z_t.radius
+        self.is3d = hasattr(model, "mlp_in_pos_high_dim")
 
     # ---------------------------------------------------------------------------------------- PlaceHolder route
     def forward(self, z_t):
@@ -40,7 +42,10 @@ class DiscreteSampler:
         X = torch.cat((z_t.X, z_t.charges, extra.X), dim=2).float()
         E = torch.cat((z_t.E, extra.E), dim=3).float()
         y = torch.hstack((z_t.y, extra.y, z_t.t)).float()
-        return self.model(model_input(X, E, y, z_t.node_mask))
+        inp = model_input(X, E, y, z_t.node_mask)
+        if self.is3d:
+            inp.pos, inp.radius = z_t.pos, z_t.radius
+        return self.model(inp)
 
     def sample_zs_from_zt(self, z_t, s_int, rng: Rng = None):
         """reference :745-751."""
@@ -80,7 +85,7 @@ class DiscreteSampler:
             # The eigen features feed only X and y (extra_features.py:41-60): Laplacian first, then the eigensolver on the
             # denoiser's second stream (ahead of its consumers of X / y: scgg_denoiser_side_stream) while the caller's
             # stream computes the rest of the structural features and the denoiser's edge input MLP.
-            if os.environ.get("SCGG_NO_SIDE_STREAM"):   # development A/B switch
+            if os.environ.get("SCGG_NO_SIDE_STREAM") or not hasattr(self.model, "side_stream"):   # A/B switch; 3D engine: one stream
                 _, _, _, lap = ef.adjacency_features(labels, node_mask, C_e, e_dst=st["E_in"], e_off=C_e, want_onehot=True,
                                                      x_dst=st["X_in"], x_off=1, y_dst=st["y_in"], y_off=1)
                 ef.eigen_features(lap, node_mask, evl_dst=st["y_in"], evl_off=1 + ky, evc_dst=st["X_in"], evc_off=4)
@@ -186,6 +191,12 @@ class DiscreteSampler:
         for s in s_values:
             labels_t = st["labels"][cur]
             inp = self._build_inputs(st, labels_t, node_mask, t)
+            if self.is3d:
+                # z_t.pos went through one mask() per completed step (noise_model.py:446 of the reference).  The radius the
+                # chain hands on is overwritten every step (:415-444) and never read by the model, so only the last step
+                # runs the radius head.
+                inp.pos = nm.pos_after_masks(pos_raw, node_mask, 1 + n_done)
+                inp.radius = st["E_in"][..., :1] if s == s_values[-1] else None
             pred = self.model(inp)
             rng = Rng(seed=seed, step=s, graph_id_base=graph_id_base)
             nm.reverse_step_state(pred.E, labels_t, node_mask, st["t_all"][t], st["t_all"][s], rng,
@@ -213,6 +224,10 @@ class DiscreteSampler:
                 chains.X[w], chains.E[w], chains.pos[w] = cX, cE, pos[:kc]
         labels = st["labels"][cur]
         pos = nm.pos_after_masks(pos_raw, node_mask, 1 + n_done)
+        radius = None
+        if self.is3d and s_values and getattr(pred, "radius", None) is not None:          # noise_model.py:415-420
+            radius = (labels > 0) * pred.radius.squeeze(-1)
+        self.last_radius = radius
         if return_state and chains is None:
             return labels, st["cands"][cur], node_mask, pos
         X, E = self._collapse_labels(labels, node_mask)
@@ -221,7 +236,7 @@ class DiscreteSampler:
         if return_state:
             return labels, st["cands"][cur], node_mask, pos, chains
         out = PlaceHolder(X=X, charges=torch.where(node_mask, 0, 1000), E=E, y=torch.zeros(B, 0, device=dev),
-                          node_mask=node_mask, pos=pos)
+                          node_mask=node_mask, pos=pos, radius=radius)           # radius as collapse() leaves it: [B,n,n]
         out.chains = chains
         return out
 

@@ -195,3 +195,57 @@ def test_vessel_batch_512_slice_and_invariants():
         D3.DIST_MODE = old
     assert rel_err(Eo[sl], oE) < REL
     assert rel_err(out.X.cpu()[sl], oX) < REL
+
+
+def test_chain_with_3d_denoiser_matches_cpu_oracle_bit_exactly():
+    """T = 12 absorbing-edge chain driven by Graph3DTransformer (tiny dims): labels and candidates of the device chain equal
+    a CPU chain built from the oracle forward (differences mode), the oracle reverse step and the same Philox stream; the
+    positions every step sees are the reference's drifting frame (noise_model.py:446 -> utils.py:160-164), and the radius
+    handed back is the last step's prediction on the sampled edges (noise_model.py:415-420)."""
+    from oracle import noise as N
+    from test_host_logic import make_noise_model
+    from semantically_consistent_graph_generation_amd.pos_transformer_model import Graph3DTransformer
+    from semantically_consistent_graph_generation_amd.sampling import DiscreteSampler
+    NU = dict(x=1, c=1, e=1, y=1, e_small=1, e_mid=1, e_large=1)
+    C, T, top_k, seed, base = 6, 12, 4, 77, 16
+    dims = fx.TINY_DIMS
+    model = Graph3DTransformer(2, fx.dims_ns(1, C, 1), dims["hidden_mlp_dims"], dims["hidden_dims"], fx.dims_ns(1, C, 0)).eval()
+    sd = fx.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=61)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    nm = make_noise_model("absorbing_edges", C, T=T, top_k=top_k)
+    sampler = DiscreteSampler(model, nm)
+    n_nodes = [9, 4, 7, 1]
+    labels, cands, mask, pos_end = sampler.sample_batch(n_nodes, seed=seed, graph_id_base=base, return_state=True)
+    radius = sampler.last_radius
+    torch.cuda.synchronize()
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    raw = nm.sample_limit_dist(mask, generator=gen, with_onehot=False)._pos_raw.cpu()
+    m = fx.ragged_mask(n_nodes)
+    B, n = m.shape
+    live = (m[:, :, None] & m[:, None, :]) & ~torch.eye(n, dtype=torch.bool)[None]
+    tr = N.Transition(N.Schedule(T, "absorbing_edges", NU), [1.0], np.ones(C, np.float32) / C)
+    dd = D.DenoiserDims(2, dims["hidden_dims"]["n_head"], 1, C, 0)
+    lab = torch.where(live, 0, -1)
+    X = m[..., None].float()
+    pos = D3.recentre(raw, m)
+    old = D3.DIST_MODE
+    D3.DIST_MODE = "direct"
+    try:
+        for s in reversed(range(T)):
+            t = s + 1
+            E = fx.one_hot_edges(lab.clamp(min=0), m, C)
+            y = torch.full((B, 1), t / T)
+            _, _, logits, rad = D3.graph3d_transformer_forward(sd, dd, X, E, y, pos, m)
+            u0, uk = N.philox_edge_uniforms(seed, s, base + np.arange(B), n, top_k)
+            r = N.reverse_step(tr, X, E, torch.zeros(B, n, 1), logits, m, torch.full((B, 1), t), torch.full((B, 1), s),
+                               np.zeros((B, n), np.float32), u0, uk)
+            lab = r["labels_E"]
+            pos = D3.recentre(pos, m)
+    finally:
+        D3.DIST_MODE = old
+    assert int((labels.cpu().long() != lab).sum()) == 0
+    assert int(((cands.cpu().long() * live[..., None]) != r["extra_info"]).sum()) == 0
+    assert int((lab > 0).sum()) > 0
+    assert rel_err(pos_end, pos) < 1e-5
+    assert rel_err(radius, (lab > 0) * rad.squeeze(-1)) < REL
