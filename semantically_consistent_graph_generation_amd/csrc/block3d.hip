@@ -314,7 +314,8 @@ __global__ __launch_bounds__(NW * 64) void block3d_edge_kernel(Block3DArgs a) {
       const long long vbase = (long long)b * n;
       const float* vrow[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) vrow[r] = a.nodelin + (vbase + min(jc * 16 + 4 * g + r, n - 1)) * a.ldn + 2 * DX + p;
+      for (int r = 0; r < 4; ++r)      // masked keys carry p = 0: point them at the query row, whose V is always written
+        vrow[r] = a.nodelin + (vbase + (((keymask >> (4 * g + r)) & 1u) ? jc * 16 + 4 * g + r : i)) * a.ldn + 2 * DX + p;
 #pragma unroll
       for (int db = 0; db < DXB; ++db) {
         f32x4 acc = splat4(0.f);
@@ -434,19 +435,24 @@ __global__ __launch_bounds__(256) void block3d_row_merge_kernel(RowMerge3DArgs a
   }
 }
 
-// newX = wV (y_x_mul + 1) + y_x_add with wV = out(.) FiLMed by the two EtoX vectors (:180-192).  Padded rows: out, ex, px
-// are zero there (row-masked products), so newX = y_x_add, as in the reference.
+// newX = wV (y_x_mul + 1) + y_x_add with wV = out(.) FiLMed by the two EtoX vectors (:180-192).  Padded rows: wV is masked
+// to zero there (:180), so newX = y_x_add, as in the reference; out / ex / px are not read on them (the row-list Linears
+// leave those rows unwritten).
 __global__ __launch_bounds__(256) void block3d_newx_kernel(const float* __restrict__ outv, const float* __restrict__ ex,
-                                                           const float* __restrict__ px, const float* __restrict__ film, int ldf,
-                                                           int film_off, float* __restrict__ newX, long long total, int n, int dx) {
+                                                           const float* __restrict__ px, const uint8_t* __restrict__ mask,
+                                                           const float* __restrict__ film, int ldf, int film_off,
+                                                           float* __restrict__ newX, long long total, int n, int dx) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int c = (int)(idx % dx);
   const long long row = idx / dx;
   const float* fl = film + (row / n) * ldf + film_off;
-  float w = outv[idx];
-  w = w + ex[idx] * w;
-  w = w + px[idx] * w;
+  float w = 0.f;
+  if (mask[row]) {
+    w = outv[idx];
+    w = w + ex[idx] * w;
+    w = w + px[idx] * w;
+  }
   newX[idx] = w * (fl[dx + c] + 1.0f) + fl[c];
 }
 
@@ -496,7 +502,7 @@ __global__ __launch_bounds__(256) void block3d_graph_merge_kernel(GraphMerge3DAr
         mx = fmaxf(mx, ag[3 * DE]);
         N = nn;
       }
-    float* zz = z + 4 * DX + which * 4 * DE + ch;
+    float* zz = a.etoy + (long long)b * (8 * DE) + which * 4 * DE + ch;
     zz[0] = mean; zz[DE] = mn; zz[2 * DE] = mx; zz[3 * DE] = m2 / N;
   }
 }
@@ -604,12 +610,12 @@ int launch_block3d_row_merge(const RowMerge3DArgs& a, int M, hipStream_t st) {
   return 0;
 }
 
-int launch_block3d_newx(const float* outv, const float* ex, const float* px, const float* film, int ldf, int film_off,
-                        float* newX, int M, int n, int dx, hipStream_t st) {
+int launch_block3d_newx(const float* outv, const float* ex, const float* px, const uint8_t* mask, const float* film, int ldf,
+                        int film_off, float* newX, int M, int n, int dx, hipStream_t st) {
   const long long total = (long long)M * dx;
   if (total <= 0) return 0;
-  hipLaunchKernelGGL(block3d_newx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, outv, ex, px, film, ldf,
-                     film_off, newX, total, n, dx);
+  hipLaunchKernelGGL(block3d_newx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, outv, ex, px, mask, film,
+                     ldf, film_off, newX, total, n, dx);
   return 0;
 }
 

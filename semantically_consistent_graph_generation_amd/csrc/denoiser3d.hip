@@ -34,12 +34,20 @@ struct Bump {   // two-pass bump allocator (base == nullptr: measuring pass)
   }
 };
 
+struct RowLin {                  // row-list Linear on the bf16x3 scheme (node_layer.hip), null W3: generic GEMM instead
+  f32x4_t* W3 = nullptr;
+  float* b = nullptr;            // padded to a multiple of 32
+  int N = 0, K = 0;
+};
+
 struct Layer3 {
   bool predicts_y = true;
   f32x4_t* img = nullptr;        // block3d_edge_kernel's LDS image
   float *Wnl, *bnl;              // [3dx+2de, dx]: q | k | v | x_e_mul1 | x_e_mul2
   float *Wfilm, *bfilm;          // [2de+2dx, dy]: y_e_add | y_e_mul | y_x_add | y_x_mul
   float *Wycat, *bycat;          // [dy, dy+4dx+8de]: y_y | x_y.lin | e_y.lin | dist_y.lin, summed biases
+  float *Wt_cat, *Wt_o0, *Wt_o2, *Wt_l1, *Wt_l2, *Wt_film;   // transposed copies for y_layer_kernel ([K][N])
+  RowLin nl, out, ex, px, x_out, linX1, linX2;
 };
 
 __global__ void vec_sum4_kernel(const float* a, const float* b, const float* c, const float* d, float* out, int n) {
@@ -87,6 +95,33 @@ int put3(scgg_denoiser3d* h, const std::string& name, int N, int K, float* dst, 
   return 0;
 }
 
+// three-term bf16 image + padded bias of W[N,K] for the row-list Linear (K = 128 / 256 / 512 only)
+int pack_rowlin(Bump& ar, bool fill, const float* W, const float* b, int N, int K, RowLin& out, hipStream_t st) {
+  out = RowLin();
+  if (K != 128 && K != 256 && K != 512) return 0;
+  const int NB = (N + 31) / 32;
+  out.N = N;
+  out.K = K;
+  out.W3 = ar.take<f32x4_t>((size_t)NB * (K / 16) * 192);
+  out.b = ar.take<float>((size_t)NB * 32);
+  if (!fill) return 0;
+  if (!W || !b) return -1;
+  PackArgs p3{W, out.W3, N, K, NB, K / 32};
+  launch_pack_linear_x3(p3, st);
+  launch_pad_vec(b, out.b, N, NB * 32, 0.f, st);
+  return 0;
+}
+int pack_rowlin_named(scgg_denoiser3d* h, Bump& ar, bool fill, const std::string& name, int N, int K, RowLin& out, hipStream_t st) {
+  const float *W = nullptr, *b = nullptr;
+  if (fill && (K == 128 || K == 256 || K == 512)) {
+    const Param3 *w = find3(h, name + ".weight", (int64_t)N * K), *bb = find3(h, name + ".bias", N);
+    if (!w || !bb) return -1;
+    W = w->p;
+    b = bb->p;
+  }
+  return pack_rowlin(ar, fill, W, b, N, K, out, st);
+}
+
 int build3(scgg_denoiser3d* h, bool fill, hipStream_t st) {
   const scgg_denoiser3d_config& c = h->c;
   Bump ar(fill ? h->arena : nullptr);
@@ -128,6 +163,19 @@ int build3(scgg_denoiser3d* h, bool fill, hipStream_t st) {
     L.bfilm = ar.take<float>((size_t)FL);
     L.Wycat = ar.take<float>((size_t)dy * kcat);
     L.bycat = ar.take<float>((size_t)dy);
+    L.Wt_cat = ar.take<float>((size_t)dy * kcat);
+    L.Wt_o0 = ar.take<float>((size_t)dy * dy);
+    L.Wt_o2 = ar.take<float>((size_t)dy * dy);
+    L.Wt_l1 = ar.take<float>((size_t)dy * c.dim_ffy);
+    L.Wt_l2 = ar.take<float>((size_t)dy * c.dim_ffy);
+    L.Wt_film = ar.take<float>((size_t)FL * dy);
+    if (pack_rowlin(ar, false, nullptr, nullptr, NL, dx, L.nl, st)) return -1;      // filled after the concatenation below
+    if (pack_rowlin_named(h, ar, fill, sa + "out", dx, H * dx, L.out, st)) return -1;
+    if (pack_rowlin_named(h, ar, fill, sa + "e_x_mul.lin", dx, 4 * de, L.ex, st)) return -1;
+    if (pack_rowlin_named(h, ar, fill, sa + "pos_x_mul.lin", dx, 4 * de, L.px, st)) return -1;
+    if (pack_rowlin_named(h, ar, fill, sa + "x_out", dx, dx, L.x_out, st)) return -1;
+    if (pack_rowlin_named(h, ar, fill, p + "linX1", c.dim_ffX, dx, L.linX1, st)) return -1;
+    if (pack_rowlin_named(h, ar, fill, p + "linX2", dx, c.dim_ffX, L.linX2, st)) return -1;
     if (!fill) continue;
     {
       auto W = [&](const std::string& nm, int64_t numel) { const Param3* q = find3(h, nm, numel); return q ? q->p : nullptr; };
@@ -163,6 +211,11 @@ int build3(scgg_denoiser3d* h, bool fill, hipStream_t st) {
       if (put3(h, sa + nl[t] + ".bias", 1, N, L.bnl + r0, N, 0, st)) return -1;
       r0 += N;
     }
+    if (L.nl.W3 != nullptr) {
+      PackArgs p3{L.Wnl, L.nl.W3, NL, dx, (NL + 31) / 32, dx / 32};
+      launch_pack_linear_x3(p3, st);
+      launch_pad_vec(L.bnl, L.nl.b, NL, (NL + 31) / 32 * 32, 0.f, st);
+    }
     const char* fl[4] = {"y_e_add", "y_e_mul", "y_x_add", "y_x_mul"};
     r0 = 0;
     for (int t = 0; t < 4; ++t) {
@@ -180,7 +233,16 @@ int build3(scgg_denoiser3d* h, bool fill, hipStream_t st) {
                    *b2 = find3(h, sa + "e_y.lin.bias", dy), *b3 = find3(h, sa + "dist_y.lin.bias", dy);
       if (!b0 || !b1 || !b2 || !b3) return -1;
       hipLaunchKernelGGL(vec_sum4_kernel, dim3((dy + 255) / 256), dim3(256), 0, st, b0->p, b1->p, b2->p, b3->p, L.bycat, dy);
+      const Param3 *o0 = find3(h, sa + "y_out.0.weight", (int64_t)dy * dy), *o2 = find3(h, sa + "y_out.2.weight", (int64_t)dy * dy),
+                   *l1 = find3(h, p + "lin_y1.weight", (int64_t)c.dim_ffy * dy), *l2 = find3(h, p + "lin_y2.weight", (int64_t)dy * c.dim_ffy);
+      if (!o0 || !o2 || !l1 || !l2) return -1;
+      launch_transpose(L.Wycat, L.Wt_cat, dy, kcat, st);
+      launch_transpose(o0->p, L.Wt_o0, dy, dy, st);
+      launch_transpose(o2->p, L.Wt_o2, dy, dy, st);
+      launch_transpose(l1->p, L.Wt_l1, c.dim_ffy, dy, st);
+      launch_transpose(l2->p, L.Wt_l2, dy, c.dim_ffy, st);
     }
+    launch_transpose(L.Wfilm, L.Wt_film, FL, dy, st);
     if (check3("3D weight concatenation")) return -1;
   }
   h->arena_bytes = align_up3(ar.off, 256);
@@ -189,7 +251,7 @@ int build3(scgg_denoiser3d* h, bool fill, hipStream_t st) {
 
 struct Work3 {
   float *X, *X1, *nodelin, *film, *pos4, *E0, *E1, *attn, *stat, *wvcat, *rowstat, *rowagg, *t_out, *t_ex, *t_px, *newX, *t_ff,
-      *y, *y1, *zcat, *yt1, *yt2, *hidX, *hidy, *xo;
+      *y, *y1, *zcat, *etoy, *yt1, *yt2, *hidX, *hidy, *xo;
   int *rows, *row_count, *units, *unit_count, *goff, *chunk_cnt;
   size_t bytes;
 };
@@ -203,7 +265,7 @@ Work3 carve3(const scgg_denoiser3d_config& c, int B, int n, char* base) {
   w.X = ar.take<float>(M * dx);
   w.X1 = ar.take<float>(M * dx);
   w.nodelin = ar.take<float>(M * (3 * dx + 2 * de));
-  w.film = ar.take<float>((size_t)B * (2 * de + 2 * dx));
+  w.film = ar.take<float>((size_t)2 * B * (2 * de + 2 * dx));     // double-buffered: layer l+1's vectors are written while layer l's are read
   w.pos4 = ar.take<float>((size_t)c.n_layers * M * 4);
   w.E0 = ar.take<float>(P * de);
   w.E1 = ar.take<float>(P * de);
@@ -223,6 +285,7 @@ Work3 carve3(const scgg_denoiser3d_config& c, int B, int n, char* base) {
   w.y = ar.take<float>((size_t)B * dy);
   w.y1 = ar.take<float>((size_t)B * dy);
   w.zcat = ar.take<float>((size_t)B * (dy + 4 * dx + 8 * de));
+  w.etoy = ar.take<float>((size_t)B * 8 * de);
   w.yt1 = ar.take<float>((size_t)B * ywide);
   w.yt2 = ar.take<float>((size_t)B * ywide);
   w.hidy = ar.take<float>((size_t)B * ywide);
@@ -248,14 +311,6 @@ int gemm3_raw(const float* A, int lda, const float* W, const float* bias, float*
   GemmArgs g{A, W, bias, C, rowmask, M, N, K, lda, K, ldc, flags, 0, 0, 0, 0};
   return launch_gemm(g, st);
 }
-int ln3(scgg_denoiser3d* h, const float* x, const float* r, const std::string& name, const uint8_t* rowmask, float* out, int M, int D,
-        hipStream_t st) {
-  const Param3 *g = find3(h, name + ".weight", D), *b = find3(h, name + ".bias", D);
-  if (!g || !b) return -1;
-  AddLnArgs a{x, r, g->p, b->p, rowmask, out, M, D, nullptr, nullptr};
-  return launch_add_layernorm(a, st);
-}
-
 // sym + mask copy of an unsymmetrised hidden E into a caller buffer (debug tap)
 __global__ void sym_copy3_kernel(const float* E, const uint8_t* mask, float* out, int B, int n, int de) {
   const long long idx = blockIdx.x * 256ll + threadIdx.x;
@@ -311,44 +366,88 @@ int run3(scgg_denoiser3d* h, const float* X, const float* E, const float* y, con
   }
   float *Ecur = w.E0, *Enext = w.E1;
   const int L_run = tap ? n_run_layers : c.n_layers;
+  // row-list Linear on the valid rows (bf16x3 scheme) where the shape is packed, else the generic GEMM over all rows
+  auto rowlin = [&](const RowLin& pk, const float* Wraw, const float* braw, const float* A, int lda, float* C, int ldc, int N, int K,
+                    bool relu) -> int {
+    if (pk.W3 != nullptr) {
+      NodeLinearArgs a{A, nullptr, pk.b, C, w.rows, w.row_count, N, K, (N + 31) / 32, lda, ldc, 1, relu ? 1 : 0};
+      const int rc = launch_node_linear_x3(a, pk.W3, M, st);
+      if (rc == 0) return 0;
+      if (rc != -1) return fail("row-list Linear launch failed (N=%d K=%d)", N, K);
+    }
+    return gemm3_raw(A, lda, Wraw, braw, C, ldc, M, N, K, (relu ? GEMM_RELU : 0) | GEMM_ROWMASK, mask, st);
+  };
+  auto rowlin_named = [&](const RowLin& pk, const std::string& name, const float* A, int lda, float* C, int ldc, int N, int K,
+                          bool relu) -> int {
+    const Param3 *W = find3(h, name + ".weight", (int64_t)N * K), *b = find3(h, name + ".bias", N);
+    if (!W || !b) return -1;
+    return rowlin(pk, W->p, b->p, A, lda, C, ldc, N, K, relu);
+  };
+  auto ln_rows = [&](const float* x, const float* r, const std::string& name, float* out) -> int {
+    const Param3 *g = find3(h, name + ".weight", dx), *b = find3(h, name + ".bias", dx);
+    if (!g || !b) return -1;
+    AddLnArgs a{x, r, g->p, b->p, mask, out, M, dx, w.rows, w.row_count};
+    return launch_add_layernorm(a, st);
+  };
+  auto y_round = [&](int l, bool update, float* film_dst) -> int {   // y(l) -> y(l+1) (update) and the FiLM vectors of `film_of`
+    const int film_of = update ? l + 1 : l;
+    YLayerArgs ya{};
+    ya.y = w.y; ya.ycat = w.zcat; ya.etoy = w.etoy; ya.B = B; ya.dy = dy; ya.ffy = c.dim_ffy; ya.kcat = kcat; ya.dx = dx;
+    ya.update = update ? 1 : 0;
+    ya.film_n = FL;
+    if (update) {
+      const Layer3& L = h->layers[l];
+      const std::string p = "tf_layers." + std::to_string(l) + ".", sa = p + "self_attn.";
+      const Param3 *bo0 = find3(h, sa + "y_out.0.bias", dy), *bo2 = find3(h, sa + "y_out.2.bias", dy),
+                   *g1 = find3(h, p + "norm_y1.weight", dy), *b1 = find3(h, p + "norm_y1.bias", dy),
+                   *bl1 = find3(h, p + "lin_y1.bias", c.dim_ffy), *bl2 = find3(h, p + "lin_y2.bias", dy),
+                   *g2 = find3(h, p + "norm_y2.weight", dy), *b2 = find3(h, p + "norm_y2.bias", dy);
+      if (!bo0 || !bo2 || !g1 || !b1 || !bl1 || !bl2 || !g2 || !b2) return -1;
+      ya.Wt_cat = L.Wt_cat; ya.b_cat = L.bycat; ya.Wt_o0 = L.Wt_o0; ya.b_o0 = bo0->p; ya.Wt_o2 = L.Wt_o2; ya.b_o2 = bo2->p;
+      ya.ln1_g = g1->p; ya.ln1_b = b1->p; ya.Wt_l1 = L.Wt_l1; ya.b_l1 = bl1->p; ya.Wt_l2 = L.Wt_l2; ya.b_l2 = bl2->p;
+      ya.ln2_g = g2->p; ya.ln2_b = b2->p;
+    }
+    if (film_of < c.n_layers) {
+      ya.Wt_film = h->layers[film_of].Wt_film;
+      ya.b_film = h->layers[film_of].bfilm;
+      ya.film = film_dst;
+    }
+    if (launch_y_layer(ya, st)) return fail("y kernel: unsupported dims dy=%d dim_ffy=%d", dy, c.dim_ffy);
+    return 0;
+  };
+  float* film_buf[2] = {w.film, w.film + (size_t)B * FL};
+  if (L_run > 0) TRY(y_round(0, false, film_buf[0]));
   for (int l = 0; l < L_run; ++l) {
     const Layer3& L = h->layers[l];
     const std::string p = "tf_layers." + std::to_string(l) + ".", sa = p + "self_attn.";
     const bool need_x = l != c.n_layers - 1 || eq || tap;      // the last layer's X feeds nothing in Graph3DTransformer
-    TRY(gemm3_raw(w.X, dx, L.Wnl, L.bnl, w.nodelin, NL, M, NL, dx, GEMM_ROWMASK, mask, st));
-    TRY(gemm3_raw(w.y, dy, L.Wfilm, L.bfilm, w.film, FL, B, FL, dy, 0, nullptr, st));
+    const float* film = film_buf[l & 1];
+    TRY(rowlin(L.nl, L.Wnl, L.bnl, w.X, dx, w.nodelin, NL, NL, dx, false));
     {
       Block3DArgs a;
-      a.E_in = Ecur; a.E_out = Enext; a.mask = mask; a.nodelin = w.nodelin; a.ldn = NL; a.film = w.film; a.ldf = FL;
+      a.E_in = Ecur; a.E_out = Enext; a.mask = mask; a.nodelin = w.nodelin; a.ldn = NL; a.film = film; a.ldf = FL;
       a.pos4 = w.pos4 + (size_t)l * M * 4; a.img = L.img; a.attn_part = w.attn; a.stat_part = w.stat;
       a.units = w.units; a.unit_count = w.unit_count; a.B = B; a.n = n; a.n_head = H; a.need_attn = need_x ? 1 : 0;
       a.inv_sqrt_de = 1.0f / sqrtf((float)de);
       if (launch_block3d_edge(a, dx, de, c.dim_ffE, st)) return fail("3D edge kernel: unsupported dims");
     }
     if (need_x) {
-      RowMerge3DArgs r{w.attn, w.stat, w.chunk_cnt, w.film, FL, w.wvcat, w.rowstat, w.rowagg, w.rows, w.row_count, n, H, dx, de};
+      RowMerge3DArgs r{w.attn, w.stat, w.chunk_cnt, film, FL, w.wvcat, w.rowstat, w.rowagg, w.rows, w.row_count, n, H, dx, de};
       TRY(launch_block3d_row_merge(r, M, st));
-      TRY(gemm3(h, w.wvcat, H * dx, sa + "out", w.t_out, dx, M, dx, H * dx, GEMM_ROWMASK, mask, st));
-      TRY(gemm3(h, w.rowstat, 8 * de, sa + "e_x_mul.lin", w.t_ex, dx, M, dx, 4 * de, GEMM_ROWMASK, mask, st));
-      TRY(gemm3(h, w.rowstat + 4 * de, 8 * de, sa + "pos_x_mul.lin", w.t_px, dx, M, dx, 4 * de, GEMM_ROWMASK, mask, st));
-      TRY(launch_block3d_newx(w.t_out, w.t_ex, w.t_px, w.film, FL, 2 * de, w.newX, M, n, dx, st));
-      if (L.predicts_y) {
-        GraphMerge3DArgs g{w.rowagg, mask, w.newX, w.zcat, kcat, n, dx, de, dy};
+      TRY(rowlin_named(L.out, sa + "out", w.wvcat, H * dx, w.t_out, dx, dx, H * dx, false));
+      TRY(rowlin_named(L.ex, sa + "e_x_mul.lin", w.rowstat, 8 * de, w.t_ex, dx, dx, 4 * de, false));
+      TRY(rowlin_named(L.px, sa + "pos_x_mul.lin", w.rowstat + 4 * de, 8 * de, w.t_px, dx, dx, 4 * de, false));
+      TRY(launch_block3d_newx(w.t_out, w.t_ex, w.t_px, mask, film, FL, 2 * de, w.newX, M, n, dx, st));
+      if (L.predicts_y) {   // y(l+1) and the FiLM vectors of layer l+1 (into the other buffer: film(l) is still being read)
+        GraphMerge3DArgs g{w.rowagg, mask, w.newX, w.zcat, w.etoy, kcat, n, dx, de, dy};
         TRY(launch_block3d_graph_merge(g, B, st));
-        TRY(launch_copy_cols(w.y, dy, w.zcat, kcat, B, dy, st));
-        TRY(gemm3_raw(w.zcat, kcat, L.Wycat, L.bycat, w.yt1, dy, B, dy, kcat, 0, nullptr, st));
-        TRY(gemm3(h, w.yt1, dy, sa + "y_out.0", w.yt2, dy, B, dy, dy, GEMM_RELU, nullptr, st));
-        TRY(gemm3(h, w.yt2, dy, sa + "y_out.2", w.yt1, dy, B, dy, dy, 0, nullptr, st));
-        TRY(ln3(h, w.y, w.yt1, p + "norm_y1", nullptr, w.y1, B, dy, st));
-        TRY(gemm3(h, w.y1, dy, p + "lin_y1", w.hidy, c.dim_ffy, B, c.dim_ffy, dy, GEMM_RELU, nullptr, st));
-        TRY(gemm3(h, w.hidy, c.dim_ffy, p + "lin_y2", w.yt2, dy, B, dy, c.dim_ffy, 0, nullptr, st));
+        TRY(y_round(l, true, film_buf[(l + 1) & 1]));
       }
-      TRY(gemm3(h, w.newX, dx, sa + "x_out", w.t_out, dx, M, dx, dx, GEMM_ROWMASK, mask, st));
-      TRY(ln3(h, w.X, w.t_out, p + "normX1", nullptr, w.X1, M, dx, st));
-      TRY(gemm3(h, w.X1, dx, p + "linX1", w.t_ff, c.dim_ffX, M, c.dim_ffX, dx, GEMM_RELU, nullptr, st));
-      TRY(gemm3(h, w.t_ff, c.dim_ffX, p + "linX2", w.t_out, dx, M, dx, c.dim_ffX, 0, nullptr, st));
-      TRY(ln3(h, w.X1, w.t_out, p + "normX2", mask, w.X, M, dx, st));
-      if (L.predicts_y) TRY(ln3(h, w.y1, w.yt2, p + "norm_y2", nullptr, w.y, B, dy, st));   // after film(l) and Xtoy were taken
+      TRY(rowlin_named(L.x_out, sa + "x_out", w.newX, dx, w.t_out, dx, dx, dx, false));
+      TRY(ln_rows(w.X, w.t_out, p + "normX1", w.X1));
+      TRY(rowlin_named(L.linX1, p + "linX1", w.X1, dx, w.t_ff, c.dim_ffX, c.dim_ffX, dx, true));
+      TRY(rowlin_named(L.linX2, p + "linX2", w.t_ff, c.dim_ffX, w.t_out, dx, dx, c.dim_ffX, false));
+      TRY(ln_rows(w.X1, w.t_out, p + "normX2", w.X));
     }
     float* t = Ecur; Ecur = Enext; Enext = t;
   }
@@ -398,6 +497,9 @@ extern "C" scgg_denoiser3d* scgg_denoiser3d_create(const scgg_denoiser3d_config*
     return nullptr;
   }
   if (c.dy % 4 != 0 || c.dx % 4 != 0) { fail("dx, dy must be multiples of 4"); return nullptr; }
+  if (!y_layer_supported(c.dy, c.dim_ffy, c.dy + 4 * c.dx + 8 * c.de)) {
+    fail("y kernel has no build for dy=%d dim_ffy=%d", c.dy, c.dim_ffy); return nullptr;
+  }
   scgg_denoiser3d* h = new scgg_denoiser3d();
   h->c = c;
   return h;

@@ -207,6 +207,7 @@ struct YLayerArgs {       // fused global-feature part of one layer (y_layer.hip
   float* film;            // [B,4dx] destination of the FiLM vectors
   int B, dy, ffy, kcat, dx;
   int update;             // 0: only the FiLM vectors of the current y
+  int film_n;             // 0: 4 dx FiLM outputs with +1 on the "mul" quarters (2D block); > 0: film_n raw outputs
 };
 
 bool y_layer_supported(int dy, int ffy, int kcat);
@@ -296,15 +297,16 @@ struct GraphMerge3DArgs {
   const float* rowagg;
   const uint8_t* mask;
   const float* newX;      // [B,n,dx], padded rows included
-  float* zcat;            // [B, ldz]: columns [dy, dy+4dx) Xtoy, [.., +4de) Etoy(Y), [.., +4de) Etoy(dist1)
+  float* zcat;            // [B, ldz]: columns [dy, dy+4dx) <- Xtoy inputs
+  float* etoy;            // [B, 8de]: Etoy inputs of Y | of dist1
   int ldz, n, dx, de, dy;
 };
 long long block3d_img_f4(int dx, int de, int ffe);      // -1 if unsupported
 int launch_block3d_pack(const Block3DPackArgs& a, int dx, int de, int ffe, hipStream_t st);
 int launch_block3d_edge(const Block3DArgs& a, int dx, int de, int ffe, hipStream_t st);
 int launch_block3d_row_merge(const RowMerge3DArgs& a, int M, hipStream_t st);
-int launch_block3d_newx(const float* outv, const float* ex, const float* px, const float* film, int ldf, int film_off,
-                        float* newX, int M, int n, int dx, hipStream_t st);
+int launch_block3d_newx(const float* outv, const float* ex, const float* px, const uint8_t* mask, const float* film, int ldf,
+                        int film_off, float* newX, int M, int n, int dx, hipStream_t st);
 int launch_block3d_graph_merge(const GraphMerge3DArgs& a, int B, hipStream_t st);
 int launch_block3d_pos(const float* pos, const uint8_t* mask, int B, int n, int n_layers, float* pos4, hipStream_t st);
 int launch_block3d_chunk_count(const uint8_t* mask, int B, int n, int* cnt, hipStream_t st);

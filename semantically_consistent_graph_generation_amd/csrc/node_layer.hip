@@ -527,8 +527,8 @@ __global__ __launch_bounds__(512) void node_linear_x3_kernel(NodeLinearArgs a, c
   for (int t = 0; t < RPW; ++t) {
     const int ridx = tile * TR + wave * RPW + t;
     const long long row = a.rows[ridx < count ? ridx : count - 1];
-    const int c = lane * 4;
-    if (c < K) put_split4<KS, PLANE>(S, wave * RPW + t, c, *reinterpret_cast<const f32x4*>(a.A + row * a.lda + c));
+    for (int c = lane * 4; c < K; c += 256)
+      put_split4<KS, PLANE>(S, wave * RPW + t, c, *reinterpret_cast<const f32x4*>(a.A + row * a.lda + c));
   }
   long long qrow[NRG];
   bool qok[NRG];
@@ -601,9 +601,10 @@ bool node_layer_x3_enabled() { return node_x3(); }
 
 bool node_layer_supported(int dx, int ffx) { return (dx == 256 && ffx == 256) || (dx == 128 && ffx == 128); }
 
-// row-list Linear through the x3 kernel when the shape allows (K = 128 or 256, N a multiple of 4, padded bias), else -1
+// row-list Linear through the x3 kernel when the shape allows (K = 128, 256 or 512, N a multiple of 4, padded bias), else -1
 int launch_node_linear_x3(const NodeLinearArgs& a, const f32x4_t* W3, int M, hipStream_t st) {
   if (!node_x3() || W3 == nullptr || a.lda % 4 != 0 || a.ldc % 4 != 0 || a.N % 4 != 0) return -1;
+  if (a.K == 512) return launch_linear_x3<16>(a, W3, M, st);
   if (a.K == 256) return launch_linear_x3<8>(a, W3, M, st);
   if (a.K == 128) return launch_linear_x3<4>(a, W3, M, st);
   return -1;

@@ -179,20 +179,23 @@ __global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
     }
   }
   if (a.Wt_film != nullptr) {
-    // FiLM vectors for the next edge / node kernels, +1 folded into the two "mul" quarters
-    const int N4 = a.dx;                                         // 4 dx outputs = dx float4
+    // FiLM vectors for the next edge / node kernels.  film_n == 0: the 2D block's four dx-wide vectors with +1 folded into
+    // the two "mul" quarters; film_n > 0: film_n raw outputs (the position-aware block: y_e_add | y_e_mul | y_x_add | y_x_mul
+    // of widths de, de, dx, dx; its kernels add the 1 themselves)
+    const int FN = a.film_n > 0 ? a.film_n : 4 * a.dx;
+    const int N4 = FN >> 2;
     const yf4* w4 = reinterpret_cast<const yf4*>(a.Wt_film);
     for (int o4 = tid; o4 < N4; o4 += YT) {
       yf4 acc[YG];
       yf4 bv = *reinterpret_cast<const yf4*>(a.b_film + 4 * o4);
       const int quarter = (4 * o4) / a.dx;
-      if (quarter == 1 || quarter == 3) bv += 1.0f;
+      if (a.film_n == 0 && (quarter == 1 || quarter == 3)) bv += 1.0f;
 #pragma unroll
       for (int g = 0; g < YG; ++g) acc[g] = bv;
       y_dot(acc, w4, N4, o4, yv, ldy, 0, dy);
 #pragma unroll
       for (int g = 0; g < YG; ++g)
-        if (b0 + g < a.B) *reinterpret_cast<yf4*>(a.film + (size_t)(b0 + g) * 4 * a.dx + 4 * o4) = acc[g];
+        if (b0 + g < a.B) *reinterpret_cast<yf4*>(a.film + (size_t)(b0 + g) * FN + 4 * o4) = acc[g];
     }
   }
 }
