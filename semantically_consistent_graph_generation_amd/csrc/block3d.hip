@@ -582,9 +582,8 @@ int launch_block3d_pack(const Block3DPackArgs& a, int dx, int de, int ffe, hipSt
   return -1;
 }
 
-template <int DEB, int FFB, int DXB>
-static int launch_b3d(const Block3DArgs& a, hipStream_t st) {
-  constexpr int NW = 8;
+template <int DEB, int FFB, int DXB, int NW>
+static int launch_b3d_nw(const Block3DArgs& a, hipStream_t st) {
   const int n_cu = device_cu_count();
   if (n_cu <= 0) return -2;
   static LdsAttrOnce attr;
@@ -593,6 +592,18 @@ static int launch_b3d(const Block3DArgs& a, hipStream_t st) {
   if (set_max_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds)) return -2;
   hipLaunchKernelGGL(kern, dim3(n_cu), dim3(NW * 64), lds, st, a);
   return 0;
+}
+// waves per workgroup (= per CU: the LDS image leaves room for one workgroup).  SCGG_B3D_NW = 8 / 12 / 16 for A/B runs.
+template <int DEB, int FFB, int DXB>
+static int launch_b3d(const Block3DArgs& a, hipStream_t st) {
+  static int nw = 0;
+  if (nw == 0) {
+    const char* e = getenv("SCGG_B3D_NW");
+    nw = e ? atoi(e) : 12;   // 12: 3 % faster than 8 at B = 512 vessel dims (168 VGPRs, 15 spilled), 16 spills 57 and is 5 % slower
+  }
+  if (nw == 16) return launch_b3d_nw<DEB, FFB, DXB, 16>(a, st);
+  if (nw == 12) return launch_b3d_nw<DEB, FFB, DXB, 12>(a, st);
+  return launch_b3d_nw<DEB, FFB, DXB, 8>(a, st);
 }
 
 int launch_block3d_edge(const Block3DArgs& a, int dx, int de, int ffe, hipStream_t st) {

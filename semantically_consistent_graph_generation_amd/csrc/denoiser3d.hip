@@ -67,6 +67,7 @@ struct scgg_denoiser3d {
   char* arena = nullptr;
   size_t arena_bytes = 0;
   f32x4_t *in_E_img = nullptr, *out_E_img = nullptr, *rad_img = nullptr;
+  RowLin in_X2, pos2, out_X1;      // mlp_in_X.3, mlp_in_pos_high_dim.3, mlp_out_X.0
   std::vector<Layer3> layers;
 };
 
@@ -148,6 +149,9 @@ int build3(scgg_denoiser3d* h, bool fill, hipStream_t st) {
         return fail("edge MLP pack: unsupported dims in_E=%d hid_E=%d de=%d out_E=%d", c.in_E, c.hid_E, de, c.out_E);
     }
   }
+  if (pack_rowlin_named(h, ar, fill, "mlp_in_X.3", dx, c.hid_X, h->in_X2, st)) return -1;
+  if (pack_rowlin_named(h, ar, fill, "mlp_in_pos_high_dim.3", dx, c.hid_X, h->pos2, st)) return -1;
+  if (pack_rowlin_named(h, ar, fill, "mlp_out_X.0", c.hid_X, dx, h->out_X1, st)) return -1;
   h->layers.resize(c.n_layers);
   const int NL = 3 * dx + 2 * de, FL = 2 * de + 2 * dx, kcat = dy + 4 * dx + 8 * de;
   for (int l = 0; l < c.n_layers; ++l) {
@@ -350,22 +354,6 @@ int run3(scgg_denoiser3d* h, const float* X, const float* E, const float* y, con
   }
   TRY(gemm3(h, y, c.in_y, "mlp_in_y.0", w.hidy, c.hid_y, B, c.hid_y, c.in_y, GEMM_RELU, nullptr, st));
   TRY(gemm3(h, w.hidy, c.hid_y, "mlp_in_y.3", w.y, dy, B, dy, c.hid_y, GEMM_RELU, nullptr, st));
-  if (eq) {
-    TRY(gemm3(h, X, c.in_X, "mlp_in_X.0", w.hidX, c.hid_X, M, c.hid_X, c.in_X, GEMM_RELU, nullptr, st));
-    TRY(gemm3(h, w.hidX, c.hid_X, "mlp_in_X.3", w.X, dx, M, dx, c.hid_X, GEMM_RELU | GEMM_ROWMASK, mask, st));
-  } else {
-    TRY(gemm3(h, pos, 3, "mlp_in_pos_high_dim.0", w.hidX, c.hid_X, M, c.hid_X, 3, GEMM_RELU, nullptr, st));
-    TRY(gemm3(h, w.hidX, c.hid_X, "mlp_in_pos_high_dim.3", w.X, dx, M, dx, c.hid_X, GEMM_RELU | GEMM_ROWMASK, mask, st));
-    if (!tap && c.out_X > 0) {   // :467: the node head never sees the layers
-      TRY(gemm3(h, X, c.in_X, "mlp_in_X.0", w.hidX, c.hid_X, M, c.hid_X, c.in_X, GEMM_RELU, nullptr, st));
-      TRY(gemm3(h, w.hidX, c.hid_X, "mlp_in_X.3", w.t_ff, dx, M, dx, c.hid_X, GEMM_RELU, nullptr, st));
-      TRY(gemm3(h, w.t_ff, dx, "mlp_out_X.0", w.hidX, c.hid_X, M, c.hid_X, dx, GEMM_RELU, nullptr, st));
-      TRY(gemm3(h, w.hidX, c.hid_X, "mlp_out_X.3", w.xo, c.out_X, M, c.out_X, c.hid_X, 0, nullptr, st));
-      TRY(launch_x_out_residual(w.xo, X, c.in_X, mask, o1, M, c.out_X, st));
-    }
-  }
-  float *Ecur = w.E0, *Enext = w.E1;
-  const int L_run = tap ? n_run_layers : c.n_layers;
   // row-list Linear on the valid rows (bf16x3 scheme) where the shape is packed, else the generic GEMM over all rows
   auto rowlin = [&](const RowLin& pk, const float* Wraw, const float* braw, const float* A, int lda, float* C, int ldc, int N, int K,
                     bool relu) -> int {
@@ -389,6 +377,42 @@ int run3(scgg_denoiser3d* h, const float* X, const float* E, const float* y, con
     AddLnArgs a{x, r, g->p, b->p, mask, out, M, dx, w.rows, w.row_count};
     return launch_add_layernorm(a, st);
   };
+  // first Linear of a node MLP: K <= 64 inputs per row (raw node features / coordinates), valid rows only when possible
+  auto first_lin = [&](const std::string& name, const float* A, int K, float* C, int N) -> int {
+    const Param3 *W = find3(h, name + ".weight", (int64_t)N * K), *b = find3(h, name + ".bias", N);
+    if (!W || !b) return -1;
+    if (K <= 64 && N % 4 == 0) {
+      NarrowLinearArgs na{A, W->p, b->p, C, w.rows, w.row_count, N, K, K, N, 1};
+      if (launch_narrow_linear(na, M, st) == 0) return 0;
+    }
+    return gemm3_raw(A, K, W->p, b->p, C, N, M, N, K, GEMM_RELU, nullptr, st);
+  };
+  auto x_head = [&](const float* hidden_X) -> int {     // mlp_out_X on `hidden_X` + residual to the input, masked (:467-472, :492)
+    TRY(rowlin_named(h->out_X1, "mlp_out_X.0", hidden_X, dx, w.hidX, c.hid_X, c.hid_X, dx, true));
+    const Param3 *w3 = find3(h, "mlp_out_X.3.weight", (int64_t)c.out_X * c.hid_X), *b3 = find3(h, "mlp_out_X.3.bias", c.out_X);
+    if (!w3 || !b3) return -1;
+    if (c.out_X <= 16 && c.hid_X % 4 == 0) {
+      if (hipMemsetAsync(o1, 0, (size_t)M * c.out_X * sizeof(float), st) != hipSuccess) return fail("memset failed");
+      if (launch_row_head(w.hidX, c.hid_X, w3->p, b3->p, X, c.in_X, w.rows, w.row_count, o1, M, c.out_X, c.hid_X, st) == 0) return 0;
+    }
+    TRY(gemm3_raw(w.hidX, c.hid_X, w3->p, b3->p, w.xo, c.out_X, M, c.out_X, c.hid_X, 0, nullptr, st));
+    return launch_x_out_residual(w.xo, X, c.in_X, mask, o1, M, c.out_X, st);
+  };
+  if (hipMemsetAsync(w.X, 0, (size_t)M * dx * sizeof(float), st) != hipSuccess) return fail("memset failed");   // padded rows stay zero
+  if (eq) {
+    TRY(first_lin("mlp_in_X.0", X, c.in_X, w.hidX, c.hid_X));
+    TRY(rowlin_named(h->in_X2, "mlp_in_X.3", w.hidX, c.hid_X, w.X, dx, dx, c.hid_X, true));
+  } else {
+    TRY(first_lin("mlp_in_pos_high_dim.0", pos, 3, w.hidX, c.hid_X));
+    TRY(rowlin_named(h->pos2, "mlp_in_pos_high_dim.3", w.hidX, c.hid_X, w.X, dx, dx, c.hid_X, true));
+    if (!tap && c.out_X > 0) {   // :467: the node head never sees the layers
+      TRY(first_lin("mlp_in_X.0", X, c.in_X, w.hidX, c.hid_X));
+      TRY(rowlin_named(h->in_X2, "mlp_in_X.3", w.hidX, c.hid_X, w.t_ff, dx, dx, c.hid_X, true));
+      TRY(x_head(w.t_ff));
+    }
+  }
+  float *Ecur = w.E0, *Enext = w.E1;
+  const int L_run = tap ? n_run_layers : c.n_layers;
   auto y_round = [&](int l, bool update, float* film_dst) -> int {   // y(l) -> y(l+1) (update) and the FiLM vectors of `film_of`
     const int film_of = update ? l + 1 : l;
     YLayerArgs ya{};
@@ -460,11 +484,7 @@ int run3(scgg_denoiser3d* h, const float* X, const float* E, const float* y, con
     if (o3) (void)hipMemcpyAsync(o3, w.y, (size_t)B * dy * 4, hipMemcpyDeviceToDevice, st);
     return check3("denoiser3d tap");
   }
-  if (eq && c.out_X > 0) {
-    TRY(gemm3(h, w.X, dx, "mlp_out_X.0", w.hidX, c.hid_X, M, c.hid_X, dx, GEMM_RELU, nullptr, st));
-    TRY(gemm3(h, w.hidX, c.hid_X, "mlp_out_X.3", w.xo, c.out_X, M, c.out_X, c.hid_X, 0, nullptr, st));
-    TRY(launch_x_out_residual(w.xo, X, c.in_X, mask, o1, M, c.out_X, st));
-  }
+  if (eq && c.out_X > 0) TRY(x_head(w.X));
   // ---- edge heads (:468-487): logits with the residual to the input classes, radius without one
   if (hipMemsetAsync(o2, 0, (size_t)M * n * c.out_E * 4, st) != hipSuccess) return fail("memset failed");
   {

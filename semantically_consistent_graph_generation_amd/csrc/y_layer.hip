@@ -211,12 +211,14 @@ bool y_layer_supported(int dy, int ffy, int kcat) {
 int launch_y_layer(const YLayerArgs& a, hipStream_t st) {
   if (!y_layer_supported(a.dy, a.ffy, a.kcat)) return -1;
   const size_t lds = y_layer_lds(a.dy, a.ffy, a.kcat);
-  static size_t attr_lds = 0;
-  if (lds > attr_lds) {
+  static size_t attr_lds[MAX_DEVICES] = {};   // per device: the largest size asked for so far (engines of different widths share the kernel)
+  const int dev = current_device();
+  if (dev < 0) return -2;
+  if (lds > attr_lds[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(y_layer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return -2;
-    attr_lds = lds;
+    attr_lds[dev] = lds;
   }
   hipLaunchKernelGGL(y_layer_kernel, dim3((a.B + YG - 1) / YG), dim3(YT), lds, st, a);
   return 0;
