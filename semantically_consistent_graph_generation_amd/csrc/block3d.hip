@@ -23,9 +23,12 @@
 // (mean, M2, min, max) of Y and of dist1 over the unit's valid keys (exact two-pass inside the unit, Chan merge later).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "mfma_chain.h"
 #include "c16.h"
 #include "kernels.h"
+#include "x3_mfma.h"
 
 namespace scgg {
 
@@ -48,6 +51,150 @@ struct Geom3D {
   static constexpr int IMG_F4 = VEC + (V_FLOATS + 3) / 4;
   static_assert(DEB % 2 == 0 && FFB % 4 == 0, "de: multiple of 32, dim_ffE: multiple of 64");
 };
+
+
+// ---- default form: the same layer as TWO kernels on the bf16 matrix pipe with fp32 accuracy (x3_mfma.h).  As three bf16
+// terms the layer's weights are 1.5 x their fp32 size and no longer fit LDS together, but the block part (in_E,
+// dist_add_e | dist_mul_e, e_out: 96 KB, plus the fp32 attention heads) and the FFN part (linE1, linE2: 96 KB) each do:
+//   block3d_edge_kernel<.., X3 = true>   everything up to E'' = x + newE (stored), attention and statistics partials
+//   block3d_ffn_kernel                   E_out = LN2(E' + linE2 relu linE1 E'), E' = LN1(E''), in place on the stored tile
+// Both keep their weights resident (no phases, no barriers in the unit loop); the price is one extra write + read of the
+// tile (512 B per pair), which a compute-bound kernel hides.  Weight blocks: (16 output rows, 32-channel K chunk) x three
+// terms x 64 lanes x 16 B (192 float4 slots), ordered as the pipelines walk them.
+template <int DEB, int DXB>
+struct Geom3DA {
+  static constexpr int DE = 16 * DEB, DX = 16 * DXB, Q = DEB / 2;
+  static constexpr int NBLK = DEB * Q;                            // blocks of a de x de matrix
+  static constexpr int W_IN = 0;                                  // (ob, q)
+  static constexpr int W_DIST = NBLK * 192;                       // (ob, {dist_add_e, dist_mul_e}, q)
+  static constexpr int W_EOUT = 3 * NBLK * 192;                   // (ob, q)
+  static constexpr int W_EATT = 4 * NBLK * 192;                   // fp32 fragments from here on, as in Geom3D
+  static constexpr int W_PATT = W_EATT + DEB * 64;
+  static constexpr int W_A = W_PATT + DEB * 64;
+  static constexpr int VEC = W_A + DXB * 64;
+  enum { B_IN = 0, B_DADD, B_DMUL, B_EOUT, WD0, WD1, BD, WN1, WN2, NVEC_DE };
+  static constexpr int V_EATT = NVEC_DE * DE;
+  static constexpr int V_PATT = V_EATT + 16;
+  static constexpr int V_FLOATS = V_PATT + 16;
+  static constexpr int IMG_F4 = VEC + (V_FLOATS + 3) / 4;
+};
+template <int DEB, int FFB>
+struct Geom3DF {
+  static constexpr int DE = 16 * DEB, FFE = 16 * FFB, Q1 = DEB / 2, Q2 = FFB / 2;
+  static constexpr int W_1 = 0;                                   // linE1 (hidden block, q)
+  static constexpr int W_2 = FFB * Q1 * 192;                      // linE2 (hidden chunk q2, output block): a chunk is split once
+  static constexpr int VEC = W_2 + DEB * Q2 * 192;
+  enum { B_FF2 = 0, LN1G, LN1B, LN2G, LN2B, NVEC_DE };
+  static constexpr int V_FF1 = NVEC_DE * DE;
+  static constexpr int V_FLOATS = V_FF1 + FFE;
+  static constexpr int IMG_F4 = VEC + (V_FLOATS + 3) / 4;
+  static_assert((FFB * Q1) % 2 == 0 && (DEB * Q2) % 2 == 0, "even block counts");
+};
+
+// one 16-byte slot of a three-term bf16 weight block: rows 16 ob + (l & 15), channels 32 q + {4g..4g+3, 16+4g..16+4g+3}
+__device__ __forceinline__ f32x4 x3_slot(const float* W, int N, int K, int ob, int q, int term, int l) {
+  const int g = l >> 4, row = 16 * ob + (l & 15);
+  unsigned hw[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int col = 32 * q + (i < 4 ? 4 * g + i : 16 + 4 * g + i - 4);
+    float x = (row < N && col < K) ? W[(size_t)row * K + col] : 0.f;
+    for (int k = 0; k < term; ++k) x = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+    hw[i] = __float_as_uint(x) >> 16;
+  }
+  f32x4 out;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) out[d] = __uint_as_float(hw[2 * d] | (hw[2 * d + 1] << 16));
+  return out;
+}
+
+template <int DEB, int FFB, int DXB>
+__global__ __launch_bounds__(256) void block3d_pack_x3_kernel(Block3DPackArgs a) {
+  using GA = Geom3DA<DEB, DXB>;
+  using GF = Geom3DF<DEB, FFB>;
+  constexpr int DE = GA::DE, DX = GA::DX, FFE = GF::FFE, Q = GA::Q;
+  for (int idx0 = blockIdx.x * 256 + threadIdx.x; idx0 < GA::IMG_F4 + GF::IMG_F4; idx0 += gridDim.x * 256) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (idx0 < GA::IMG_F4) {
+      const int idx = idx0;
+      if (idx < GA::W_EATT) {
+        const int blk = idx / 192, term = (idx % 192) >> 6, l = idx & 63;
+        if (blk < GA::NBLK) v = x3_slot(a.W_in, DE, DE, blk / Q, blk % Q, term, l);
+        else if (blk < 3 * GA::NBLK) {
+          const int t = blk - GA::NBLK;
+          v = x3_slot(((t / Q) & 1) ? a.W_dmul : a.W_dadd, DE, DE, t / (2 * Q), t % Q, term, l);
+        } else {
+          const int t = blk - 3 * GA::NBLK;
+          v = x3_slot(a.W_eout, DE, DE, t / Q, t % Q, term, l);
+        }
+      } else if (idx < GA::VEC) {
+        const float* W;
+        int K, KBLK, off;
+        if (idx < GA::W_PATT) { W = a.W_eatt; K = DE; KBLK = DEB; off = GA::W_EATT; }
+        else if (idx < GA::W_A) { W = a.W_patt; K = DE; KBLK = DEB; off = GA::W_PATT; }
+        else { W = a.W_a; K = DX; KBLK = DXB; off = GA::W_A; }
+        const int t = (idx - off) >> 6, l = idx & 63, ib = t % KBLK, row = l & 15;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int col = 16 * ib + 4 * (l >> 4) + e;
+          if (row < a.n_head && col < K) v[e] = W[(size_t)row * K + col];
+        }
+      } else {
+        const int f0 = (idx - GA::VEC) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int f = f0 + e;
+          float x = 0.f;
+          if (f < GA::V_EATT) {
+            const int which = f / DE, c = f - which * DE;
+            switch (which) {
+              case GA::B_IN: x = a.b_in[c]; break;
+              case GA::B_DADD: x = a.b_dadd[c]; break;
+              case GA::B_DMUL: x = a.b_dmul[c]; break;
+              case GA::B_EOUT: x = a.b_eout[c]; break;
+              case GA::WD0: x = a.W_dist[2 * c]; break;
+              case GA::WD1: x = a.W_dist[2 * c + 1]; break;
+              case GA::BD: x = (a.b_dist[c] + a.b_n1[c]) + a.b_n2[c]; break;
+              case GA::WN1: x = a.W_n1[c]; break;
+              case GA::WN2: x = a.W_n2[c]; break;
+            }
+          } else if (f < GA::V_PATT) x = (f - GA::V_EATT) < a.n_head ? a.b_eatt[f - GA::V_EATT] : 0.f;
+          else if (f < GA::V_FLOATS) x = (f - GA::V_PATT) < a.n_head ? a.b_patt[f - GA::V_PATT] : 0.f;
+          v[e] = x;
+        }
+      }
+    } else {
+      const int idx = idx0 - GA::IMG_F4;
+      if (idx < GF::VEC) {
+        const int blk = idx / 192, term = (idx % 192) >> 6, l = idx & 63;
+        if (blk < FFB * GF::Q1) v = x3_slot(a.W_ff1, FFE, DE, blk / GF::Q1, blk % GF::Q1, term, l);
+        else {
+          const int t = blk - FFB * GF::Q1;
+          v = x3_slot(a.W_ff2, DE, FFE, t % DEB, t / DEB, term, l);
+        }
+      } else {
+        const int f0 = (idx - GF::VEC) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int f = f0 + e;
+          float x = 0.f;
+          if (f < GF::V_FF1) {
+            const int which = f / DE, c = f - which * DE;
+            switch (which) {
+              case GF::B_FF2: x = a.b_ff2[c]; break;
+              case GF::LN1G: x = a.ln1g[c]; break;
+              case GF::LN1B: x = a.ln1b[c]; break;
+              case GF::LN2G: x = a.ln2g[c]; break;
+              case GF::LN2B: x = a.ln2b[c]; break;
+            }
+          } else if (f < GF::V_FLOATS) x = a.b_ff1[f - GF::V_FF1];
+          v[e] = x;
+        }
+      }
+    }
+    a.img[idx0] = v;
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // LDS image.  Fragment (ob, ib) of W[N][K], lane l: W[16 ob + (l & 15)][16 ib + 4 (l >> 4) + 0..3], zero outside.
@@ -112,7 +259,15 @@ __global__ __launch_bounds__(256) void block3d_pack_kernel(Block3DPackArgs a) {
   }
 }
 
-__device__ __forceinline__ float row_min16(float v) { return -row_max16(-v); }
+#define SCGG_DPP_MIN_STEP(v, ctrl_text) \
+  asm("s_nop 1\n\tv_min_f32_dpp %0, %1, %1 " ctrl_text " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(v) : "v"(v))
+__device__ __forceinline__ float row_min16_fused(float v) {   // as row_max16_fused (c16.h): one v_min_f32_dpp per step
+  SCGG_DPP_MIN_STEP(v, "quad_perm:[1,0,3,2]");
+  SCGG_DPP_MIN_STEP(v, "quad_perm:[2,3,0,1]");
+  SCGG_DPP_MIN_STEP(v, "row_half_mirror");
+  SCGG_DPP_MIN_STEP(v, "row_mirror");
+  return v;
+}
 __device__ __forceinline__ float groups_max(float v) {          // across the four lane rows (same lane & 15)
   v = swap_rows16_max(v);
   auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -128,10 +283,11 @@ __device__ __forceinline__ void mfma4x2d(f32x4& acc0, f32x4& acc1, const f32x4& 
   }
 }
 
-template <int DEB, int FFB, int DXB, int NW>
+template <int DEB, int FFB, int DXB, int NW, bool X3>
 __global__ __launch_bounds__(NW * 64) void block3d_edge_kernel(Block3DArgs a) {
-  using G = Geom3D<DEB, FFB, DXB>;
+  using G = typename std::conditional<X3, Geom3DA<DEB, DXB>, Geom3D<DEB, FFB, DXB>>::type;
   constexpr int DE = G::DE, DX = G::DX;
+  constexpr int Q = DEB / 2;                                           // 32-channel K chunks of the E width (x3 form)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* img = reinterpret_cast<f32x4*>(smem);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, g = lane >> 4;
@@ -185,30 +341,64 @@ __global__ __launch_bounds__(NW * 64) void block3d_edge_kernel(Block3DArgs a) {
     }
     // ---- Y = in_E(x) . x_e_mul1_j . x_e_mul2_i, then the distance FiLM
     f32x4 Y[DEB];
+    Frag3 fa, fb;
+    if constexpr (X3) {
+      load_frag3(fa, img + Geom3DA<DEB, DXB>::W_IN, lane);
+      u32x4 xh[Q], xm[Q], xl[Q];
 #pragma unroll
-    for (int ob = 0; ob < DEB; ob += 2) {
-      f32x4 a0 = ld4(vec + G::B_IN * DE + 16 * ob + 4 * g), a1 = ld4(vec + G::B_IN * DE + 16 * (ob + 1) + 4 * g);
+      for (int q = 0; q < Q; ++q) split3(x[2 * q], x[2 * q + 1], xh[q], xm[q], xl[q]);
 #pragma unroll
-      for (int ib = 0; ib < DEB; ++ib)
-        mfma4x2(a0, a1, img[G::W_IN + (ob * DEB + ib) * 64 + lane], img[G::W_IN + ((ob + 1) * DEB + ib) * 64 + lane], x[ib]);
-      const f32x4 m10 = ld4(nl_j + 3 * DX + 16 * ob + 4 * g), m11 = ld4(nl_j + 3 * DX + 16 * (ob + 1) + 4 * g);
-      const f32x4 m20 = ld4(nl_i + 3 * DX + DE + 16 * ob + 4 * g), m21 = ld4(nl_i + 3 * DX + DE + 16 * (ob + 1) + 4 * g);
+      for (int ob = 0; ob < DEB; ++ob) Y[ob] = ld4(vec + G::B_IN * DE + 16 * ob + 4 * g);
+      block_pipeline<DEB * Q, 0>(img + Geom3DA<DEB, DXB>::W_IN, img + Geom3DA<DEB, DXB>::W_DIST, fa, fb, lane,
+                                 [&](int t, const Frag3& w) { mfma_x3(Y[t / Q], w, xh[t % Q], xm[t % Q], xl[t % Q]); });
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        Y[ob][r] = vj ? a0[r] * m10[r] * m20[r] : 0.f;
-        Y[ob + 1][r] = vj ? a1[r] * m11[r] * m21[r] : 0.f;
+      for (int ob = 0; ob < DEB; ++ob) {
+        const f32x4 m1 = ld4(nl_j + 3 * DX + 16 * ob + 4 * g), m2 = ld4(nl_i + 3 * DX + DE + 16 * ob + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Y[ob][r] = vj ? Y[ob][r] * m1[r] * m2[r] : 0.f;
       }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+      u32x4 dh[Q], dm3[Q], dl[Q];
 #pragma unroll
-    for (int ob = 0; ob < DEB; ++ob) {
-      f32x4 da = ld4(vec + G::B_DADD * DE + 16 * ob + 4 * g), dm = ld4(vec + G::B_DMUL * DE + 16 * ob + 4 * g);
+      for (int q = 0; q < Q; ++q) split3(d1[2 * q], d1[2 * q + 1], dh[q], dm3[q], dl[q]);
+      f32x4 acc2[2];
+      block_pipeline<2 * DEB * Q, 0>(img + Geom3DA<DEB, DXB>::W_DIST, img + Geom3DA<DEB, DXB>::W_EOUT, fa, fb, lane,
+                                     [&](int t, const Frag3& w) {
+        const int ob = t / (2 * Q), m = (t / Q) & 1, q = t % Q;
+        if (q == 0) acc2[m] = ld4(vec + (m ? G::B_DMUL : G::B_DADD) * DE + 16 * ob + 4 * g);
+        mfma_x3(acc2[m], w, dh[q], dm3[q], dl[q]);
+        if (m == 1 && q == Q - 1) {
 #pragma unroll
-      for (int ib = 0; ib < DEB; ++ib)
-        mfma4x2(da, dm, img[G::W_DADD + (ob * DEB + ib) * 64 + lane], img[G::W_DMUL + (ob * DEB + ib) * 64 + lane], d1[ib]);
+          for (int r = 0; r < 4; ++r) Y[ob][r] = vj ? (Y[ob][r] + acc2[0][r]) + Y[ob][r] * acc2[1][r] : 0.f;
+        }
+      });
+    } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Y[ob][r] = vj ? (Y[ob][r] + da[r]) + Y[ob][r] * dm[r] : 0.f;
-      __builtin_amdgcn_sched_barrier(0);
+      for (int ob = 0; ob < DEB; ob += 2) {
+        f32x4 a0 = ld4(vec + G::B_IN * DE + 16 * ob + 4 * g), a1 = ld4(vec + G::B_IN * DE + 16 * (ob + 1) + 4 * g);
+#pragma unroll
+        for (int ib = 0; ib < DEB; ++ib)
+          mfma4x2(a0, a1, img[Geom3D<DEB, FFB, DXB>::W_IN + (ob * DEB + ib) * 64 + lane],
+                  img[Geom3D<DEB, FFB, DXB>::W_IN + ((ob + 1) * DEB + ib) * 64 + lane], x[ib]);
+        const f32x4 m10 = ld4(nl_j + 3 * DX + 16 * ob + 4 * g), m11 = ld4(nl_j + 3 * DX + 16 * (ob + 1) + 4 * g);
+        const f32x4 m20 = ld4(nl_i + 3 * DX + DE + 16 * ob + 4 * g), m21 = ld4(nl_i + 3 * DX + DE + 16 * (ob + 1) + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          Y[ob][r] = vj ? a0[r] * m10[r] * m20[r] : 0.f;
+          Y[ob + 1][r] = vj ? a1[r] * m11[r] * m21[r] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int ob = 0; ob < DEB; ++ob) {
+        f32x4 da = ld4(vec + G::B_DADD * DE + 16 * ob + 4 * g), dm = ld4(vec + G::B_DMUL * DE + 16 * ob + 4 * g);
+#pragma unroll
+        for (int ib = 0; ib < DEB; ++ib)
+          mfma4x2(da, dm, img[Geom3D<DEB, FFB, DXB>::W_DADD + (ob * DEB + ib) * 64 + lane],
+                  img[Geom3D<DEB, FFB, DXB>::W_DMUL + (ob * DEB + ib) * 64 + lane], d1[ib]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Y[ob][r] = vj ? (Y[ob][r] + da[r]) + Y[ob][r] * dm[r] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     // ---- pooled statistics of Y and dist1 over this unit's valid keys
     if (a.need_attn) {
@@ -234,8 +424,8 @@ __global__ __launch_bounds__(NW * 64) void block3d_edge_kernel(Block3DArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             m2[r] = q[r];
-            mn[r] = row_min16(vj ? val[r] : INFINITY);
-            mx[r] = row_max16(vj ? val[r] : -INFINITY);
+            mn[r] = row_min16_fused(vj ? val[r] : INFINITY);
+            mx[r] = row_max16_fused(vj ? val[r] : -INFINITY);
           }
           if (p == 0) {
             float* d = sp + t * 4 * DE + 16 * ob + 4 * g;
@@ -258,18 +448,38 @@ __global__ __launch_bounds__(NW * 64) void block3d_edge_kernel(Block3DArgs a) {
       }
     }
     f32x4 nE[DEB];
+    if constexpr (X3) {
+      u32x4 eh[Q], em[Q], el[Q];
 #pragma unroll
-    for (int ob = 0; ob < DEB; ob += 2) {
-      f32x4 a0 = ld4(vec + G::B_EOUT * DE + 16 * ob + 4 * g), a1 = ld4(vec + G::B_EOUT * DE + 16 * (ob + 1) + 4 * g);
+      for (int q = 0; q < Q; ++q) split3(Y[2 * q], Y[2 * q + 1], eh[q], em[q], el[q]);
+      // accumulators start at bias + x: the sum leaves as E'' = x + newE.  x is read again here (an L2 hit) rather than
+      // held in 16 registers across the distance pipeline and the statistics
 #pragma unroll
-      for (int ib = 0; ib < DEB; ++ib)
-        mfma4x2(a0, a1, img[G::W_EOUT + (ob * DEB + ib) * 64 + lane], img[G::W_EOUT + ((ob + 1) * DEB + ib) * 64 + lane], Y[ib]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        nE[ob][r] = vj ? a0[r] : 0.f;
-        nE[ob + 1][r] = vj ? a1[r] : 0.f;
+      for (int ob = 0; ob < DEB; ++ob) {
+        nE[ob] = ld4(vec + G::B_EOUT * DE + 16 * ob + 4 * g);
+        if (offd) nE[ob] += 0.5f * (ld4(a.E_in + pij + 16 * ob + 4 * g) + ld4(a.E_in + pji + 16 * ob + 4 * g));
       }
-      __builtin_amdgcn_sched_barrier(0);
+      block_pipeline<DEB * Q, 0>(img + Geom3DA<DEB, DXB>::W_EOUT, nullptr, fa, fb, lane,
+                                 [&](int t, const Frag3& w) { mfma_x3(nE[t / Q], w, eh[t % Q], em[t % Q], el[t % Q]); });
+#pragma unroll
+      for (int ob = 0; ob < DEB; ++ob)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nE[ob][r] = vj ? nE[ob][r] : 0.f;
+    } else {
+#pragma unroll
+      for (int ob = 0; ob < DEB; ob += 2) {
+        f32x4 a0 = ld4(vec + G::B_EOUT * DE + 16 * ob + 4 * g), a1 = ld4(vec + G::B_EOUT * DE + 16 * (ob + 1) + 4 * g);
+#pragma unroll
+        for (int ib = 0; ib < DEB; ++ib)
+          mfma4x2(a0, a1, img[Geom3D<DEB, FFB, DXB>::W_EOUT + (ob * DEB + ib) * 64 + lane],
+                  img[Geom3D<DEB, FFB, DXB>::W_EOUT + ((ob + 1) * DEB + ib) * 64 + lane], Y[ib]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          nE[ob][r] = vj ? a0[r] : 0.f;
+          nE[ob + 1][r] = vj ? a1[r] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     // ---- attention, transposed: lane (head p, key group g) register r <-> key 4 g + r
     if (a.need_attn) {
@@ -311,18 +521,33 @@ __global__ __launch_bounds__(NW * 64) void block3d_edge_kernel(Block3DArgs a) {
       }
       const float S = groups_sum(sl);
       float* ap = a.attn_part + (long long)u * AP;
+      // weighted V: out[h][d] = sum_key p[key][h] V[key][d].  A = p^T (the registers as they are: lane (head, key group),
+      // register r = key 4g + r), B = V with the channel on the lane: lane n reads the float4 V[key][64 c + 4n .. 4n+3] and
+      // element e goes to MFMA (c, e), whose column n is therefore channel 64 c + 4n + e -- coalesced 256-byte reads per
+      // key, and the four results of a lane are again one float4 of the output row of head 4 g' + r'.
       const long long vbase = (long long)b * n;
       const float* vrow[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r)      // masked keys carry p = 0: point them at the query row, whose V is always written
-        vrow[r] = a.nodelin + (vbase + (((keymask >> (4 * g + r)) & 1u) ? jc * 16 + 4 * g + r : i)) * a.ldn + 2 * DX + p;
+        vrow[r] = a.nodelin + (vbase + (((keymask >> (4 * g + r)) & 1u) ? jc * 16 + 4 * g + r : i)) * a.ldn + 2 * DX + 4 * p;
 #pragma unroll
-      for (int db = 0; db < DXB; ++db) {
-        f32x4 acc = splat4(0.f);
+      for (int c = 0; c < (DX + 63) / 64; ++c) {
+        const bool on = 64 * c + 4 * p < DX;
+        f32x4 vq[4], acc[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)                                       // A = V^T (channel on the row), B = p
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[r][16 * db], pe[r], acc, 0, 0, 0);
-        if (p < a.n_head) *reinterpret_cast<f32x4*>(ap + p * DX + 16 * db + 4 * g) = acc;
+        for (int r = 0; r < 4; ++r) vq[r] = on ? ld4(vrow[r] + 64 * c) : splat4(0.f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = splat4(0.f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(pe[r], vq[r][e], acc[e], 0, 0, 0);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          if (on && 4 * g + rr < a.n_head) {
+            const f32x4 o = {acc[0][rr], acc[1][rr], acc[2][rr], acc[3][rr]};
+            *reinterpret_cast<f32x4*>(ap + (4 * g + rr) * DX + 64 * c + 4 * p) = o;
+          }
         __builtin_amdgcn_sched_barrier(0);
       }
       if (g == 0 && p < a.n_head) {
@@ -330,46 +555,114 @@ __global__ __launch_bounds__(NW * 64) void block3d_edge_kernel(Block3DArgs a) {
         ap[a.n_head * DX + 16 + p] = S;
       }
     }
-    // ---- E' = LN1(x + newE); E_out = LN2(E' + linE2 relu linE1 E')
+    // ---- x3 form: E'' = x + newE (already summed in nE) goes to memory, block3d_ffn_kernel finishes the layer in place
 #pragma unroll
-    for (int ib = 0; ib < DEB; ++ib) x[ib] += nE[ib];
-    layernorm_c16<DEB>(x, vec + G::LN1G * DE, vec + G::LN1B * DE, g);
-    f32x4 o2[DEB];
+    for (int ib = 0; ib < DEB; ++ib) x[ib] = X3 ? nE[ib] : x[ib] + nE[ib];
+    if constexpr (!X3) {
+      using GG = Geom3D<DEB, FFB, DXB>;
+      // ---- E' = LN1(x + newE); E_out = LN2(E' + linE2 relu linE1 E')
+      layernorm_c16<DEB>(x, vec + GG::LN1G * DE, vec + GG::LN1B * DE, g);
+      f32x4 o2[DEB];
 #pragma unroll
-    for (int ob = 0; ob < DEB; ++ob) o2[ob] = ld4(vec + G::B_FF2 * DE + 16 * ob + 4 * g);
+      for (int ob = 0; ob < DEB; ++ob) o2[ob] = ld4(vec + GG::B_FF2 * DE + 16 * ob + 4 * g);
 #pragma unroll
-    for (int f = 0; f < FFB / 4; ++f) {
-      f32x4 hid[4];
+      for (int f = 0; f < FFB / 4; ++f) {
+        f32x4 hid[4];
 #pragma unroll
-      for (int hb = 0; hb < 4; hb += 2) {
-        const int h0 = 4 * f + hb;
-        f32x4 a0 = ld4(vec + G::V_FF1 + 16 * h0 + 4 * g), a1 = ld4(vec + G::V_FF1 + 16 * (h0 + 1) + 4 * g);
+        for (int hb = 0; hb < 4; hb += 2) {
+          const int h0 = 4 * f + hb;
+          f32x4 a0 = ld4(vec + GG::V_FF1 + 16 * h0 + 4 * g), a1 = ld4(vec + GG::V_FF1 + 16 * (h0 + 1) + 4 * g);
 #pragma unroll
-        for (int ib = 0; ib < DEB; ++ib)
-          mfma4x2(a0, a1, img[G::W_FF1 + (h0 * DEB + ib) * 64 + lane], img[G::W_FF1 + ((h0 + 1) * DEB + ib) * 64 + lane], x[ib]);
+          for (int ib = 0; ib < DEB; ++ib)
+            mfma4x2(a0, a1, img[GG::W_FF1 + (h0 * DEB + ib) * 64 + lane], img[GG::W_FF1 + ((h0 + 1) * DEB + ib) * 64 + lane], x[ib]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          hid[hb][r] = fmaxf(a0[r], 0.f);
-          hid[hb + 1][r] = fmaxf(a1[r], 0.f);
+          for (int r = 0; r < 4; ++r) {
+            hid[hb][r] = fmaxf(a0[r], 0.f);
+            hid[hb + 1][r] = fmaxf(a1[r], 0.f);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ob = 0; ob < DEB; ob += 2) {
+#pragma unroll
+          for (int hb = 0; hb < 4; ++hb)
+            mfma4x2(o2[ob], o2[ob + 1], img[GG::W_FF2 + (ob * FFB + 4 * f + hb) * 64 + lane],
+                    img[GG::W_FF2 + ((ob + 1) * FFB + 4 * f + hb) * 64 + lane], hid[hb]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
 #pragma unroll
-      for (int ob = 0; ob < DEB; ob += 2) {
-#pragma unroll
-        for (int hb = 0; hb < 4; ++hb)
-          mfma4x2(o2[ob], o2[ob + 1], img[G::W_FF2 + (ob * FFB + 4 * f + hb) * 64 + lane],
-                  img[G::W_FF2 + ((ob + 1) * FFB + 4 * f + hb) * 64 + lane], hid[hb]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      for (int ib = 0; ib < DEB; ++ib) x[ib] += o2[ib];
+      layernorm_c16<DEB>(x, vec + GG::LN2G * DE, vec + GG::LN2B * DE, g);
     }
-#pragma unroll
-    for (int ib = 0; ib < DEB; ++ib) x[ib] += o2[ib];
-    layernorm_c16<DEB>(x, vec + G::LN2G * DE, vec + G::LN2B * DE, g);
     if (inb) {
       float* dst = a.E_out + pij + 4 * g;
 #pragma unroll
       for (int ib = 0; ib < DEB; ++ib) *reinterpret_cast<f32x4*>(dst + 16 * ib) = vj ? x[ib] : splat4(0.f);
+    }
+  }
+}
+
+// E_out = LN2(E' + linE2 relu linE1 E'), E' = LN1(E''), in place on the tiles block3d_edge_kernel<.., true> stored
+// (pos_transformer_model.py:278-288): the edge_mlp_unit_x3 scheme (both weight matrices resident as three-term images,
+// no barrier in the unit loop) with the two LayerNorms and the residual around it.
+template <int DEB, int FFB, int NW>
+__global__ __launch_bounds__(NW * 64) void block3d_ffn_kernel(Block3DArgs a) {
+  using G = Geom3DF<DEB, FFB>;
+  constexpr int DE = G::DE, Q1 = G::Q1, Q2 = G::Q2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* img = reinterpret_cast<f32x4*>(smem);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  for (int idx = tid; idx < G::IMG_F4; idx += NW * 64) img[idx] = a.img[idx];
+  __syncthreads();
+  const float* vec = reinterpret_cast<const float*>(img + G::VEC);
+  const f32x4* W1 = img + G::W_1;
+  const f32x4* W2 = img + G::W_2;
+  const int n = a.n, nch = (n + 15) >> 4;
+  const int count = *a.unit_count;
+  for (int uidx = blockIdx.x * NW + wave; uidx < count; uidx += gridDim.x * NW) {
+    const int u = a.units[uidx];
+    const int row = u / nch, jc = u - row * nch;
+    const int b = row / n;
+    const int j = jc * 16 + p;
+    const bool inb = j < n;
+    const int jj = inb ? j : 0;
+    const bool vj = inb && a.mask[(long long)b * n + jj] != 0;
+    float* tile = a.E_out + ((long long)row * n + jj) * DE + 4 * g;
+    Frag3 fa, fb;
+    load_frag3(fa, W1, lane);
+    f32x4 x[DEB];
+#pragma unroll
+    for (int ib = 0; ib < DEB; ++ib) x[ib] = vj ? ld4(tile + 16 * ib) : splat4(0.f);
+    layernorm_c16<DEB>(x, vec + G::LN1G * DE, vec + G::LN1B * DE, g);
+    u32x4 xh[Q1], xm[Q1], xl[Q1];
+#pragma unroll
+    for (int q = 0; q < Q1; ++q) split3(x[2 * q], x[2 * q + 1], xh[q], xm[q], xl[q]);
+    f32x4 hid[FFB];
+#pragma unroll
+    for (int hb = 0; hb < FFB; ++hb) hid[hb] = ld4(vec + G::V_FF1 + 16 * hb + 4 * g);
+    block_pipeline<FFB * Q1, 0>(W1, W2, fa, fb, lane,
+                                [&](int t, const Frag3& w) { mfma_x3(hid[t / Q1], w, xh[t % Q1], xm[t % Q1], xl[t % Q1]); });
+#pragma unroll
+    for (int hb = 0; hb < FFB; ++hb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hid[hb][r] = fmaxf(hid[hb][r], 0.f);
+    f32x4 o[DEB];
+#pragma unroll
+    for (int ob = 0; ob < DEB; ++ob) o[ob] = ld4(vec + G::B_FF2 * DE + 16 * ob + 4 * g);
+    {
+      u32x4 hh, hm, hl;
+      block_pipeline<DEB * Q2, 0>(W2, nullptr, fa, fb, lane, [&](int t, const Frag3& w) {
+        if (t % DEB == 0) split3(hid[2 * (t / DEB)], hid[2 * (t / DEB) + 1], hh, hm, hl);
+        mfma_x3(o[t % DEB], w, hh, hm, hl);
+      });
+    }
+#pragma unroll
+    for (int ib = 0; ib < DEB; ++ib) x[ib] += o[ib];
+    layernorm_c16<DEB>(x, vec + G::LN2G * DE, vec + G::LN2B * DE, g);
+    if (vj) {
+#pragma unroll
+      for (int ib = 0; ib < DEB; ++ib) *reinterpret_cast<f32x4*>(tile + 16 * ib) = x[ib];
     }
   }
 }
@@ -562,9 +855,20 @@ __global__ void block3d_chunk_count_kernel(const uint8_t* mask, int B, int n, in
 // ---------------------------------------------------------------------------------------------------------
 #define SCGG_B3D_CASES CASE(4, 8, 8) CASE(4, 8, 16) CASE(2, 4, 2)   /* (de/16, dim_ffE/16, dx/16) */
 
+// SCGG_B3D_MODE=f32 selects the one-kernel fp32-MFMA form (development A/B switch); default: the bf16x3 pair
+static bool b3d_x3() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("SCGG_B3D_MODE");
+    mode = (e != nullptr && e[0] == 'f') ? 0 : 1;
+  }
+  return mode == 1;
+}
+
 long long block3d_img_f4(int dx, int de, int ffe) {
-#define CASE(DEB, FFB, DXB) \
-  if (de == 16 * DEB && ffe == 16 * FFB && dx == 16 * DXB) return Geom3D<DEB, FFB, DXB>::IMG_F4;
+#define CASE(DEB, FFB, DXB)                                                                            \
+  if (de == 16 * DEB && ffe == 16 * FFB && dx == 16 * DXB)                                             \
+    return b3d_x3() ? (long long)Geom3DA<DEB, DXB>::IMG_F4 + Geom3DF<DEB, FFB>::IMG_F4 : (long long)Geom3D<DEB, FFB, DXB>::IMG_F4;
   SCGG_B3D_CASES
 #undef CASE
   return -1;
@@ -574,7 +878,8 @@ int launch_block3d_pack(const Block3DPackArgs& a, int dx, int de, int ffe, hipSt
   if (a.n_head < 1 || a.n_head > 16) return -1;
 #define CASE(DEB, FFB, DXB)                                                                           \
   if (de == 16 * DEB && ffe == 16 * FFB && dx == 16 * DXB) {                                          \
-    hipLaunchKernelGGL((block3d_pack_kernel<DEB, FFB, DXB>), dim3(64), dim3(256), 0, st, a);          \
+    if (b3d_x3()) hipLaunchKernelGGL((block3d_pack_x3_kernel<DEB, FFB, DXB>), dim3(64), dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((block3d_pack_kernel<DEB, FFB, DXB>), dim3(64), dim3(256), 0, st, a);     \
     return 0;                                                                                         \
   }
   SCGG_B3D_CASES
@@ -582,28 +887,53 @@ int launch_block3d_pack(const Block3DPackArgs& a, int dx, int de, int ffe, hipSt
   return -1;
 }
 
-template <int DEB, int FFB, int DXB, int NW>
-static int launch_b3d_nw(const Block3DArgs& a, hipStream_t st) {
-  const int n_cu = device_cu_count();
-  if (n_cu <= 0) return -2;
+template <int DEB, int FFB, int NW>
+static int launch_b3d_ffn(const Block3DArgs& a, int n_cu, hipStream_t st) {
   static LdsAttrOnce attr;
-  void (*kern)(Block3DArgs) = block3d_edge_kernel<DEB, FFB, DXB, NW>;
-  const size_t lds = (size_t)Geom3D<DEB, FFB, DXB>::IMG_F4 * 16;
-  if (set_max_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds)) return -2;
-  hipLaunchKernelGGL(kern, dim3(n_cu), dim3(NW * 64), lds, st, a);
+  void (*kf)(Block3DArgs) = block3d_ffn_kernel<DEB, FFB, NW>;
+  const size_t lds = (size_t)Geom3DF<DEB, FFB>::IMG_F4 * 16;
+  if (set_max_dynamic_lds(attr, reinterpret_cast<const void*>(kf), lds)) return -2;
+  hipLaunchKernelGGL(kf, dim3(n_cu), dim3(NW * 64), lds, st, a);
   return 0;
 }
-// waves per workgroup (= per CU: the LDS image leaves room for one workgroup).  SCGG_B3D_NW = 8 / 12 / 16 for A/B runs.
+template <int DEB, int FFB, int DXB, int NW, bool X3>
+static int launch_b3d_edge(const Block3DArgs& a, int n_cu, hipStream_t st) {
+  using GA = typename std::conditional<X3, Geom3DA<DEB, DXB>, Geom3D<DEB, FFB, DXB>>::type;
+  static LdsAttrOnce attr;
+  void (*ka)(Block3DArgs) = block3d_edge_kernel<DEB, FFB, DXB, NW, X3>;
+  const size_t lds = (size_t)GA::IMG_F4 * 16;
+  if (set_max_dynamic_lds(attr, reinterpret_cast<const void*>(ka), lds)) return -2;
+  hipLaunchKernelGGL(ka, dim3(n_cu), dim3(NW * 64), lds, st, a);
+  return 0;
+}
+// Waves per workgroup (= per CU: the LDS images leave room for one workgroup).  x3 pair: 8 for the block kernel (it needs
+// ~200 VGPRs; at 12 waves = 168 it spills 69 and is 14 % slower), 12 for the FFN kernel (8: 2.69 ms per forward, 12: 2.65, 16: 2.68); the fp32
+// kernel 12.  SCGG_B3D_NW / SCGG_B3D_FFN_NW = 8 | 12 | 16 for A/B runs.
 template <int DEB, int FFB, int DXB>
 static int launch_b3d(const Block3DArgs& a, hipStream_t st) {
-  static int nw = 0;
+  static int nw = 0, nwf = 0;
   if (nw == 0) {
-    const char* e = getenv("SCGG_B3D_NW");
-    nw = e ? atoi(e) : 12;   // 12: 3 % faster than 8 at B = 512 vessel dims (168 VGPRs, 15 spilled), 16 spills 57 and is 5 % slower
+    const char *e = getenv("SCGG_B3D_NW"), *f = getenv("SCGG_B3D_FFN_NW");
+    nw = e ? atoi(e) : (b3d_x3() ? 8 : 12);
+    nwf = f ? atoi(f) : 12;
   }
-  if (nw == 16) return launch_b3d_nw<DEB, FFB, DXB, 16>(a, st);
-  if (nw == 12) return launch_b3d_nw<DEB, FFB, DXB, 12>(a, st);
-  return launch_b3d_nw<DEB, FFB, DXB, 8>(a, st);
+  const int n_cu = device_cu_count();
+  if (n_cu <= 0) return -2;
+  if (!b3d_x3()) {
+    if (nw == 16) return launch_b3d_edge<DEB, FFB, DXB, 16, false>(a, n_cu, st);
+    if (nw == 12) return launch_b3d_edge<DEB, FFB, DXB, 12, false>(a, n_cu, st);
+    return launch_b3d_edge<DEB, FFB, DXB, 8, false>(a, n_cu, st);
+  }
+  int rc;
+  if (nw == 16) rc = launch_b3d_edge<DEB, FFB, DXB, 16, true>(a, n_cu, st);
+  else if (nw == 12) rc = launch_b3d_edge<DEB, FFB, DXB, 12, true>(a, n_cu, st);
+  else rc = launch_b3d_edge<DEB, FFB, DXB, 8, true>(a, n_cu, st);
+  if (rc) return rc;
+  Block3DArgs f = a;
+  f.img = a.img + Geom3DA<DEB, DXB>::IMG_F4;
+  if (nwf == 8) return launch_b3d_ffn<DEB, FFB, 8>(f, n_cu, st);
+  if (nwf == 12) return launch_b3d_ffn<DEB, FFB, 12>(f, n_cu, st);
+  return launch_b3d_ffn<DEB, FFB, 16>(f, n_cu, st);
 }
 
 int launch_block3d_edge(const Block3DArgs& a, int dx, int de, int ffe, hipStream_t st) {
