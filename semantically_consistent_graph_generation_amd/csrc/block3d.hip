@@ -767,34 +767,42 @@ __global__ __launch_bounds__(256) void block3d_graph_merge_kernel(GraphMerge3DAr
   __syncthreads();
   const int nv = s_nv;
   if (nv == 0) return;
+  // loads are unconditional and unrolled (8 rows in flight per thread): the loops are chains of L2 round trips otherwise
   for (int t = threadIdx.x; t < DX; t += 256) {
+    const float* col = a.newX + (long long)b * n * DX + t;
     float s = 0.f;
-    for (int i = 0; i < n; ++i) s += a.newX[((long long)b * n + i) * DX + t];
+#pragma unroll 8
+    for (int i = 0; i < n; ++i) s += col[(long long)i * DX];
     const float mean = s / (float)nv;
     float q = 0.f, mn = INFINITY, mx = -INFINITY;
-    for (int i = 0; i < n; ++i)
-      if (m[i]) {
-        const float v = a.newX[((long long)b * n + i) * DX + t], d = v - mean;
-        q += d * d;
-        mn = fminf(mn, v);
-        mx = fmaxf(mx, v);
-      }
+#pragma unroll 8
+    for (int i = 0; i < n; ++i) {
+      const float v = col[(long long)i * DX], d = v - mean;
+      const bool on = m[i] != 0;
+      q += on ? d * d : 0.f;
+      mn = fminf(mn, on ? v : INFINITY);
+      mx = fmaxf(mx, on ? v : -INFINITY);
+    }
     z[t] = mean; z[DX + t] = mn; z[2 * DX + t] = mx; z[3 * DX + t] = q / (float)nv;
   }
   for (int t = threadIdx.x; t < 2 * DE; t += 256) {
     const int which = t / DE, ch = t - which * DE;
     float N = 0.f, mean = 0.f, m2 = 0.f, mn = INFINITY, mx = -INFINITY;
     const float k = (float)nv;
-    for (int i = 0; i < n; ++i)
+    const float* col = a.rowagg + (long long)b * n * (8 * DE) + which * 4 * DE + ch;
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) {
+      const float* ag = col + (long long)i * (8 * DE);
+      const float r_mean = ag[0], r_m2 = ag[DE], r_mn = ag[2 * DE], r_mx = ag[3 * DE];
       if (m[i]) {
-        const float* ag = a.rowagg + ((long long)b * n + i) * (8 * DE) + which * 4 * DE + ch;
-        const float dl = ag[0] - mean, nn = N + k;
+        const float dl = r_mean - mean, nn = N + k;
         mean += dl * (k / nn);
-        m2 += ag[DE] + dl * dl * (N * k / nn);
-        mn = fminf(mn, ag[2 * DE]);
-        mx = fmaxf(mx, ag[3 * DE]);
+        m2 += r_m2 + dl * dl * (N * k / nn);
+        mn = fminf(mn, r_mn);
+        mx = fmaxf(mx, r_mx);
         N = nn;
       }
+    }
     float* zz = a.etoy + (long long)b * (8 * DE) + which * 4 * DE + ch;
     zz[0] = mean; zz[DE] = mn; zz[2 * DE] = mx; zz[3 * DE] = m2 / N;
   }
