@@ -249,3 +249,41 @@ def test_chain_with_3d_denoiser_matches_cpu_oracle_bit_exactly():
     assert int((lab > 0).sum()) > 0
     assert rel_err(pos_end, pos) < 1e-5
     assert rel_err(radius, (lab > 0) * rad.squeeze(-1)) < REL
+
+
+def test_vessel_graphs_of_256_nodes_match_oracle():
+    """ATM-size graphs (n_max = 256: 16 key chunks per row, 16 units merged per row, one full and one ragged graph), vessel
+    dims, 2 layers, both heads: against the oracle (differences mode) at 1e-4, plus the structural invariants."""
+    from semantically_consistent_graph_generation_amd.pos_transformer_model import Graph3DTransformer
+    from semantically_consistent_graph_generation_amd.placeholder import PlaceHolder
+    dims, ind, od, L = fx.VESSEL_DIMS, (1, 5, 1, 0), (1, 5, 0, 0), 2
+    model = Graph3DTransformer(L, fx.dims_ns(*ind), dims["hidden_mlp_dims"], dims["hidden_dims"], fx.dims_ns(*od)).eval()
+    sd = fx.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=53)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    g = torch.Generator().manual_seed(8)
+    n_nodes = [256, 203]
+    mask = fx.ragged_mask(n_nodes)
+    B, n = mask.shape
+    E = fx.one_hot_edges(fx.random_labels(mask, 5, 0.01, 6), mask, 5)
+    X = mask[..., None].float()
+    y = torch.tensor([[0.37], [0.81]])
+    pos = torch.randn(B, n, 3, generator=g) * 2.0
+    dev = torch.device("cuda")
+    inp = PlaceHolder(X=X.to(dev), E=E.to(dev), y=y.to(dev), pos=pos.to(dev), node_mask=mask.to(dev),
+                      radius=torch.zeros(B, n, n, 1, device=dev))
+    out = model(inp)
+    torch.cuda.synchronize()
+    dd = D.DenoiserDims(L, dims["hidden_dims"]["n_head"], 1, 5, 0, 0)
+    old = D3.DIST_MODE
+    D3.DIST_MODE = "direct"
+    try:
+        oX, oc, oE, orad = D3.graph3d_transformer_forward(sd, dd, X, E, y, pos, mask)
+    finally:
+        D3.DIST_MODE = old
+    assert rel_err(out.E, oE) < REL
+    assert rel_err(out.radius, orad) < REL
+    assert rel_err(out.X, oX) < REL
+    Eo = out.E.cpu()
+    pm = (mask[:, :, None] & mask[:, None, :]) & ~torch.eye(n, dtype=torch.bool)[None]
+    assert torch.equal(Eo, Eo.transpose(1, 2)) and (Eo[~pm] == 0).all()
