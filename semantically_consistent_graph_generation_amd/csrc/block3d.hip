@@ -68,9 +68,9 @@ struct Geom3DA {
   static constexpr int W_IN = 0;                                  // (ob, q)
   static constexpr int W_DIST = NBLK * 192;                       // (ob, {dist_add_e, dist_mul_e}, q)
   static constexpr int W_EOUT = 3 * NBLK * 192;                   // (ob, q)
-  static constexpr int W_EATT = 4 * NBLK * 192;                   // fp32 fragments from here on, as in Geom3D
-  static constexpr int W_PATT = W_EATT + DEB * 64;
-  static constexpr int W_A = W_PATT + DEB * 64;
+  static constexpr int W_EATT = 4 * NBLK * 192;                   // e_att_mul: Q blocks (16 rows = heads, zero padded)
+  static constexpr int W_PATT = W_EATT + Q * 192;                 // pos_att_mul
+  static constexpr int W_A = W_PATT + Q * 192;                    // fp32 fragments of `a` (16 heads x dx), as in Geom3D
   static constexpr int VEC = W_A + DXB * 64;
   enum { B_IN = 0, B_DADD, B_DMUL, B_EOUT, WD0, WD1, BD, WN1, WN2, NVEC_DE };
   static constexpr int V_EATT = NVEC_DE * DE;
@@ -127,17 +127,15 @@ __global__ __launch_bounds__(256) void block3d_pack_x3_kernel(Block3DPackArgs a)
           const int t = blk - 3 * GA::NBLK;
           v = x3_slot(a.W_eout, DE, DE, t / Q, t % Q, term, l);
         }
+      } else if (idx < GA::W_A) {
+        const int i2 = idx - GA::W_EATT, blk = i2 / 192, term = (i2 % 192) >> 6, l = i2 & 63;
+        v = x3_slot(blk < Q ? a.W_eatt : a.W_patt, a.n_head, DE, 0, blk % Q, term, l);
       } else if (idx < GA::VEC) {
-        const float* W;
-        int K, KBLK, off;
-        if (idx < GA::W_PATT) { W = a.W_eatt; K = DE; KBLK = DEB; off = GA::W_EATT; }
-        else if (idx < GA::W_A) { W = a.W_patt; K = DE; KBLK = DEB; off = GA::W_PATT; }
-        else { W = a.W_a; K = DX; KBLK = DXB; off = GA::W_A; }
-        const int t = (idx - off) >> 6, l = idx & 63, ib = t % KBLK, row = l & 15;
+        const int t = (idx - GA::W_A) >> 6, l = idx & 63, row = l & 15;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int col = 16 * ib + 4 * (l >> 4) + e;
-          if (row < a.n_head && col < K) v[e] = W[(size_t)row * K + col];
+          const int col = 16 * t + 4 * (l >> 4) + e;
+          if (row < a.n_head && col < DX) v[e] = a.W_a[(size_t)row * DX + col];
         }
       } else {
         const int f0 = (idx - GA::VEC) * 4;
@@ -273,6 +271,38 @@ __device__ __forceinline__ float groups_max(float v) {          // across the fo
   auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
+// acc += x . W^T with the ACTIVATION as the A operand (keys as rows) and the weight block as B: the same six partial
+// products as mfma_x3, roles swapped
+__device__ __forceinline__ void mfma_x3_t(f32x4& acc, const u32x4& xh, const u32x4& xm, const u32x4& xl, const Frag3& w) {
+#define SCGG_BF(v) __builtin_bit_cast(bf16x8, v)
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(xh), SCGG_BF(w.l), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(xl), SCGG_BF(w.h), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(xm), SCGG_BF(w.m), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(xh), SCGG_BF(w.m), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(xm), SCGG_BF(w.h), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(xh), SCGG_BF(w.h), acc, 0, 0, 0);
+#undef SCGG_BF
+}
+// 16-lane minima of mn[0..3] and maxima of mx[0..3], step-major inside one asm block per step: an instruction never reads
+// a register written by one of the seven before it, so one s_nop per step (for whatever the compiler placed in front)
+// replaces the one per instruction of row_min16_fused / row_max16_fused
+#define SCGG_MINMAX_STEP(ctrl)                                                                                  \
+  asm("s_nop 1\n\t"                                                                                             \
+      "v_min_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                            \
+      "v_min_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                            \
+      "v_min_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                            \
+      "v_min_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                            \
+      "v_max_f32_dpp %4, %4, %4 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                            \
+      "v_max_f32_dpp %5, %5, %5 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                            \
+      "v_max_f32_dpp %6, %6, %6 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                            \
+      "v_max_f32_dpp %7, %7, %7 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1"                                 \
+      : "+v"(mn[0]), "+v"(mn[1]), "+v"(mn[2]), "+v"(mn[3]), "+v"(mx[0]), "+v"(mx[1]), "+v"(mx[2]), "+v"(mx[3]))
+__device__ __forceinline__ void row_minmax16_x4(f32x4& mn, f32x4& mx) {
+  SCGG_MINMAX_STEP("quad_perm:[1,0,3,2]");
+  SCGG_MINMAX_STEP("quad_perm:[2,3,0,1]");
+  SCGG_MINMAX_STEP("row_half_mirror");
+  SCGG_MINMAX_STEP("row_mirror");
+}
 // two accumulators, two fragments, two inputs
 __device__ __forceinline__ void mfma4x2d(f32x4& acc0, f32x4& acc1, const f32x4& f0, const f32x4& f1, const f32x4& x0,
                                          const f32x4& x1) {
@@ -342,6 +372,7 @@ __global__ __launch_bounds__(NW * 64) void block3d_edge_kernel(Block3DArgs a) {
     // ---- Y = in_E(x) . x_e_mul1_j . x_e_mul2_i, then the distance FiLM
     f32x4 Y[DEB];
     Frag3 fa, fb;
+    u32x4 eh[Q], em[Q], el[Q];     // x3 form: bf16 terms of E1 (operands of e_out and of the attention multiplier e_att_mul)
     if constexpr (X3) {
       load_frag3(fa, img + Geom3DA<DEB, DXB>::W_IN, lane);
       u32x4 xh[Q], xm[Q], xl[Q];
@@ -401,7 +432,7 @@ __global__ __launch_bounds__(NW * 64) void block3d_edge_kernel(Block3DArgs a) {
       }
     }
     // ---- pooled statistics of Y and dist1 over this unit's valid keys
-    if (a.need_attn) {
+    if (a.need_attn & 2) {
       const float inv = 1.0f / (float)__popc(keymask);
       float* sp = a.stat_part + (long long)u * (8 * DE);
 #pragma unroll
@@ -424,9 +455,10 @@ __global__ __launch_bounds__(NW * 64) void block3d_edge_kernel(Block3DArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             m2[r] = q[r];
-            mn[r] = row_min16_fused(vj ? val[r] : INFINITY);
-            mx[r] = row_max16_fused(vj ? val[r] : -INFINITY);
+            mn[r] = vj ? val[r] : INFINITY;
+            mx[r] = vj ? val[r] : -INFINITY;
           }
+          row_minmax16_x4(mn, mx);
           if (p == 0) {
             float* d = sp + t * 4 * DE + 16 * ob + 4 * g;
             *reinterpret_cast<f32x4*>(d) = mean;
@@ -449,7 +481,6 @@ __global__ __launch_bounds__(NW * 64) void block3d_edge_kernel(Block3DArgs a) {
     }
     f32x4 nE[DEB];
     if constexpr (X3) {
-      u32x4 eh[Q], em[Q], el[Q];
 #pragma unroll
       for (int q = 0; q < Q; ++q) split3(Y[2 * q], Y[2 * q + 1], eh[q], em[q], el[q]);
       // accumulators start at bias + x: the sum leaves as E'' = x + newE.  x is read again here (an L2 hit) rather than
@@ -482,7 +513,7 @@ __global__ __launch_bounds__(NW * 64) void block3d_edge_kernel(Block3DArgs a) {
       }
     }
     // ---- attention, transposed: lane (head p, key group g) register r <-> key 4 g + r
-    if (a.need_attn) {
+    if (a.need_attn & 1) {
       f32x4 la0 = splat4(0.f), la1 = splat4(0.f);
 #pragma unroll
       for (int db = 0; db < DXB; db += 2) {
@@ -497,9 +528,24 @@ __global__ __launch_bounds__(NW * 64) void block3d_edge_kernel(Block3DArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       f32x4 fe = splat4(vec[G::V_EATT + p]), fp = splat4(vec[G::V_PATT + p]);
+      if constexpr (X3) {      // the split operand of e_out serves again, now as the A side; dist1 is split once more (holding its
+                               // 6 Q registers across e_out spills)
 #pragma unroll
-      for (int ib = 0; ib < DEB; ++ib)
-        mfma4x2d(fe, fp, Y[ib], d1[ib], img[G::W_EATT + ib * 64 + lane], img[G::W_PATT + ib * 64 + lane]);
+        for (int q = 0; q < Q; ++q) {
+          Frag3 we, wp;
+          u32x4 dh, dm3, dl;
+          split3(d1[2 * q], d1[2 * q + 1], dh, dm3, dl);
+          load_frag3(we, img + Geom3DA<DEB, DXB>::W_EATT + q * 192, lane);
+          load_frag3(wp, img + Geom3DA<DEB, DXB>::W_PATT + q * 192, lane);
+          mfma_x3_t(fe, eh[q], em[q], el[q], we);
+          mfma_x3_t(fp, dh, dm3, dl, wp);
+        }
+      } else {
+#pragma unroll
+        for (int ib = 0; ib < DEB; ++ib)
+          mfma4x2d(fe, fp, Y[ib], d1[ib], img[Geom3D<DEB, FFB, DXB>::W_EATT + ib * 64 + lane],
+                   img[Geom3D<DEB, FFB, DXB>::W_PATT + ib * 64 + lane]);
+      }
       __builtin_amdgcn_sched_barrier(0);
       float lg[4], mloc = -INFINITY;
 #pragma unroll

@@ -5,6 +5,7 @@
 // No torch types, no synchronisation, no allocation after finalize.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -451,7 +452,8 @@ int run3(scgg_denoiser3d* h, const float* X, const float* E, const float* y, con
       Block3DArgs a;
       a.E_in = Ecur; a.E_out = Enext; a.mask = mask; a.nodelin = w.nodelin; a.ldn = NL; a.film = film; a.ldf = FL;
       a.pos4 = w.pos4 + (size_t)l * M * 4; a.img = L.img; a.attn_part = w.attn; a.stat_part = w.stat;
-      a.units = w.units; a.unit_count = w.unit_count; a.B = B; a.n = n; a.n_head = H; a.need_attn = need_x ? 1 : 0;
+      a.units = w.units; a.unit_count = w.unit_count; a.B = B; a.n = n; a.n_head = H; a.need_attn = need_x ? 3 : 0;   // bit 0: attention partials, bit 1: statistics partials
+      { static const char* dbg = getenv("SCGG_B3D_PARTS"); if (dbg && need_x) a.need_attn = atoi(dbg); }   // timing experiments only
       a.inv_sqrt_de = 1.0f / sqrtf((float)de);
       if (launch_block3d_edge(a, dx, de, c.dim_ffE, st)) return fail("3D edge kernel: unsupported dims");
     }

@@ -277,7 +277,7 @@ struct Block3DArgs {
   float* stat_part;       // [B*n*nch][8*de]: Y: mean | M2 | min | max, dist1: the same, over the unit's valid keys
   const int* units;
   const int* unit_count;
-  int B, n, n_head, need_attn;
+  int B, n, n_head, need_attn;   // need_attn: bit 0 = attention partials, bit 1 = statistics partials
   float inv_sqrt_de;
 };
 struct RowMerge3DArgs {

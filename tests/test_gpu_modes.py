@@ -59,3 +59,42 @@ def test_staggered_x3s_kernel_agrees_with_the_default(tmp_path):
         scale = float(np.abs(a[k]).max())
         err = float(np.abs(a[k] - b[k]).max()) / scale
         assert err < 2e-5, f"{k}: x3s vs x3 differ by {err:.2e} of the output scale"
+
+
+SCRIPT_3D = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from oracle import fixtures as fx
+from semantically_consistent_graph_generation_amd.pos_transformer_model import Graph3DTransformer
+from semantically_consistent_graph_generation_amd.placeholder import PlaceHolder
+torch.manual_seed(6)
+dims = fx.VESSEL_DIMS
+B, n = 6, 32
+model = Graph3DTransformer(3, fx.dims_ns(1, 14, 1), dims["hidden_mlp_dims"], dims["hidden_dims"], fx.dims_ns(1, 14, 0)).eval()
+model.load_state_dict(fx.make_state_dict({{k: tuple(v.shape) for k, v in model.state_dict().items()}}, seed=62))
+model = model.cuda()
+mask = fx.ragged_mask(torch.tensor([32, 12, 27, 16, 5, 21]), n)
+E = fx.one_hot_edges(fx.random_labels(mask, 14, 0.15, 3), mask, 14)
+inp = PlaceHolder(X=mask[..., None].float().cuda(), E=E.cuda(), y=torch.rand(B, 1).cuda(), pos=torch.randn(B, n, 3).cuda(),
+                  node_mask=mask.cuda(), radius=torch.zeros(B, n, n, 1).cuda())
+out = model(inp)
+torch.cuda.synchronize()
+np.savez(sys.argv[1], X=out.radius.cpu().numpy(), E=out.E.cpu().numpy())
+"""
+
+
+@pytest.mark.gpu
+def test_3d_edge_layer_x3_pair_agrees_with_the_one_kernel_fp32_form(tmp_path):
+    """SCGG_B3D_MODE=f32: the position-aware layer as ONE fp32-MFMA kernel (all weights in LDS as fp32) against the default
+    pair of bf16x3 kernels (block part, then LN-FFN-LN in place): DESIGN.md 4.9.  Logits and radius agree to fp32 round-off."""
+    def run(tag, env_extra):
+        out = tmp_path / f"{tag}.npz"
+        r = subprocess.run([sys.executable, "-c", SCRIPT_3D.format(root=ROOT), str(out)], env=dict(os.environ, **env_extra),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return np.load(out)
+    a, b = run("x3", {}), run("f32", {"SCGG_B3D_MODE": "f32"})
+    for k in ("X", "E"):
+        scale = float(np.abs(b[k]).max())
+        err = float(np.abs(a[k] - b[k]).max()) / scale
+        assert err < 2e-5, f"{k}: x3 pair vs fp32 kernel differ by {err:.2e} of the output scale"
