@@ -441,13 +441,15 @@ int run3(scgg_denoiser3d* h, const float* X, const float* E, const float* y, con
     return 0;
   };
   float* film_buf[2] = {w.film, w.film + (size_t)B * FL};
+  bool nodelin_done = false;     // the fused node kernel of layer l already produced layer l+1's q | k | v | x_e_mul
   if (L_run > 0) TRY(y_round(0, false, film_buf[0]));
   for (int l = 0; l < L_run; ++l) {
     const Layer3& L = h->layers[l];
     const std::string p = "tf_layers." + std::to_string(l) + ".", sa = p + "self_attn.";
     const bool need_x = l != c.n_layers - 1 || eq || tap;      // the last layer's X feeds nothing in Graph3DTransformer
     const float* film = film_buf[l & 1];
-    TRY(rowlin(L.nl, L.Wnl, L.bnl, w.X, dx, w.nodelin, NL, NL, dx, false));
+    if (!nodelin_done) TRY(rowlin(L.nl, L.Wnl, L.bnl, w.X, dx, w.nodelin, NL, NL, dx, false));
+    nodelin_done = false;
     {
       Block3DArgs a;
       a.E_in = Ecur; a.E_out = Enext; a.mask = mask; a.nodelin = w.nodelin; a.ldn = NL; a.film = film; a.ldf = FL;
@@ -469,11 +471,39 @@ int run3(scgg_denoiser3d* h, const float* X, const float* E, const float* y, con
         TRY(launch_block3d_graph_merge(g, B, st));
         TRY(y_round(l, true, film_buf[(l + 1) & 1]));
       }
-      TRY(rowlin_named(L.x_out, sa + "x_out", w.newX, dx, w.t_out, dx, dx, dx, false));
-      TRY(ln_rows(w.X, w.t_out, p + "normX1", w.X1));
-      TRY(rowlin_named(L.linX1, p + "linX1", w.X1, dx, w.t_ff, c.dim_ffX, c.dim_ffX, dx, true));
-      TRY(rowlin_named(L.linX2, p + "linX2", w.t_ff, c.dim_ffX, w.t_out, dx, dx, c.dim_ffX, false));
-      TRY(ln_rows(w.X1, w.t_out, p + "normX2", w.X));
+      // x_out, normX1, linX1 / linX2, normX2 and the next layer's q | k | v | x_e_mul1 | x_e_mul2: one fused launch of the 2D
+      // engine's node kernel (fed with the finished newX) when its shape is built, else the separate launches
+      bool fused = false;
+      if (node_layer_supported(dx, c.dim_ffX) && node_layer_x3_enabled() && L.x_out.W3 && L.linX1.W3 && L.linX2.W3) {
+        const Param3 *g1 = find3(h, p + "normX1.weight", dx), *b1 = find3(h, p + "normX1.bias", dx),
+                     *g2 = find3(h, p + "normX2.weight", dx), *b2 = find3(h, p + "normX2.bias", dx);
+        if (!g1 || !b1 || !g2 || !b2) return -1;
+        const bool next = l + 1 < c.n_layers && h->layers[l + 1].nl.W3 != nullptr && NL % 32 == 0;
+        if (next || l + 1 >= c.n_layers) {
+          NodeLayerArgs na{};
+          na.mask = mask; na.X = w.X; na.rows = w.rows; na.row_count = w.row_count; na.n = n;
+          na.b_xout = L.x_out.b; na.ln1_g = g1->p; na.ln1_b = b1->p; na.b_lin1 = L.linX1.b; na.b_lin2 = L.linX2.b;
+          na.ln2_g = g2->p; na.ln2_b = b2->p;
+          na.W3_xout = L.x_out.W3; na.W3_lin1 = L.linX1.W3; na.W3_lin2 = L.linX2.W3;
+          na.X_out = w.X;                        // in place: a workgroup reads its rows' residual before it writes them
+          na.newX_in = w.newX;
+          if (next) {
+            na.W3_qkv = h->layers[l + 1].nl.W3; na.b_qkv = h->layers[l + 1].nl.b; na.qkv = w.nodelin;
+            na.tail_pairs = NL / 32; na.tail_ld = NL; na.tail_relu = 0;
+          }
+          if (launch_node_layer(na, dx, c.dim_ffX, M, st) == 0) {
+            fused = true;
+            nodelin_done = next;
+          }
+        }
+      }
+      if (!fused) {
+        TRY(rowlin_named(L.x_out, sa + "x_out", w.newX, dx, w.t_out, dx, dx, dx, false));
+        TRY(ln_rows(w.X, w.t_out, p + "normX1", w.X1));
+        TRY(rowlin_named(L.linX1, p + "linX1", w.X1, dx, w.t_ff, c.dim_ffX, c.dim_ffX, dx, true));
+        TRY(rowlin_named(L.linX2, p + "linX2", w.t_ff, c.dim_ffX, w.t_out, dx, dx, c.dim_ffX, false));
+        TRY(ln_rows(w.X1, w.t_out, p + "normX2", w.X));
+      }
     }
     float* t = Ecur; Ecur = Enext; Enext = t;
   }

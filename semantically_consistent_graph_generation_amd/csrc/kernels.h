@@ -187,6 +187,9 @@ struct NodeLayerArgs {    // fused node part of one layer (node_layer.hip); pack
   // stride of the destination, ReLU.  0 pairs = the next layer's q|k|v (3 dx wide, no activation); the last layer passes
   // mlp_out_X.0 here (transformer_model.py:371), so that the output head needs no separate launch over X.
   int tail_pairs, tail_ld, tail_relu;
+  // x3 kernel only: the block's node output before x_out, already complete ([B,n,dx]; the position-aware block, whose attention
+  // merge and EtoX FiLMs happen in its own kernels).  Non-null: attn_part / film are not read.
+  const float* newX_in;
 };
 bool node_layer_supported(int dx, int ffx);
 bool node_layer_x3_enabled();   // the x3 kernels are selected (SCGG_NODE_MODE is not f32)

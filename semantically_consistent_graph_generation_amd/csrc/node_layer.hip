@@ -385,7 +385,10 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
     const uint8_t* mb = a.mask + (long long)b * n;
     const float* film = a.film + (long long)b * (4 * DX);
     const int c = lane * 4;
-    if (c < DX) {
+    if (c < DX && a.newX_in != nullptr) {
+      put_split4<KS, PLANE>(S1, wave * RPW + t, c, *reinterpret_cast<const f32x4*>(a.newX_in + row * DX + c));
+      res[t] = *reinterpret_cast<const f32x4*>(a.X + row * DX + c);
+    } else if (c < DX) {
       f32x4 M = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, S = {0.f, 0.f, 0.f, 0.f}, A = {0.f, 0.f, 0.f, 0.f};
       for (int jc = 0; jc < nch; ++jc) {
         bool any = false;
@@ -589,6 +592,7 @@ template <int DXB, int FXB>
 static int launch_one(const NodeLayerArgs& a, int M, hipStream_t st) {
   static LdsAttrOnce attr_x3, attr_f32;
   const bool x3 = node_x3() && a.W3_xout && a.W3_lin1 && a.W3_lin2;
+  if (a.newX_in != nullptr && !x3) return -1;      // the fp32 kernel has no such mode
   auto kern = x3 ? node_layer_x3_kernel<DXB, FXB> : node_layer_kernel<DXB, FXB>;
   const size_t lds = x3 ? NodeGeomX3<DXB, FXB>::LDS_BYTES : NodeGeom<DXB, FXB>::LDS_BYTES;
   if (set_max_dynamic_lds(x3 ? attr_x3 : attr_f32, reinterpret_cast<const void*>(kern), lds)) return -2;
