@@ -435,11 +435,11 @@ __global__ __launch_bounds__(NW * 64) void block3d_edge_kernel(Block3DArgs a) {
     if (a.need_attn & 2) {
       const float inv = 1.0f / (float)__popc(keymask);
       float* sp = a.stat_part + (long long)u * (8 * DE);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
+      // (the statistics of dist1 depend on the positions only: block3d_dist_stats_kernel makes them for all layers up front)
+      constexpr int t = 0;
 #pragma unroll
         for (int ob = 0; ob < DEB; ++ob) {
-          const f32x4 val = t == 0 ? Y[ob] : d1[ob];
+          const f32x4 val = Y[ob];
           float s[4], q[4];
           f32x4 mean, m2, mn, mx;
 #pragma unroll
@@ -745,8 +745,8 @@ __global__ __launch_bounds__(256) void block3d_row_merge_kernel(RowMerge3DArgs a
   }
   const float* sp0 = a.stat_part + (long long)row * nch * (8 * DE);
   const float* fl = a.film + (long long)b * a.ldf;
-  for (int t = lane; t < 2 * DE; t += 64) {
-    const int which = t / DE, ch = t - which * DE;
+  for (int t = lane; t < DE; t += 64) {
+    const int which = 0, ch = t;
     float N = 0.f, mean = 0.f, m2 = 0.f, mn = INFINITY, mx = -INFINITY;
     for (int c = 0; c < nch; ++c)
       if (cc[c] > 0) {
@@ -835,10 +835,11 @@ __global__ __launch_bounds__(256) void block3d_graph_merge_kernel(GraphMerge3DAr
     const int which = t / DE, ch = t - which * DE;
     float N = 0.f, mean = 0.f, m2 = 0.f, mn = INFINITY, mx = -INFINITY;
     const float k = (float)nv;
-    const float* col = a.rowagg + (long long)b * n * (8 * DE) + which * 4 * DE + ch;
+    const int ld = which ? 4 * DE : 8 * DE;
+    const float* col = (which ? a.rowaggD : a.rowagg) + (long long)b * n * ld + ch;
 #pragma unroll 4
     for (int i = 0; i < n; ++i) {
-      const float* ag = col + (long long)i * (8 * DE);
+      const float* ag = col + (long long)i * ld;
       const float r_mean = ag[0], r_m2 = ag[DE], r_mn = ag[2 * DE], r_mx = ag[3 * DE];
       if (m[i]) {
         const float dl = r_mean - mean, nn = N + k;
@@ -893,6 +894,76 @@ __global__ __launch_bounds__(64) void block3d_pos_kernel(const float* __restrict
       *reinterpret_cast<f32x4*>(cur + i * 4) = v;
     }
     __syncthreads();   // one wave: orders this layer's stores before the next layer's loads
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Statistics of dist1 (pos_transformer_model.py:122-132) over the keys of every valid row, for ALL layers in one launch:
+// dist1 depends on the positions and on five weight vectors per layer only, so the EtoX input of pos_x_mul (:186) and the
+// row aggregates behind the Etoy input of dist_y (:203) need not come out of the edge kernel.  One wave per (row, layer),
+// lane = channel; two passes over the keys (mean, then squared deviations), as the reference's own formula.
+//   dvec[l]     = [w_dist | w_cos | b | w_norm_i | w_norm_j][de]
+//   rowstatD[l][row] = [mean | min | max | var][de],  rowaggD[l][row] = [mean | M2 | min | max][de]
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void block3d_dist_stats_kernel(const float* __restrict__ pos4, const uint8_t* __restrict__ mask,
+                                                                 const float* __restrict__ dvec, const int* __restrict__ rows,
+                                                                 const int* __restrict__ row_count, float* __restrict__ rowstatD,
+                                                                 float* __restrict__ rowaggD, int M, int n, int de) {
+  // per wave: (distance, cosine, key norm) of the row's valid keys, compacted, 64 keys at a time
+  __shared__ float geo[4][64 * 3];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l = blockIdx.y;
+  const int ridx = blockIdx.x * 4 + wave;
+  if (ridx >= *row_count) return;                    // wave-uniform; no workgroup barrier below
+  const long long row = rows[ridx];
+  const int b = (int)(row / n);
+  const float* P = pos4 + (long long)l * M * 4;
+  const uint8_t* mb = mask + (long long)b * n;
+  const f32x4 pi = *reinterpret_cast<const f32x4*>(P + row * 4);
+  const float di = pi[3] + 1e-7f, uix = pi[0] / di, uiy = pi[1] / di, uiz = pi[2] / di;
+  const float* dv = dvec + (long long)l * 5 * de;
+  float* gw = geo[wave];
+  // one channel per lane and pass over the channels (de <= 64: one pass); statistics in one sweep over the keys with the
+  // first value as the shift (sum and sum of squares of t - k: nothing is lost to cancellation)
+  for (int c0 = 0; c0 < de; c0 += 64) {
+    const int c = c0 + lane;
+    const bool con = c < de;
+    const float w0 = con ? dv[c] : 0.f, w1 = con ? dv[de + c] : 0.f, bd = con ? dv[2 * de + c] : 0.f;
+    const float n1 = con ? dv[3 * de + c] : 0.f, n2 = con ? dv[4 * de + c] : 0.f;
+    const float base = bd + n1 * pi[3];
+    float k = 0.f, s1 = 0.f, s2 = 0.f, mn = INFINITY, mx = -INFINITY, cnt = 0.f;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+      const int j = j0 + lane;
+      const bool vj = j < n && mb[j] != 0;
+      const unsigned long long bal = __ballot(vj);
+      const int m = __popcll(bal);
+      if (vj) {
+        const f32x4 pj = *reinterpret_cast<const f32x4*>(P + ((long long)b * n + j) * 4);
+        const float ex = pi[0] - pj[0], ey = pi[1] - pj[1], ez = pi[2] - pj[2];
+        const float dj = pj[3] + 1e-7f;
+        const int slot = __popcll(bal & ((1ull << lane) - 1ull));
+        gw[3 * slot] = sqrtf(ex * ex + ey * ey + ez * ez);
+        gw[3 * slot + 1] = uix * (pj[0] / dj) + uiy * (pj[1] / dj) + uiz * (pj[2] / dj);
+        gw[3 * slot + 2] = pj[3];
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's LDS writes are visible to its other lanes
+      for (int q = 0; q < m; ++q) {
+        const float t = fmaxf(gw[3 * q] * w0 + gw[3 * q + 1] * w1 + base + n2 * gw[3 * q + 2], 0.f);
+        if (cnt == 0.f) k = t;
+        const float d = t - k;
+        s1 += d; s2 += d * d;
+        mn = fminf(mn, t); mx = fmaxf(mx, t);
+        cnt += 1.f;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (con) {
+      const float mean = k + s1 / cnt, m2 = fmaxf(s2 - s1 * s1 / cnt, 0.f);
+      float* rs = rowstatD + ((long long)l * M + row) * (4 * de) + c;
+      rs[0] = mean; rs[de] = mn; rs[2 * de] = mx; rs[3 * de] = m2 / cnt;
+      float* ag = rowaggD + ((long long)l * M + row) * (4 * de) + c;
+      ag[0] = mean; ag[de] = m2; ag[2 * de] = mn; ag[3 * de] = mx;
+    }
   }
 }
 
@@ -1023,6 +1094,15 @@ int launch_block3d_graph_merge(const GraphMerge3DArgs& a, int B, hipStream_t st)
 int launch_block3d_pos(const float* pos, const uint8_t* mask, int B, int n, int n_layers, float* pos4, hipStream_t st) {
   if (B <= 0) return 0;
   hipLaunchKernelGGL(block3d_pos_kernel, dim3(B), dim3(64), 0, st, pos, mask, n, n_layers, pos4, (long long)B * n * 4);
+  return 0;
+}
+
+int launch_block3d_dist_stats(const float* pos4, const uint8_t* mask, const float* dvec, const int* rows, const int* row_count,
+                              float* rowstatD, float* rowaggD, int B, int n, int de, int n_layers, hipStream_t st) {
+  const int M = B * n;
+  if (M <= 0 || n_layers <= 0) return 0;
+  hipLaunchKernelGGL(block3d_dist_stats_kernel, dim3((M + 3) / 4, n_layers), dim3(256), 0, st, pos4, mask, dvec, rows, row_count,
+                     rowstatD, rowaggD, M, n, de);
   return 0;
 }
 

@@ -51,6 +51,18 @@ struct Layer3 {
   RowLin nl, out, ex, px, x_out, linX1, linX2;
 };
 
+// [w_dist | w_cos | b_dist + b_n1 + b_n2 | w_n1 | w_n2] of one layer (the same folding as the edge kernel's LDS image)
+__global__ void dvec_kernel(const float* W_dist, const float* b_dist, const float* W_n1, const float* b_n1, const float* W_n2,
+                            const float* b_n2, float* out, int de) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= de) return;
+  out[c] = W_dist[2 * c];
+  out[de + c] = W_dist[2 * c + 1];
+  out[2 * de + c] = (b_dist[c] + b_n1[c]) + b_n2[c];
+  out[3 * de + c] = W_n1[c];
+  out[4 * de + c] = W_n2[c];
+}
+
 __global__ void vec_sum4_kernel(const float* a, const float* b, const float* c, const float* d, float* out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = ((a[i] + b[i]) + c[i]) + d[i];
@@ -69,6 +81,7 @@ struct scgg_denoiser3d {
   size_t arena_bytes = 0;
   f32x4_t *in_E_img = nullptr, *out_E_img = nullptr, *rad_img = nullptr;
   RowLin in_X2, pos2, out_X1;      // mlp_in_X.3, mlp_in_pos_high_dim.3, mlp_out_X.0
+  float* dvec = nullptr;           // [n_layers][5][de]: the distance-feature vectors of every layer (block3d_dist_stats_kernel)
   std::vector<Layer3> layers;
 };
 
@@ -154,6 +167,7 @@ int build3(scgg_denoiser3d* h, bool fill, hipStream_t st) {
   if (pack_rowlin_named(h, ar, fill, "mlp_in_pos_high_dim.3", dx, c.hid_X, h->pos2, st)) return -1;
   if (pack_rowlin_named(h, ar, fill, "mlp_out_X.0", c.hid_X, dx, h->out_X1, st)) return -1;
   h->layers.resize(c.n_layers);
+  h->dvec = ar.take<float>((size_t)c.n_layers * 5 * de);
   const int NL = 3 * dx + 2 * de, FL = 2 * de + 2 * dx, kcat = dy + 4 * dx + 8 * de;
   for (int l = 0; l < c.n_layers; ++l) {
     Layer3& L = h->layers[l];
@@ -207,6 +221,8 @@ int build3(scgg_denoiser3d* h, bool fill, hipStream_t st) {
       for (const float* q : all)
         if (!q) return -1;
       if (launch_block3d_pack(a, dx, de, c.dim_ffE, st)) return fail("3D edge pack failed");
+      hipLaunchKernelGGL(dvec_kernel, dim3((de + 255) / 256), dim3(256), 0, st, a.W_dist, a.b_dist, a.W_n1, a.b_n1, a.W_n2, a.b_n2,
+                         h->dvec + (size_t)l * 5 * de, de);
     }
     const char* nl[5] = {"q", "k", "v", "x_e_mul1", "x_e_mul2"};
     int r0 = 0;
@@ -255,7 +271,7 @@ int build3(scgg_denoiser3d* h, bool fill, hipStream_t st) {
 }
 
 struct Work3 {
-  float *X, *X1, *nodelin, *film, *pos4, *E0, *E1, *attn, *stat, *wvcat, *rowstat, *rowagg, *t_out, *t_ex, *t_px, *newX, *t_ff,
+  float *X, *X1, *nodelin, *film, *pos4, *E0, *E1, *attn, *stat, *wvcat, *rowstat, *rowagg, *rowstatD, *rowaggD, *t_out, *t_ex, *t_px, *newX, *t_ff,
       *y, *y1, *zcat, *etoy, *yt1, *yt2, *hidX, *hidy, *xo;
   int *rows, *row_count, *units, *unit_count, *goff, *chunk_cnt;
   size_t bytes;
@@ -279,6 +295,8 @@ Work3 carve3(const scgg_denoiser3d_config& c, int B, int n, char* base) {
   w.wvcat = ar.take<float>(M * (size_t)c.n_head * dx);
   w.rowstat = ar.take<float>(M * 8 * de);
   w.rowagg = ar.take<float>(M * 8 * de);
+  w.rowstatD = ar.take<float>((size_t)c.n_layers * M * 4 * de);
+  w.rowaggD = ar.take<float>((size_t)c.n_layers * M * 4 * de);
   w.t_out = ar.take<float>(M * dx);
   w.t_ex = ar.take<float>(M * dx);
   w.t_px = ar.take<float>(M * dx);
@@ -348,6 +366,7 @@ int run3(scgg_denoiser3d* h, const float* X, const float* E, const float* y, con
   TRY(launch_build_lists(mask, B, n, w.goff, w.rows, w.row_count, w.units, w.unit_count, st));
   TRY(launch_block3d_chunk_count(mask, B, n, w.chunk_cnt, st));
   TRY(launch_block3d_pos(pos, mask, B, n, c.n_layers, w.pos4, st));
+  TRY(launch_block3d_dist_stats(w.pos4, mask, h->dvec, w.rows, w.row_count, w.rowstatD, w.rowaggD, B, n, de, c.n_layers, st));
   // ---- input MLPs (:451-461).  Hidden E is stored unsymmetrised; every consumer symmetrises and masks on load.
   {
     EdgeMlpUnitArgs a{E, nullptr, mask, h->in_E_img, w.E0, w.units, w.unit_count, B, n, c.in_E, 0};
@@ -464,10 +483,10 @@ int run3(scgg_denoiser3d* h, const float* X, const float* E, const float* y, con
       TRY(launch_block3d_row_merge(r, M, st));
       TRY(rowlin_named(L.out, sa + "out", w.wvcat, H * dx, w.t_out, dx, dx, H * dx, false));
       TRY(rowlin_named(L.ex, sa + "e_x_mul.lin", w.rowstat, 8 * de, w.t_ex, dx, dx, 4 * de, false));
-      TRY(rowlin_named(L.px, sa + "pos_x_mul.lin", w.rowstat + 4 * de, 8 * de, w.t_px, dx, dx, 4 * de, false));
+      TRY(rowlin_named(L.px, sa + "pos_x_mul.lin", w.rowstatD + (size_t)l * M * 4 * de, 4 * de, w.t_px, dx, dx, 4 * de, false));
       TRY(launch_block3d_newx(w.t_out, w.t_ex, w.t_px, mask, film, FL, 2 * de, w.newX, M, n, dx, st));
       if (L.predicts_y) {   // y(l+1) and the FiLM vectors of layer l+1 (into the other buffer: film(l) is still being read)
-        GraphMerge3DArgs g{w.rowagg, mask, w.newX, w.zcat, w.etoy, kcat, n, dx, de, dy};
+        GraphMerge3DArgs g{w.rowagg, w.rowaggD + (size_t)l * M * 4 * de, mask, w.newX, w.zcat, w.etoy, kcat, n, dx, de, dy};
         TRY(launch_block3d_graph_merge(g, B, st));
         TRY(y_round(l, true, film_buf[(l + 1) & 1]));
       }

@@ -277,7 +277,7 @@ struct Block3DArgs {
   const float* pos4;      // [B*n, 4]: masked, re-centred positions of this layer and their norms
   const f32x4_t* img;
   float* attn_part;       // [B*n*nch][n_head*dx + 32]: sum p V per head | max (16) | sum p (16)
-  float* stat_part;       // [B*n*nch][8*de]: Y: mean | M2 | min | max, dist1: the same, over the unit's valid keys
+  float* stat_part;       // [B*n*nch][8*de], first half used: mean | M2 | min | max of Y over the unit's valid keys
   const int* units;
   const int* unit_count;
   int B, n, n_head, need_attn;   // need_attn: bit 0 = attention partials, bit 1 = statistics partials
@@ -290,14 +290,15 @@ struct RowMerge3DArgs {
   const float* film;
   int ldf;
   float* wvcat;           // [B*n, n_head*dx]
-  float* rowstat;         // [B*n, 8*de]: EtoX inputs of E1 | of dist1  ([mean|min|max|var] each)
-  float* rowagg;          // [B*n, 8*de]: (mean, M2, min, max) of Y | of dist1 over the row's valid keys
+  float* rowstat;         // [B*n, 8*de], first half used: EtoX input of E1 ([mean|min|max|var])
+  float* rowagg;          // [B*n, 8*de], first half used: (mean, M2, min, max) of Y over the row's valid keys
   const int* rows;
   const int* row_count;
   int n, n_head, dx, de;
 };
 struct GraphMerge3DArgs {
-  const float* rowagg;
+  const float* rowagg;    // [B*n, 8*de], first half used: (mean, M2, min, max) of Y
+  const float* rowaggD;   // [B*n, 4*de]: the same of dist1 (block3d_dist_stats_kernel, this layer's slice)
   const uint8_t* mask;
   const float* newX;      // [B,n,dx], padded rows included
   float* zcat;            // [B, ldz]: columns [dy, dy+4dx) <- Xtoy inputs
@@ -312,6 +313,8 @@ int launch_block3d_newx(const float* outv, const float* ex, const float* px, con
                         int film_off, float* newX, int M, int n, int dx, hipStream_t st);
 int launch_block3d_graph_merge(const GraphMerge3DArgs& a, int B, hipStream_t st);
 int launch_block3d_pos(const float* pos, const uint8_t* mask, int B, int n, int n_layers, float* pos4, hipStream_t st);
+int launch_block3d_dist_stats(const float* pos4, const uint8_t* mask, const float* dvec, const int* rows, const int* row_count,
+                              float* rowstatD, float* rowaggD, int B, int n, int de, int n_layers, hipStream_t st);
 int launch_block3d_chunk_count(const uint8_t* mask, int B, int n, int* cnt, hipStream_t st);
 
 }  // namespace scgg
