@@ -752,9 +752,95 @@ def gen_graph3d(R):
          False, onehot_C=5)
 
 
+def gen_training_3d(R):
+    """G10: the loss and every parameter gradient of one training step through the class the driver builds
+    (Graph3DTransformer, train mode with every Dropout switched off, TrainLoss with the radius term,
+    train_metrics.py:25-85, lambda_train = [1, 2, 5, 0]) on a given noisy state (apply_noise itself is pinned by F10).
+    Tiny dims, graphs of at most 25 nodes (torch.cdist takes differences there)."""
+    import torch.nn as nn
+
+    class Metric(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+            self._defaults = {}
+
+        def add_state(self, name, default, dist_reduce_fx=None):
+            self._defaults[name] = default
+            setattr(self, name, default.clone())
+
+        def reset(self):
+            for k, v in self._defaults.items():
+                setattr(self, k, v.clone())
+
+        def forward(self, *a, **k):
+            self.reset()
+            self.update(*a, **k)
+            return self.compute()
+
+    class MSE(Metric):                         # torchmetrics.MeanSquaredError: sum of squared errors / number of elements
+        def __init__(self, *a, **k):
+            super().__init__()
+            self.add_state("sse", torch.tensor(0.0))
+            self.add_state("n", torch.tensor(0.0))
+
+        def update(self, preds, target):
+            self.sse = self.sse + ((preds - target) ** 2).sum()
+            self.n = self.n + target.numel()
+
+        def compute(self):
+            return self.sse / self.n
+    sys.modules["torchmetrics"].Metric = Metric
+    sys.modules["torchmetrics"].MeanSquaredError = MSE
+    sys.modules["torchmetrics"].MetricCollection = Metric
+    for mod in ("src.ConStruct.metrics.train_metrics", "src.ConStruct.metrics.abstract_metrics"):
+        sys.modules.pop(mod, None)
+    from src.ConStruct.metrics import train_metrics as TL
+    from src.ConStruct.models import pos_transformer_model as P3
+    C, n_nodes, dims, n_layers = 5, [11, 6, 9, 2], fx.TINY_DIMS, 2
+    mask = fx.ragged_mask(n_nodes)
+    B, n = mask.shape
+    lab0 = _spanning_tree_labels(n_nodes, n, C, 411)
+    E0 = fx.one_hot_edges(lab0, mask, C)
+    X0 = mask[..., None].float()
+    g = torch.Generator().manual_seed(412)
+    pos = torch.randn(B, n, 3, generator=g)
+    rad0 = (torch.rand(B, n, n, generator=g) + 0.2)
+    rad0 = (0.5 * (rad0 + rad0.transpose(1, 2)) * (lab0 > 0))[..., None]
+    dense = R.U.PlaceHolder(X=X0, charges=torch.zeros(B, n, 0), E=E0, y=torch.zeros(B, 0), node_mask=mask, pos=pos, radius=rad0)
+    lab_t = torch.where(torch.rand(B, n, n, generator=g) < 0.5, lab0, torch.zeros_like(lab0))      # a noisy state: half the edges absorbed
+    lab_t = torch.triu(lab_t, 1)
+    lab_t = lab_t + lab_t.transpose(1, 2)
+    Et = fx.one_hot_edges(lab_t, mask, C)
+    t = torch.rand(B, 1, generator=g)
+    model = P3.Graph3DTransformer(n_layers=n_layers, input_dims=fx.dims_ns(1, C, 1), hidden_mlp_dims=dims["hidden_mlp_dims"],
+                                  hidden_dims=dims["hidden_dims"], output_dims=fx.dims_ns(1, C, 0), dropout=0.0).train()
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = fx.make_state_dict(shapes, seed=413)
+    model.load_state_dict(sd)
+    pred = model(R.U.PlaceHolder(X=X0, E=Et, y=t, pos=pos, radius=torch.zeros(B, n, n, 1), node_mask=mask))
+    loss, _ = TL.TrainLoss(lambda_train=[1, 2, 5, 0])(masked_pred=pred, masked_true=dense, log=False)
+    loss.backward()
+    grads, unused = {}, []
+    for k, p_ in model.named_parameters():
+        if p_.grad is None:
+            unused.append(k)
+        elif p_.grad.numel() <= 4096:
+            grads["grad/" + k] = p_.grad
+        else:
+            grads["gradhead/" + k] = p_.grad.flatten()[:1024]
+            grads["gradstat/" + k] = torch.stack([p_.grad.double().norm(), p_.grad.double().sum()])
+    save("g10_training_3d_tiny", node_mask=mask, C=C, n_layers=n_layers, labels0=lab0, labels_t=lab_t, t=t, pos=pos, radius0=rad0,
+         logits_E=pred.E.detach(), logits_X=pred.X.detach(), radius=pred.radius.detach(), loss=loss.detach(), sd_seed=413,
+         unused=np.array(unused), **grads)
+    print(f"g10: loss {float(loss.detach()):.6f}, {len(unused)} parameters without gradient")
+
+
 def main():
     R = import_reference()
-    extra = {"graph3d": gen_graph3d, "training": gen_training, "extra_large": gen_extra_features_large, "gt_large": gen_graph_transformer_large}
+    extra = {"training_3d": gen_training_3d, "graph3d": gen_graph3d, "training": gen_training, "extra_large": gen_extra_features_large, "gt_large": gen_graph_transformer_large}
     if len(sys.argv) == 2 and sys.argv[1] in extra:
         return extra[sys.argv[1]](R)
     if sys.argv[1:] == ["projector"]:
@@ -775,6 +861,7 @@ def main():
     gen_extra_features_large(R)
     gen_graph_transformer_large(R)
     gen_graph3d(R)
+    gen_training_3d(R)
 
 
 if __name__ == "__main__":

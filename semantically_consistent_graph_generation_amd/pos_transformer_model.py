@@ -5,7 +5,8 @@ and the same ``forward(model_input) -> PlaceHolder`` contract (pos_transformer_m
 of the two at diffusion_model_discrete_3d.py:111-132).
 
 Only the parameter containers live here.  The arithmetic of forward runs in libscgg.so (HIP, gfx950) through
-``scgg_denoiser3d_forward``; there is no eager fallback and no training-mode forward (eval only).
+``scgg_denoiser3d_forward``; there is no eager fallback for inference.  In training mode ``forward`` is the differentiable
+device-tensor forward of ``training.train_forward_3d`` (dropout through the Philox kernel), as for the 2D class.
 """
 from __future__ import annotations
 
@@ -88,6 +89,7 @@ class Graph3DTransformer(nn.Module):
         if self.predicts_final_y:
             raise _lib.ScggError("output_dims.y > 0: the reference class has no mlp_out_y (pos_transformer_model.py:479-481)")
         self.hidden_mlp_dims, self.hidden_dims = dict(hidden_mlp_dims), dict(hidden_dims)
+        self.dropout, self.dropout_in_and_out = dropout, dropout_in_and_out
         hm, hd = self.hidden_mlp_dims, self.hidden_dims
         self.mlp_in_X = _two_linears(self.in_dim_X, hm["X"], hd["dx"])
         self.mlp_in_E = _two_linears(self.in_dim_E, hm["E"], hd["de"])
@@ -159,8 +161,6 @@ class Graph3DTransformer(nn.Module):
         X, E, y, pos, m = mi.X, mi.E, mi.y, mi.pos, mi.node_mask
         if not X.is_cuda:
             raise _lib.ScggError("Graph3DTransformer.forward runs on the MI355X only; move the inputs to the GPU")
-        if self.training:
-            raise _lib.ScggError("Graph3DTransformer: only the eval-mode forward is built (call .eval())")
         B, n = X.shape[0], X.shape[1]
         if X.shape[2] != self.in_dim_X or E.shape[3] != self.in_dim_E or y.shape[1] != self.in_dim_y or pos.shape != (B, n, 3):
             raise _lib.ScggError(f"input widths {X.shape[2]},{E.shape[3]},{y.shape[1]}, pos {tuple(pos.shape)} do not match the "
@@ -169,11 +169,22 @@ class Graph3DTransformer(nn.Module):
         return f(X), f(E), f(y), f(pos), m.to(torch.bool).contiguous(), B, n
 
     # ------------------------------------------------------------------------------------------------- forward
-    @torch.no_grad()
+    dropout_seed = None     # training mode: seed of the Philox dropout masks of the next forward (None: no dropout)
+
     def forward(self, model_input):
         """model_input: .X[B,n,dX] .E[B,n,n,dE] .y[B,dy] .pos[B,n,3] .radius (None: no radius head) .node_mask[B,n]
         -> PlaceHolder(pos, X, charges, E, y=None, node_mask, radius), masked as the reference's final ``.mask()`` does
-        (pos masked and centred over all n rows, utils.py:160-164)."""
+        (pos masked and centred over all n rows, utils.py:160-164).  Eval mode: the fused HIP engine, no autograd.  Training
+        mode: the differentiable forward of training.py (device tensor ops + the dropout kernel)."""
+        if self.training:
+            from .training import train_forward_3d
+            return train_forward_3d(self, model_input.X.float(), model_input.E.float(), model_input.y.float(),
+                                    model_input.pos.float(), model_input.node_mask,
+                                    with_radius=getattr(model_input, "radius", None) is not None, seed=self.dropout_seed)
+        return self._forward_eval(model_input)
+
+    @torch.no_grad()
+    def _forward_eval(self, model_input):
         X, E, y, pos, m, B, n = self._inputs(model_input)
         eng = self._ensure_engine(X.device)
         ws, ws_bytes = self._workspace(B, n, X.device)

@@ -105,7 +105,9 @@ class TrainLoss(torch.nn.Module):
         super().__init__()
         self.lambda_train = tuple(float(v) for v in lambda_train)
 
-    def forward(self, pred, true_X_labels, true_E_labels, node_mask):
+    def forward(self, pred, true_X_labels, true_E_labels, node_mask, true_radius=None):
+        """``true_radius`` [B,n,n,1] (the clean data's edge radii): adds the reference's radius term, the mean squared error
+        over the valid off-diagonal pairs scaled like the edge term (train_metrics.py:45-53, :76-83)."""
         n = node_mask.shape[1]
         eye = torch.eye(n, dtype=torch.bool, device=node_mask.device)[None]
         live = node_mask[:, :, None] & node_mask[:, None, :] & ~eye
@@ -113,7 +115,10 @@ class TrainLoss(torch.nn.Module):
         tX = torch.where(node_mask, true_X_labels.to(torch.int8), torch.full_like(true_X_labels, -1, dtype=torch.int8))
         loss_X = masked_cross_entropy(pred.X, tX)
         loss_E = masked_cross_entropy(pred.E, tE)
-        return self.lambda_train[0] * loss_X + self.lambda_train[2] * loss_E
+        loss = self.lambda_train[0] * loss_X + self.lambda_train[2] * loss_E
+        if true_radius is not None and getattr(pred, "radius", None) is not None and bool(live.any()):
+            loss = loss + self.lambda_train[2] * ((pred.radius[live] - true_radius[live]) ** 2).mean()
+        return loss
 
 
 # ------------------------------------------------------------------------------------------------- train-mode forward
@@ -212,6 +217,110 @@ def train_forward(model, X, E, y, node_mask, seed=None, p_layer=None):
     oy = mlp_out(model.mlp_out_y, hy) + y[..., : model.out_dim_y] if model.predicts_final_y else None
     oX, oE = _mask_xe(oX, oE, m, offdiag)
     return PlaceHolder(X=oX[..., : model.out_dim_X], charges=oX[..., model.out_dim_X:], E=oE, y=oy, node_mask=node_mask)
+
+
+def _row_stats(E, m):
+    """EtoX pooling (layers.py:60-69): per query row over the keys, mask on the key only."""
+    w = m[:, None, :, None]
+    cnt = w.sum(dim=2)
+    mean = E.sum(dim=2) / cnt
+    big = 1e5 * (1.0 - w)
+    var = (((E - mean[:, :, None, :]) ** 2) * w).sum(dim=2) / cnt
+    return torch.cat([mean, (E + big).min(dim=2).values, (E - big).max(dim=2).values, var], dim=2)
+
+
+def _recentre(pos, m):
+    pos = pos * m[:, :, None]
+    return pos - pos.mean(dim=1, keepdim=True)
+
+
+def _block3d(a, X, E, y, pos, m, node_mask):
+    """The position-aware NodeEdgeBlock.forward (pos_transformer_model.py:106-209) on the parameter holder ``a``."""
+    xm = m[:, :, None]
+    pm = (m[:, :, None] * m[:, None, :])[..., None]
+    pos = pos * xm
+    norm = torch.linalg.vector_norm(pos, dim=-1, keepdim=True)
+    unit = pos / (norm + 1e-7)
+    diff = pos[:, :, None, :] - pos[:, None, :, :]
+    info = torch.cat([torch.sqrt((diff * diff).sum(-1, keepdim=True)), (unit[:, None] * unit[:, :, None]).sum(-1, keepdim=True)], dim=-1)
+    dist1 = torch.relu(_lin(a.lin_dist1, info) + _lin(a.lin_norm_pos1, norm)[:, :, None, :] + _lin(a.lin_norm_pos2, norm)[:, None, :, :]) * pm
+    Y = _lin(a.in_E, E) * (_lin(a.x_e_mul1, X) * xm)[:, None, :, :] * (_lin(a.x_e_mul2, X) * xm)[:, :, None, :] * pm
+    Y = (Y + _lin(a.dist_add_e, dist1) + Y * _lin(a.dist_mul_e, dist1)) * pm
+    E1 = (Y + _lin(a.y_e_add, y)[:, None, None, :] + Y * _lin(a.y_e_mul, y)[:, None, None, :]) * pm
+    Eout = _lin(a.e_out, E1) * pm
+    Q, K, V = _lin(a.q, X) * xm, _lin(a.k, X) * xm, _lin(a.v, X) * xm
+    att = F.linear(Q[:, :, None, :] * K[:, None, :, :] / math.sqrt(a.de), a.a.weight) * pm
+    att = att + _lin(a.e_att_mul, E1) * att
+    att = att + _lin(a.pos_att_mul, dist1) * att
+    att = att * pm
+    alpha = torch.softmax(att.masked_fill(~node_mask[:, None, :, None], float("-inf")), dim=2)
+    wV = torch.einsum("bijh,bjd->bihd", alpha, V).flatten(start_dim=2)
+    wV = _lin(a.out, wV) * xm
+    wV = wV + _lin(a.e_x_mul.lin, _row_stats(E1, m)) * wV
+    wV = wV + _lin(a.pos_x_mul.lin, _row_stats(dist1, m)) * wV
+    newX = wV * (_lin(a.y_x_mul, y)[:, None, :] + 1.0) + _lin(a.y_x_add, y)[:, None, :]
+    Xout = _lin(a.x_out, newX) * xm
+    new_y = None
+    if a.predicts_y:
+        z = (_lin(a.y_y, y) + _lin(a.x_y.lin, _node_stats(newX, m)) + _lin(a.e_y.lin, _edge_stats(Y, m))
+             + _lin(a.dist_y.lin, _edge_stats(dist1, m)))          # _node_stats sums every row: the unmasked-newX quirk (:202)
+        new_y = _lin(a.y_out[2], torch.relu(_lin(a.y_out[0], z)))
+    return Xout, Eout, new_y
+
+
+def train_forward_3d(model, X, E, y, pos, node_mask, with_radius=True, seed=None, p_layer=None):
+    """Graph3DTransformer.forward / EquivariantGraph3DTransformer.forward in training mode (pos_transformer_model.py:433-493
+    with the dropout sites of :275-297 and :365-428), differentiable: device tensor ops under autograd over the parameter
+    tensors the fused inference engine borrows (as ``train_forward`` for the 2D class).  The layers drop with the
+    reference's hard-wired 0.1 (the classes do not pass ``dropout`` on, :400-407).  Dropout sites: in-MLPs 0..7 (E, X or pos,
+    y; two each, then the node head's mlp_in_X), layer l: 100 + 16 l + (0..8), out-MLPs 50.. (X, E, radius)."""
+    if not X.is_cuda:
+        raise _lib.ScggError("the training forward runs on the MI355X only; move the inputs to the GPU")
+    p_layer = 0.1 if p_layer is None else p_layer
+    p_io = model.dropout if model.dropout_in_and_out else 0.0
+    dio, dl = DropoutSites(p_io, seed), DropoutSites(p_layer, seed)
+    node_mask = node_mask.bool()
+    m = node_mask.to(X.dtype)
+    n = X.shape[1]
+    offdiag = (1.0 - torch.eye(n, dtype=X.dtype, device=X.device))[None]
+    oXc = model.out_dim_X + model.out_dim_charges
+    pos = pos.detach()
+
+    def mlp_in(seq, x):        # Linear, ReLU, Dropout, Linear, then ReLU / Dropout in either order (same result for one mask)
+        return dio(torch.relu(_lin(seq[3], dio(torch.relu(_lin(seq[0], x))))))
+
+    def mlp_out(seq, x):
+        return _lin(seq[3], dio(torch.relu(_lin(seq[0], x))))
+    hE = mlp_in(model.mlp_in_E, E)
+    hE = (hE + hE.transpose(1, 2)) / 2
+    hX = mlp_in(model.mlp_in_X, X) if model.equivariant else mlp_in(model.mlp_in_pos_high_dim, pos)
+    hy = mlp_in(model.mlp_in_y, y)
+    hX, hE = _mask_xe(hX, hE, m, offdiag)
+    hpos = _recentre(pos, m)
+    for l, layer in enumerate(model.tf_layers):
+        dl.site = 100 + 16 * l
+        newX, newE, new_y = _block3d(layer.self_attn, hX, hE, hy, hpos, m, node_mask)
+        hX = _ln(layer.normX1, hX + dl(newX))
+        hE = _ln(layer.normE1, hE + dl(newE))
+        hX = _ln(layer.normX2, hX + dl(_lin(layer.linX2, dl(torch.relu(_lin(layer.linX1, hX))))))
+        hE = _ln(layer.normE2, hE + dl(_lin(layer.linE2, dl(torch.relu(_lin(layer.linE1, hE))))))
+        hE = 0.5 * (hE + hE.transpose(1, 2))
+        if layer.predicts_y:
+            hy = _ln(layer.norm_y1, hy + dl(new_y))
+            hy = _ln(layer.norm_y2, hy + dl(_lin(layer.lin_y2, dl(torch.relu(_lin(layer.lin_y1, hy))))))
+        hX, hE = _mask_xe(hX, hE, m, offdiag)
+        hpos = _recentre(hpos, m)
+    dio.site = 50
+    oX = mlp_out(model.mlp_out_X, hX if model.equivariant else mlp_in(model.mlp_in_X, X)) + X[..., :oXc]
+    oE = (mlp_out(model.mlp_out_E, hE) + E[..., : model.out_dim_E]) * offdiag[..., None]
+    oE = 0.5 * (oE + oE.transpose(1, 2))
+    oX, oE = _mask_xe(oX, oE, m, offdiag)
+    rad = None
+    if with_radius:
+        rad = mlp_out(model.mlp_out_radius, hE) * offdiag[..., None]
+        rad = 0.5 * (rad + rad.transpose(1, 2)) * (m[:, :, None] * m[:, None, :])[..., None]
+    return PlaceHolder(pos=_recentre(pos, m), X=oX[..., : model.out_dim_X], charges=oX[..., model.out_dim_X:], E=oE, y=None,
+                       node_mask=node_mask, radius=rad)
 
 
 # ------------------------------------------------------------------------------------------------- the step
