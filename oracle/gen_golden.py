@@ -838,9 +838,60 @@ def gen_training_3d(R):
     print(f"g10: loss {float(loss.detach()):.6f}, {len(unused)} parameters without gradient")
 
 
+def gen_sit(R):
+    """H1: the reference's SiT-T denoiser of the node-coordinate DDPM (sit_model.py) on ragged batches.  ``timm`` is absent
+    here; sit_model.py takes two things from it: the CONSTRUCTOR of ``Attention`` (the forward is the reference's own
+    ``AttentionWithPads.forward``) and ``Mlp``.  The stand-in below states their published layout -- qkv / proj Linears,
+    head scale, fc1 / activation / fc2 -- and nothing else; every line of arithmetic that runs, apart from Mlp's
+    fc2(act(fc1(x))), is the reference's.  Weights: make_state_dict (NOT the zero adaLN initialisation, which would make
+    every block the identity)."""
+    import torch.nn as nn
+
+    class Attention(nn.Module):
+        def __init__(self, dim, num_heads=8, qkv_bias=False, **kw):
+            super().__init__()
+            self.num_heads = num_heads
+            self.scale = (dim // num_heads) ** -0.5
+            self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+            self.attn_drop = nn.Dropout(0.0)
+            self.proj = nn.Linear(dim, dim)
+            self.proj_drop = nn.Dropout(0.0)
+
+    class Mlp(nn.Module):
+        def __init__(self, in_features, hidden_features=None, act_layer=nn.GELU, drop=0.0, **kw):
+            super().__init__()
+            self.fc1 = nn.Linear(in_features, hidden_features)
+            self.act = act_layer()
+            self.fc2 = nn.Linear(hidden_features, in_features)
+
+        def forward(self, x):
+            return self.fc2(self.act(self.fc1(x)))
+    timm = types.ModuleType("timm")
+    timm.models = types.ModuleType("timm.models")
+    timm.models.vision_transformer = types.ModuleType("timm.models.vision_transformer")
+    timm.models.vision_transformer.Attention = Attention
+    timm.models.vision_transformer.Mlp = Mlp
+    sys.modules.update({"timm": timm, "timm.models": timm.models, "timm.models.vision_transformer": timm.models.vision_transformer})
+    from src.bootstrap.node_coordinate_diffusion import sit_model as SM
+    for name, n_nodes, seed in (("a", [9, 5, 2, 12], 501), ("b", [40, 33], 502)):
+        torch.manual_seed(seed)
+        model = SM.SiT_models["SiT-T"](in_channels=3).eval()
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        sd = fx.make_state_dict(shapes, seed=seed)
+        model.load_state_dict(sd)
+        mask = fx.ragged_mask(n_nodes)
+        B, n = mask.shape
+        x = torch.randn(B, n, 3)
+        t = torch.tensor([999, 500, 1, 37][:B] if B == 4 else [250, 3])
+        with torch.no_grad():
+            out = model(x, t, mask)
+        save(f"h1_sit_{name}", x=x, t=t, node_mask=mask, out=out, seed=seed, shape_keys=np.array(sorted(shapes)),
+             shape_vals=np.array([",".join(map(str, shapes[k])) for k in sorted(shapes)]))
+
+
 def main():
     R = import_reference()
-    extra = {"training_3d": gen_training_3d, "graph3d": gen_graph3d, "training": gen_training, "extra_large": gen_extra_features_large, "gt_large": gen_graph_transformer_large}
+    extra = {"sit": gen_sit, "training_3d": gen_training_3d, "graph3d": gen_graph3d, "training": gen_training, "extra_large": gen_extra_features_large, "gt_large": gen_graph_transformer_large}
     if len(sys.argv) == 2 and sys.argv[1] in extra:
         return extra[sys.argv[1]](R)
     if sys.argv[1:] == ["projector"]:
@@ -862,6 +913,7 @@ def main():
     gen_graph_transformer_large(R)
     gen_graph3d(R)
     gen_training_3d(R)
+    gen_sit(R)
 
 
 if __name__ == "__main__":

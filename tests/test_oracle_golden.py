@@ -315,3 +315,15 @@ def test_graph3d_transformer(name, dims, equivariant):
     # the positions handed back are the model's input through one mask() (:455, :492), not the layers' drifting copy
     close(D3.recentre(T(g["pos"]), T(g["node_mask"])), g["out_pos"], 1e-5, 1e-6)
     assert (hidden[-1][3] - hidden[0][3]).abs().max() > 1e-3      # ragged batch: the layers did see shifted positions
+
+
+# ---- row f3: the SiT-T denoiser of the node-coordinate DDPM (oracle/sit.py)
+@pytest.mark.parametrize("name", ["h1_sit_a", "h1_sit_b"])
+def test_sit_forward(name):
+    from oracle import sit as S
+    g = load_golden(name)
+    sd = fx.make_state_dict(golden_shapes(g), int(g["seed"]))
+    m = T(g["node_mask"])
+    out = S.sit_forward(sd, T(g["x"]), T(g["t"]), m)
+    # padded query rows attend uniformly over every slot in the reference (all their scores are -1e9); they are compared too
+    close(out, g["out"], 1e-4, 1e-5)
