@@ -148,6 +148,42 @@ int scgg_denoiser3d_forward_hidden(scgg_denoiser3d* h, const float* X, const flo
                                    float* hid_E, float* hid_y, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Node-coordinate DDPM: the SiT-T denoiser (src/bootstrap/node_coordinate_diffusion/sit_model.py:157-247, blocks :112-134,
+ * AttentionWithPads :80-103, TimestepEmbedder :41-77) and the ancestral sampler NodeCoordsDiffusionModel.sample
+ * (cow_diff_nodes_with_3d_checks.py:63-81, schedule :22-46), which sample_limit_dist calls once per sampled batch
+ * (src/ConStruct/diffusion/noise_model.py:323-325).  Same life cycle as scgg_denoiser: create, set_param per state_dict
+ * name ("blocks.0.attn.qkv.weight", ...), finalize (also builds the per-timestep modulation tables: the only allocation).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct scgg_sit scgg_sit;
+typedef struct scgg_sit_config {
+  int32_t in_channels;                 /* 3 */
+  int32_t hidden, n_blocks, n_heads;   /* SiT-T: 192, 6, 6 (sit_model.py:271) */
+  int32_t mlp_hidden;                  /* int(hidden * mlp_ratio) = 768 */
+  int32_t noise_steps;                 /* 1000 */
+  float beta_start, beta_end;          /* 1e-4, 0.02: torch.linspace schedule (cow_diff_nodes_with_3d_checks.py:22-46) */
+} scgg_sit_config;
+
+scgg_sit* scgg_sit_create(const scgg_sit_config* cfg);          /* NULL on unsupported dims */
+void scgg_sit_destroy(scgg_sit* h);
+int scgg_sit_set_param(scgg_sit* h, const char* name, const float* data, int64_t numel);
+int scgg_sit_finalize(scgg_sit* h, void* stream);
+size_t scgg_sit_workspace_bytes(const scgg_sit* h, int32_t B, int32_t n);
+
+/* replaces SiT.forward(x, t, padding_mask) (sit_model.py:228-247): x[B,n,3], t[B] int32 timesteps in [0, noise_steps),
+ * node_mask[B,n] -> eps_out[B,n,3] on the valid rows, 0 on padded ones (the reference lets padded tokens attend uniformly to
+ * every slot; nothing downstream reads them). */
+int scgg_sit_forward(scgg_sit* h, const float* x, const int32_t* t, const uint8_t* node_mask, int32_t B, int32_t n,
+                     float* eps_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* replaces NodeCoordsDiffusionModel.sample(pos, node_mask) (:63-81): starts from x_T[B,n,3] (the reference draws it with
+ * torch.randn inside; here the caller passes it) and runs i = noise_steps-1 .. 1 (`steps` >= 0: only the first `steps`
+ * iterations).  noise: [iterations][B,n,3] normal draws in iteration order (tests), or NULL: Philox4x32-10 + Box-Muller
+ * keyed by (seed, graph_id_base + b, node, i).  x_out[B,n,3]: valid rows, zero on padded slots. */
+int scgg_sit_sample(scgg_sit* h, const float* x_T, const uint8_t* node_mask, int32_t B, int32_t n, int32_t steps,
+                    const float* noise, uint64_t seed, uint32_t graph_id_base, float* x_out, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Reverse step: NoiseModel.sample_zs_from_zt_and_pred (src/ConStruct/diffusion/noise_model.py:342-447) with
  * sample_discrete_features (src/ConStruct/diffusion/diffusion_utils.py:200-285).  Called at
  * diffusion_model_discrete_3d.py:749.

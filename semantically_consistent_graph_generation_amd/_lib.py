@@ -25,6 +25,11 @@ class Denoiser3DConfig(C.Structure):
         "dx", "de", "dy", "n_head", "dim_ffX", "dim_ffE", "dim_ffy", "equivariant")]
 
 
+class SitConfig(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("in_channels", "hidden", "n_blocks", "n_heads", "mlp_hidden", "noise_steps")] + \
+               [("beta_start", C.c_float), ("beta_end", C.c_float)]
+
+
 class Rng(C.Structure):
     _fields_ = [("u0", C.c_void_p), ("uk", C.c_void_p), ("seed", C.c_uint64), ("step", C.c_uint32),
                 ("graph_id_base", C.c_uint32)]
@@ -53,6 +58,13 @@ SIGNATURES = {
     "scgg_denoiser3d_workspace_bytes": (_sz, [_vp, _i32, _i32]),
     "scgg_denoiser3d_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "scgg_denoiser3d_forward_hidden": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "scgg_sit_create": (_vp, [C.POINTER(SitConfig)]),
+    "scgg_sit_destroy": (None, [_vp]),
+    "scgg_sit_set_param": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),
+    "scgg_sit_finalize": (C.c_int, [_vp, _vp]),
+    "scgg_sit_workspace_bytes": (_sz, [_vp, _i32, _i32]),
+    "scgg_sit_forward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "scgg_sit_sample": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, C.c_uint64, C.c_uint32, _vp, _vp, _sz, _vp]),
     "scgg_reverse_step_edges": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                                           C.POINTER(Rng), _vp, _vp, _vp, _vp]),
     "scgg_sample_edges_from_probs": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(Rng), _vp, _vp, _vp]),

@@ -1,0 +1,497 @@
+// Node-coordinate DDPM of the reference: the SiT-T denoiser and its ancestral sampler, gfx950.
+//
+//   SiT.forward, SiTBlock (adaLN-zero), FinalLayer, TimestepEmbedder, AttentionWithPads
+//                              src/bootstrap/node_coordinate_diffusion/sit_model.py:41-77, :80-103, :112-154, :228-247
+//   NodeCoordsDiffusionModel   src/bootstrap/node_coordinate_diffusion/cow_diff_nodes_with_3d_checks.py:22-81
+//   called once per sampled batch from sample_limit_dist (src/ConStruct/diffusion/noise_model.py:323-325)
+//
+// What shapes the design: 999 ancestral steps of a SMALL transformer (6 blocks, hidden 192, 6 heads) on B graphs of n <= a
+// few dozen tokens, and every graph of a step sees the same timestep.
+//   * everything that depends on t only -- the timestep embedding, its MLP, the SiLU and the adaLN Linear of every block
+//     and of the final layer -- is computed for ALL timesteps once per weight set (finalize: GEMMs with M = noise_steps)
+//     into tables; a step reads its six vectors per block from them.
+//   * per step the dense Linears (qkv, proj, fc1, fc2) run as fp32-MFMA GEMMs over all B n rows; the glue between them is
+//     fused: [gated residual of the previous sub-layer + LayerNorm + modulate] is one kernel (16 lanes per row), attention
+//     is one wave per (graph, head) with the head's keys / values of a 64-key chunk in LDS and an online softmax (padded
+//     keys are skipped, which is exact: the reference gives them -1e9 and a valid query always has itself as a key), and
+//     [last gated residual + final LayerNorm / modulate + the 192 -> 3 Linear + the DDPM update x_{t-1} = ... + sqrt(beta) z]
+//     is one kernel.  45 launches per step, no synchronisation, no allocation.
+//   * the normal draws are Philox4x32-10 + Box-Muller keyed by (seed, graph id, node, step), or a caller-provided buffer
+//     (tests: the oracle takes the same draws).  The reference draws torch.randn from the global generator.
+// Padded tokens: the reference lets them evolve too (they attend uniformly to every slot); nothing downstream reads them
+// (sample_limit_dist masks the positions), so the step kernels work on the valid rows and leave the others at zero.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/scgg.h"
+#include "c16.h"
+#include "kernels.h"
+#include "rng.h"
+
+namespace scgg {
+namespace {
+
+// emb[t][0:half] = cos(t f_k), emb[t][half:] = sin(t f_k), f_k = exp(-ln(10000) k / half)     (sit_model.py:53-72)
+__global__ void sit_temb_kernel(float* emb, int T, int dim) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x, half = dim / 2;
+  if (idx >= T * half) return;
+  const int t = idx / half, k = idx - t * half;
+  const float f = expf(-logf(10000.0f) * (float)k / (float)half);
+  const float a = (float)t * f;
+  emb[(size_t)t * dim + k] = cosf(a);
+  emb[(size_t)t * dim + half + k] = sinf(a);
+}
+__global__ void sit_silu_kernel(const float* in, float* out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const float v = in[i]; out[i] = v / (1.0f + expf(-v)); }
+}
+// tanh-approximated GELU in place (nn.GELU(approximate="tanh"), sit_model.py:122)
+__global__ void sit_gelu_kernel(float* x, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i];
+  x[i] = 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v)));
+}
+
+struct LnModArgs {
+  float* h;              // [M,H] residual stream, updated in place when o != nullptr
+  const float* o;        // [M,H] output of the previous sub-layer (or null)
+  const float* tab;      // modulation table of this block: [T][ld]
+  int ld, off_gate, off_shift, off_scale;   // columns of the gate of the previous sub-layer / this sub-layer's shift, scale
+  const float* tab_gate; // table the gate comes from (the previous block's for a block's first sub-layer), same ld
+  float* u;              // [M,H] = LN(h) (1 + scale) + shift
+  const int* rows;
+  const int* row_count;
+  const int32_t* t;      // [B] timestep per graph, or null: t_const for all
+  int t_const, n;
+};
+
+// 16 lanes per row, F4 float4 per lane (H = 64 F4)
+template <int F4>
+__global__ __launch_bounds__(256) void sit_lnmod_kernel(LnModArgs a) {
+  constexpr int H = 64 * F4;
+  const int ridx = blockIdx.x * 16 + (threadIdx.x >> 4), p = threadIdx.x & 15;
+  const int count = *a.row_count;
+  const bool on = ridx < count;
+  const long long row = a.rows[on ? ridx : 0];
+  const int t = a.t ? a.t[row / a.n] : a.t_const;
+  f32x4 v[F4];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < F4; ++k) {
+    const int c = 64 * k + 4 * p;
+    v[k] = ld4(a.h + row * H + c);
+    if (a.o != nullptr) v[k] += ld4(a.tab_gate + (size_t)t * a.ld + a.off_gate + c) * ld4(a.o + row * H + c);
+    s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+  }
+  const float mean = row_sum16(s) * (1.0f / H);
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < F4; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float d = v[k][e] - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(row_sum16(q) * (1.0f / H) + 1e-6f);
+  if (!on) return;
+#pragma unroll
+  for (int k = 0; k < F4; ++k) {
+    const int c = 64 * k + 4 * p;
+    if (a.o != nullptr) *reinterpret_cast<f32x4*>(a.h + row * H + c) = v[k];
+    const f32x4 sh = ld4(a.tab + (size_t)t * a.ld + a.off_shift + c), sc = ld4(a.tab + (size_t)t * a.ld + a.off_scale + c);
+    f32x4 u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) u[e] = (v[k][e] - mean) * rstd * (1.0f + sc[e]) + sh[e];
+    *reinterpret_cast<f32x4*>(a.u + row * H + c) = u;
+  }
+}
+
+// One wave per (graph, head): lane = query token (64 per pass), the head's K / V rows of up to 64 valid keys in LDS, online
+// softmax.  qkv row = [q | k | v][heads][HD] (sit_model.py:87-88); out[row][head HD + d].
+template <int HD>
+__global__ __launch_bounds__(64) void sit_attn_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ mask,
+                                                      float* __restrict__ out, int n, int H, float scale) {
+  __shared__ float ks[64][HD + 1], vs[64][HD + 1];
+  const int b = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
+  const uint8_t* mb = mask + (long long)b * n;
+  const float* base = qkv + (long long)b * n * 3 * H + head * HD;
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const int i = i0 + lane;
+    const bool qon = i < n && mb[i] != 0;
+    float q[HD], acc[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { q[d] = qon ? base[(long long)i * 3 * H + d] * scale : 0.f; acc[d] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+      const int j = j0 + lane;
+      const bool kon = j < n && mb[j] != 0;
+      const unsigned long long bal = __ballot(kon);
+      const int cnt = __popcll(bal);
+      __syncthreads();
+      if (kon) {
+        const int slot = __popcll(bal & ((1ull << lane) - 1ull));
+        const float* kr = base + (long long)j * 3 * H + H;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { ks[slot][d] = kr[d]; vs[slot][d] = kr[H + d]; }
+      }
+      __syncthreads();
+      for (int c = 0; c < cnt; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) s += q[d] * ks[c][d];
+        const float mn = fmaxf(m, s), fo = __expf(m - mn), fn = __expf(s - mn);
+        l = l * fo + fn;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] = acc[d] * fo + fn * vs[c][d];
+        m = mn;
+      }
+    }
+    if (qon) {
+      float* o = out + ((long long)b * n + i) * H + head * HD;
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) o[d] = acc[d] * inv;
+    }
+  }
+}
+
+struct UpdateArgs {
+  const float* h;        // [M,H]
+  const float* o;        // [M,H] last block's MLP output
+  const float* tab_gate; // last block's table (gate_mlp at off_gate)
+  int ld_gate, off_gate;
+  const float* tabF;     // final layer's table [T][2H]: shift | scale
+  const float* Wf;       // [3,H]
+  const float* bf;       // [3]
+  const float* x;        // [M,3] current sample
+  float* x_out;          // [M,3]
+  float* eps_out;        // [M,3] predicted noise (optional: the forward-only entry point)
+  const float* noise;    // [M,3] normal draws of this step, or null: Philox
+  const int* rows;
+  const int* row_count;
+  const int32_t* t;
+  int t_const, n;
+  float c_x, c_eps, c_noise;   // x_{t-1} = c_x (x - c_eps eps) + c_noise z       (cow_diff_nodes_with_3d_checks.py:76-79)
+  int do_update;
+  uint32_t k0, k1, step, graph_id_base;
+};
+
+template <int F4>
+__global__ __launch_bounds__(256) void sit_update_kernel(UpdateArgs a) {
+  constexpr int H = 64 * F4;
+  const int ridx = blockIdx.x * 16 + (threadIdx.x >> 4), p = threadIdx.x & 15;
+  const int count = *a.row_count;
+  const bool on = ridx < count;
+  const long long row = a.rows[on ? ridx : 0];
+  const int b = (int)(row / a.n), i = (int)(row - (long long)b * a.n);
+  const int t = a.t ? a.t[b] : a.t_const;
+  f32x4 v[F4];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < F4; ++k) {
+    const int c = 64 * k + 4 * p;
+    v[k] = ld4(a.h + row * H + c) + ld4(a.tab_gate + (size_t)t * a.ld_gate + a.off_gate + c) * ld4(a.o + row * H + c);
+    s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+  }
+  const float mean = row_sum16(s) * (1.0f / H);
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < F4; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float d = v[k][e] - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(row_sum16(q) * (1.0f / H) + 1e-6f);
+  float e3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < F4; ++k) {
+    const int c = 64 * k + 4 * p;
+    const f32x4 sh = ld4(a.tabF + (size_t)t * (2 * H) + c), sc = ld4(a.tabF + (size_t)t * (2 * H) + H + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float u = (v[k][e] - mean) * rstd * (1.0f + sc[e]) + sh[e];
+#pragma unroll
+      for (int o = 0; o < 3; ++o) e3[o] += u * a.Wf[o * H + c + e];
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 3; ++o) e3[o] = row_sum16(e3[o]) + a.bf[o];
+  if (!on || p != 0) return;
+  if (a.eps_out != nullptr) { a.eps_out[row * 3] = e3[0]; a.eps_out[row * 3 + 1] = e3[1]; a.eps_out[row * 3 + 2] = e3[2]; }
+  if (!a.do_update) return;
+  float z[3] = {0.f, 0.f, 0.f};
+  if (a.c_noise != 0.f) {
+    if (a.noise != nullptr) { z[0] = a.noise[row * 3]; z[1] = a.noise[row * 3 + 1]; z[2] = a.noise[row * 3 + 2]; }
+    else {
+      uint32_t r[4];
+      philox4x32_10((uint32_t)i, a.graph_id_base + (uint32_t)b, a.step, 0x51u, a.k0, a.k1, r);
+      const float r0 = sqrtf(-2.0f * logf(1.0f - u01(r[0]))), r1 = sqrtf(-2.0f * logf(1.0f - u01(r[2])));
+      const float a0 = 6.283185307179586f * u01(r[1]), a1 = 6.283185307179586f * u01(r[3]);
+      z[0] = r0 * cosf(a0); z[1] = r0 * sinf(a0); z[2] = r1 * cosf(a1);
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 3; ++o) a.x_out[row * 3 + o] = a.c_x * (a.x[row * 3 + o] - a.c_eps * e3[o]) + a.c_noise * z[o];
+}
+
+struct ParamS { const float* p; int64_t numel; };
+struct Bump2 {
+  char* base; size_t off = 0;
+  explicit Bump2(char* b) : base(b) {}
+  template <typename T> T* take(size_t count) {
+    off = (off + 255) / 256 * 256;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+}  // namespace
+}  // namespace scgg
+
+using namespace scgg;
+
+struct scgg_sit {
+  scgg_sit_config c;
+  std::map<std::string, ParamS> params;
+  bool finalized = false;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  std::vector<float*> tab;     // per block [T][6H]
+  float* tabF = nullptr;       // [T][2H]
+  float *emb = nullptr, *t1 = nullptr, *cemb = nullptr, *csilu = nullptr;
+  std::vector<float> beta, alpha, alpha_hat;   // host copies of the schedule
+};
+
+namespace {
+
+const ParamS* findS(const scgg_sit* h, const std::string& name, int64_t numel) {
+  auto it = h->params.find(name);
+  if (it == h->params.end()) { fail("missing parameter '%s'", name.c_str()); return nullptr; }
+  if (it->second.numel != numel) {
+    fail("parameter '%s' has %lld elements, expected %lld", name.c_str(), (long long)it->second.numel, (long long)numel);
+    return nullptr;
+  }
+  return &it->second;
+}
+int gemmS(scgg_sit* h, const float* A, int lda, const std::string& name, float* C, int ldc, int M, int N, int K, hipStream_t st) {
+  const ParamS *W = findS(h, name + ".weight", (int64_t)N * K), *b = findS(h, name + ".bias", N);
+  if (!W || !b) return -1;
+  GemmArgs g{A, W->p, b->p, C, nullptr, M, N, K, lda, K, ldc, 0, 0, 0, 0, 0};
+  return launch_gemm(g, st);
+}
+int checkS(const char* what) {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail("%s: %s", what, hipGetErrorString(e));
+}
+
+constexpr int TEMB = 256;   // frequency_embedding_size (sit_model.py:45)
+
+int buildS(scgg_sit* h, bool fill, hipStream_t st) {
+  const scgg_sit_config& c = h->c;
+  const int T = c.noise_steps, H = c.hidden;
+  Bump2 ar(fill ? h->arena : nullptr);
+  h->emb = ar.take<float>((size_t)T * TEMB);
+  h->t1 = ar.take<float>((size_t)T * H);
+  h->cemb = ar.take<float>((size_t)T * H);
+  h->csilu = ar.take<float>((size_t)T * H);
+  h->tab.resize(c.n_blocks);
+  for (int i = 0; i < c.n_blocks; ++i) h->tab[i] = ar.take<float>((size_t)T * 6 * H);
+  h->tabF = ar.take<float>((size_t)T * 2 * H);
+  h->arena_bytes = (ar.off + 255) / 256 * 256;
+  if (!fill) return 0;
+  hipLaunchKernelGGL(sit_temb_kernel, dim3((T * (TEMB / 2) + 255) / 256), dim3(256), 0, st, h->emb, T, TEMB);
+  if (gemmS(h, h->emb, TEMB, "t_embedder.mlp.0", h->t1, H, T, H, TEMB, st)) return -1;
+  hipLaunchKernelGGL(sit_silu_kernel, dim3((T * H + 255) / 256), dim3(256), 0, st, h->t1, h->t1, (long long)T * H);
+  if (gemmS(h, h->t1, H, "t_embedder.mlp.2", h->cemb, H, T, H, H, st)) return -1;
+  hipLaunchKernelGGL(sit_silu_kernel, dim3((T * H + 255) / 256), dim3(256), 0, st, h->cemb, h->csilu, (long long)T * H);
+  for (int i = 0; i < c.n_blocks; ++i)
+    if (gemmS(h, h->csilu, H, "blocks." + std::to_string(i) + ".adaLN_modulation.1", h->tab[i], 6 * H, T, 6 * H, H, st)) return -1;
+  if (gemmS(h, h->csilu, H, "final_layer.adaLN_modulation.1", h->tabF, 2 * H, T, 2 * H, H, st)) return -1;
+  // every parameter the steps will ask for must be there now
+  for (int i = 0; i < c.n_blocks; ++i) {
+    const std::string p = "blocks." + std::to_string(i) + ".";
+    if (!findS(h, p + "attn.qkv.weight", (int64_t)3 * H * H) || !findS(h, p + "attn.qkv.bias", 3 * H) ||
+        !findS(h, p + "attn.proj.weight", (int64_t)H * H) || !findS(h, p + "attn.proj.bias", H) ||
+        !findS(h, p + "mlp.fc1.weight", (int64_t)c.mlp_hidden * H) || !findS(h, p + "mlp.fc1.bias", c.mlp_hidden) ||
+        !findS(h, p + "mlp.fc2.weight", (int64_t)H * c.mlp_hidden) || !findS(h, p + "mlp.fc2.bias", H)) return -1;
+  }
+  if (!findS(h, "pos_embedder.weight", (int64_t)H * c.in_channels) || !findS(h, "pos_embedder.bias", H) ||
+      !findS(h, "final_layer.linear.weight", (int64_t)c.in_channels * H) || !findS(h, "final_layer.linear.bias", c.in_channels))
+    return -1;
+  return checkS("sit tables");
+}
+
+struct WorkS {
+  float *h, *u, *qkv, *att, *o, *f, *xa, *xb;
+  int *rows, *row_count, *units, *unit_count, *goff;
+  size_t bytes;
+};
+WorkS carveS(const scgg_sit_config& c, int B, int n, char* base) {
+  Bump2 ar(base);
+  WorkS w;
+  const size_t M = (size_t)B * n, nch = (size_t)(n + 15) / 16;
+  w.h = ar.take<float>(M * c.hidden);
+  w.u = ar.take<float>(M * c.hidden);
+  w.qkv = ar.take<float>(M * 3 * c.hidden);
+  w.att = ar.take<float>(M * c.hidden);
+  w.o = ar.take<float>(M * c.hidden);
+  w.f = ar.take<float>(M * c.mlp_hidden);
+  w.xa = ar.take<float>(M * 3);
+  w.xb = ar.take<float>(M * 3);
+  w.rows = ar.take<int>(M);
+  w.row_count = ar.take<int>(64);
+  w.units = ar.take<int>(M * nch);
+  w.unit_count = ar.take<int>(64);
+  w.goff = ar.take<int>((size_t)2 * B);
+  w.bytes = (ar.off + 255) / 256 * 256;
+  return w;
+}
+
+#define TRYS(x) do { if ((x) != 0) return -1; } while (0)
+
+// one denoiser evaluation on x (and, with do_update, the DDPM step into x_out)
+int stepS(scgg_sit* h, const WorkS& w, const float* x, const uint8_t* mask, int B, int n, const int32_t* t_ptr, int t_const,
+          float* eps_out, float* x_out, int do_update, float c_x, float c_eps, float c_noise, const float* noise, uint64_t seed,
+          uint32_t step, uint32_t graph_id_base, hipStream_t st) {
+  const scgg_sit_config& c = h->c;
+  const int M = B * n, H = c.hidden, F4 = H / 64;
+  TRYS(gemmS(h, x, c.in_channels, "pos_embedder", w.h, H, M, H, c.in_channels, st));
+  auto lnmod = [&](const float* o, const float* tab_gate, int off_gate, const float* tab, int off_shift, int off_scale) -> int {
+    LnModArgs a{w.h, o, tab, 6 * H, off_gate, off_shift, off_scale, tab_gate, w.u, w.rows, w.row_count, t_ptr, t_const, n};
+    const dim3 grid((M + 15) / 16), blk(256);
+    if (F4 == 3) hipLaunchKernelGGL(sit_lnmod_kernel<3>, grid, blk, 0, st, a);
+    else if (F4 == 1) hipLaunchKernelGGL(sit_lnmod_kernel<1>, grid, blk, 0, st, a);
+    else if (F4 == 2) hipLaunchKernelGGL(sit_lnmod_kernel<2>, grid, blk, 0, st, a);
+    else if (F4 == 6) hipLaunchKernelGGL(sit_lnmod_kernel<6>, grid, blk, 0, st, a);
+    else return fail("sit: hidden %d not built (64, 128, 192, 384)", H);
+    return 0;
+  };
+  const int hd = H / c.n_heads;
+  for (int i = 0; i < c.n_blocks; ++i) {
+    const std::string p = "blocks." + std::to_string(i) + ".";
+    // [gate_mlp of block i-1 (.) its MLP output] + LN + modulate(shift_msa, scale_msa)      (sit_model.py:129-132)
+    TRYS(lnmod(i == 0 ? nullptr : w.o, i == 0 ? nullptr : h->tab[i - 1], 5 * H, h->tab[i], 0, H));
+    TRYS(gemmS(h, w.u, H, p + "attn.qkv", w.qkv, 3 * H, M, 3 * H, H, st));
+    if (hd == 32) hipLaunchKernelGGL(sit_attn_kernel<32>, dim3(B, c.n_heads), dim3(64), 0, st, w.qkv, mask, w.att, n, H, 1.0f / sqrtf((float)hd));
+    else if (hd == 16) hipLaunchKernelGGL(sit_attn_kernel<16>, dim3(B, c.n_heads), dim3(64), 0, st, w.qkv, mask, w.att, n, H, 1.0f / sqrtf((float)hd));
+    else if (hd == 64) hipLaunchKernelGGL(sit_attn_kernel<64>, dim3(B, c.n_heads), dim3(64), 0, st, w.qkv, mask, w.att, n, H, 1.0f / sqrtf((float)hd));
+    else return fail("sit: head dim %d not built (16, 32, 64)", hd);
+    TRYS(gemmS(h, w.att, H, p + "attn.proj", w.o, H, M, H, H, st));
+    TRYS(lnmod(w.o, h->tab[i], 2 * H, h->tab[i], 3 * H, 4 * H));          // gate_msa; shift_mlp, scale_mlp
+    TRYS(gemmS(h, w.u, H, p + "mlp.fc1", w.f, c.mlp_hidden, M, c.mlp_hidden, H, st));
+    const long long nf = (long long)M * c.mlp_hidden;
+    hipLaunchKernelGGL(sit_gelu_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, w.f, nf);
+    TRYS(gemmS(h, w.f, c.mlp_hidden, p + "mlp.fc2", w.o, H, M, H, c.mlp_hidden, st));
+  }
+  const ParamS *Wf = findS(h, "final_layer.linear.weight", (int64_t)c.in_channels * H), *bf = findS(h, "final_layer.linear.bias", c.in_channels);
+  if (!Wf || !bf) return -1;
+  UpdateArgs a{w.h, w.o, h->tab[c.n_blocks - 1], 6 * H, 5 * H, h->tabF, Wf->p, bf->p, x, x_out, eps_out, noise, w.rows, w.row_count,
+               t_ptr, t_const, n, c_x, c_eps, c_noise, do_update, (uint32_t)(seed & 0xffffffffull), (uint32_t)(seed >> 32), step,
+               graph_id_base};
+  const dim3 grid((M + 15) / 16), blk(256);
+  if (F4 == 3) hipLaunchKernelGGL(sit_update_kernel<3>, grid, blk, 0, st, a);
+  else if (F4 == 1) hipLaunchKernelGGL(sit_update_kernel<1>, grid, blk, 0, st, a);
+  else if (F4 == 2) hipLaunchKernelGGL(sit_update_kernel<2>, grid, blk, 0, st, a);
+  else hipLaunchKernelGGL(sit_update_kernel<6>, grid, blk, 0, st, a);
+  return 0;
+}
+
+int prepS(scgg_sit* h, WorkS& w, const uint8_t* mask, int B, int n, void* workspace, size_t ws_bytes, hipStream_t st) {
+  if (!h || !h->finalized) return fail("sit not finalized");
+  if (B <= 0 || n <= 0 || !mask) return fail("sit: bad arguments");
+  if (reinterpret_cast<uintptr_t>(workspace) % 256 != 0) return fail("workspace must be 256-byte aligned");
+  w = carveS(h->c, B, n, static_cast<char*>(workspace));
+  if (ws_bytes < w.bytes) return fail("workspace too small: %zu < %zu", ws_bytes, w.bytes);
+  // padded rows of every activation stay zero (the GEMMs run over all rows)
+  if (hipMemsetAsync(workspace, 0, w.bytes, st) != hipSuccess) return fail("memset failed");
+  return launch_build_lists(mask, B, n, w.goff, w.rows, w.row_count, w.units, w.unit_count, st);
+}
+
+}  // namespace
+
+extern "C" scgg_sit* scgg_sit_create(const scgg_sit_config* cfg) {
+  if (!cfg) { fail("null config"); return nullptr; }
+  const scgg_sit_config& c = *cfg;
+  if (c.in_channels != 3) { fail("sit: in_channels must be 3 (node coordinates)"); return nullptr; }
+  if (c.hidden % 64 != 0 || (c.hidden != 64 && c.hidden != 128 && c.hidden != 192 && c.hidden != 384)) { fail("sit: hidden %d not built", c.hidden); return nullptr; }
+  if (c.n_heads < 1 || c.hidden % c.n_heads != 0) { fail("sit: bad n_heads"); return nullptr; }
+  const int hd = c.hidden / c.n_heads;
+  if (hd != 16 && hd != 32 && hd != 64) { fail("sit: head dim %d not built", hd); return nullptr; }
+  if (c.n_blocks < 1 || c.mlp_hidden < 1 || c.noise_steps < 2 || !(c.beta_start > 0.f) || !(c.beta_end < 1.f)) { fail("sit: bad config"); return nullptr; }
+  scgg_sit* h = new scgg_sit();
+  h->c = c;
+  // torch.linspace(beta_start, beta_end, steps) in fp32, alpha = 1 - beta, alpha_hat = cumprod (fp32, as the reference)
+  h->beta.resize(c.noise_steps); h->alpha.resize(c.noise_steps); h->alpha_hat.resize(c.noise_steps);
+  const float stepv = (c.beta_end - c.beta_start) / (float)(c.noise_steps - 1);
+  float prod = 1.0f;
+  for (int i = 0; i < c.noise_steps; ++i) {
+    // torch.linspace fills the first half from the start and the second half from the end
+    h->beta[i] = i < c.noise_steps / 2 ? c.beta_start + stepv * (float)i : c.beta_end - stepv * (float)(c.noise_steps - 1 - i);
+    h->alpha[i] = 1.0f - h->beta[i];
+    prod *= h->alpha[i];
+    h->alpha_hat[i] = prod;
+  }
+  return h;
+}
+extern "C" void scgg_sit_destroy(scgg_sit* h) {
+  if (!h) return;
+  if (h->arena) (void)hipFree(h->arena);
+  delete h;
+}
+extern "C" int scgg_sit_set_param(scgg_sit* h, const char* name, const float* data, int64_t numel) {
+  if (!h || !name || !data) return fail("set_param: null argument");
+  h->params[name] = ParamS{data, numel};
+  return 0;
+}
+extern "C" int scgg_sit_finalize(scgg_sit* h, void* stream) {
+  if (!h) return fail("finalize: null handle");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (h->arena == nullptr) {
+    if (buildS(h, false, st)) return -1;
+    if (hipMalloc(reinterpret_cast<void**>(&h->arena), h->arena_bytes) != hipSuccess) return fail("arena allocation failed");
+  }
+  if (buildS(h, true, st)) return -1;
+  h->finalized = true;
+  return 0;
+}
+extern "C" size_t scgg_sit_workspace_bytes(const scgg_sit* h, int32_t B, int32_t n) {
+  if (!h || B <= 0 || n <= 0) return 0;
+  return carveS(h->c, B, n, nullptr).bytes;
+}
+extern "C" int scgg_sit_forward(scgg_sit* h, const float* x, const int32_t* t, const uint8_t* node_mask, int32_t B, int32_t n,
+                                float* eps_out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !t || !eps_out) return fail("sit_forward: null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  WorkS w;
+  if (prepS(h, w, node_mask, B, n, workspace, workspace_bytes, st)) return -1;
+  if (hipMemsetAsync(eps_out, 0, (size_t)B * n * 3 * sizeof(float), st) != hipSuccess) return fail("memset failed");
+  if (stepS(h, w, x, node_mask, B, n, t, 0, eps_out, nullptr, 0, 0.f, 0.f, 0.f, nullptr, 0, 0, 0, st)) return -1;
+  return checkS("sit forward");
+}
+extern "C" int scgg_sit_sample(scgg_sit* h, const float* x_T, const uint8_t* node_mask, int32_t B, int32_t n, int32_t steps,
+                               const float* noise, uint64_t seed, uint32_t graph_id_base, float* x_out, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  if (!x_T || !x_out) return fail("sit_sample: null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  WorkS w;
+  if (prepS(h, w, node_mask, B, n, workspace, workspace_bytes, st)) return -1;
+  const int T = h->c.noise_steps;
+  const size_t xbytes = (size_t)B * n * 3 * sizeof(float);
+  if (hipMemcpyAsync(w.xa, x_T, xbytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail("copy failed");
+  float *cur = w.xa, *nxt = w.xb;
+  int k = 0;
+  for (int i = T - 1; i >= 1; --i, ++k) {                       // reversed(range(1, noise_steps))
+    if (steps >= 0 && k >= steps) break;
+    const float al = h->alpha[i], ah = h->alpha_hat[i], be = h->beta[i];
+    const float c_x = 1.0f / sqrtf(al), c_eps = (1.0f - al) / sqrtf(1.0f - ah), c_noise = i > 1 ? sqrtf(be) : 0.f;
+    if (stepS(h, w, cur, node_mask, B, n, nullptr, i, nullptr, nxt, 1, c_x, c_eps, c_noise,
+              noise ? noise + (size_t)k * B * n * 3 : nullptr, seed, (uint32_t)i, graph_id_base, st)) return -1;
+    float* tmp = cur; cur = nxt; nxt = tmp;
+  }
+  if (hipMemcpyAsync(x_out, cur, xbytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail("copy failed");
+  launch_zero_masked_rows(x_out, node_mask, B * n, 3, st);      // padded slots: zero (the caller masks the positions anyway)
+  return checkS("sit sample");
+}

@@ -209,8 +209,8 @@ class NoiseModel:
             labels, cands = self.sample_edges_from_probs(prob, node_mask, top_k if top_k > 1 else 0, zr)
         t_int = torch.full((B, 1), self.T, dtype=torch.long, device=dev)
         pos = torch.randn(B, n, 3, device=dev, generator=generator)
-        if self.node_coord_model is not None:
-            pos = self.node_coord_model(pos, node_mask)
+        if self.node_coord_model is not None:      # reference :323-325: node_coord_model.sample(pos=start_pos_shape, node_mask=...)
+            pos = getattr(self.node_coord_model, "sample", self.node_coord_model)(pos, node_mask)
         raw = pos * node_mask[..., None]
         radius = torch.zeros(B, n, n, 1, device=dev)
         ph = self._to_placeholder(labels, cands, node_mask, t_int, self.pos_after_masks(raw, node_mask, 1), B, radius,
