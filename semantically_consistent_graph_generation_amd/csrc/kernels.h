@@ -159,7 +159,19 @@ struct NodeLinearArgs {   // row-list Linear on pre-packed weights (node path)
   float* C;               // [M,N] ldc
   const int* rows;
   const int* row_count;
-  int N, K, NB, lda, ldc, rbw, relu;
+  int N, K, NB, lda, ldc, rbw, relu;   // relu (x3 kernel): 0 none, 1 ReLU, 2 tanh-GELU, 3 accumulate into C (no activation)
+  // Optional prologue of the x3 kernel (the SiT blocks; K <= 256): the operand row is not read from A but formed from the
+  // residual stream: h[row] (+ gate (.) o[row], stored back to h), LayerNorm without affine (eps ln_eps), (1 + scale), + shift.
+  // gate / shift / scale are rows of per-timestep tables (already offset to their columns, row stride ln_ld); the row's
+  // timestep is ln_t[row / ln_n] or ln_tc.
+  float* ln_h = nullptr;
+  const float* ln_o = nullptr;
+  const float* ln_gate = nullptr;
+  const float* ln_shift = nullptr;
+  const float* ln_scale = nullptr;
+  const int32_t* ln_t = nullptr;
+  int ln_ld = 0, ln_n = 1, ln_tc = 0;
+  float ln_eps = 0.f;
 };
 int launch_node_linear(const NodeLinearArgs& a, int M, hipStream_t st);
 // the same Linear on the bf16x3 scheme (node_layer.hip; W3 from launch_pack_linear_x3); -1: shape not covered, use the above

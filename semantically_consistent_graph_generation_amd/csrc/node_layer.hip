@@ -239,10 +239,12 @@ __device__ __forceinline__ void put_split4(__bf16* planes, int r, int c, const f
 
 struct NFrag3 { nu32x4 h, m, l; };
 constexpr int NWD = 2;                                       // K chunks of weights in flight per wave
-struct NWRing {
-  NFrag3 f[NWD][2];                                          // [chunk slot][output block of the pair]
-  const nu32x4* next;                                        // block pair whose first NWD chunks the ring holds (null: none)
+template <int D>
+struct NWRingT {
+  NFrag3 f[D][2];                                            // [chunk slot][output block of the pair]
+  const nu32x4* next;                                        // block pair whose first D chunks the ring holds (null: none)
 };
+using NWRing = NWRingT<NWD>;
 
 // slot pointer of 16-channel output block ob of an x3 image with KC 32-channel chunks per block
 __device__ __forceinline__ const nu32x4* w3_block(const f32x4* w3, int ob, int KC, int lane) {
@@ -258,10 +260,10 @@ __device__ __forceinline__ void w3_load(NFrag3 (&f)[2], const nu32x4* w, int kc)
   }
 }
 // start the stream of a block pair: its first NWD chunks (L2 latency ~1 us: issued ahead of whatever precedes the Linear)
-template <int KC>
-__device__ __forceinline__ void w3_prime(NWRing& r, const nu32x4* w) {
+template <int KC, int D>
+__device__ __forceinline__ void w3_prime(NWRingT<D>& r, const nu32x4* w) {
 #pragma unroll
-  for (int d = 0; d < NWD; ++d) w3_load<KC>(r.f[d], w, d);
+  for (int d = 0; d < D; ++d) w3_load<KC>(r.f[d], w, d);
   r.next = w;
 }
 
@@ -269,10 +271,11 @@ __device__ __forceinline__ void w3_prime(NWRing& r, const nu32x4* w) {
 // of block blk in the registers) += W . X^T for the pair of 16-channel output blocks at w (consecutive in the image).
 // The ring holds the pair's first NWD chunks on entry when r.next == w (else they are fetched here); on exit it holds
 // those of `wnext` (KCN chunks per block; when not null).
-template <int KC, int KCN, int KS, int PLANE, int NRG>
-__device__ __forceinline__ void tile_linear_x3(f32x4 (&acc)[2][NRG], NWRing& r, const nu32x4* w, const nu32x4* wnext,
+template <int KC, int KCN, int KS, int PLANE, int NRG, int D>
+__device__ __forceinline__ void tile_linear_x3(f32x4 (&acc)[2][NRG], NWRingT<D>& r, const nu32x4* w, const nu32x4* wnext,
                                                const __bf16* planes, int p, int g) {
-  static_assert(KC >= NWD && KCN >= NWD, "K too small for the weight ring");
+  static_assert(KC >= D && KCN >= D, "K too small for the weight ring");
+  static_assert(KC % D == 0, "chunk j of the next pair has to land in ring slot j % D");
   const __bf16* x = planes + p * KS + 8 * g;
   NFrag3 xf[2][NRG];
   auto xload = [&](NFrag3 (&f)[NRG], int kc) {
@@ -293,7 +296,7 @@ __device__ __forceinline__ void tile_linear_x3(f32x4 (&acc)[2][NRG], NWRing& r, 
 #define SCGG_NB(v) __builtin_bit_cast(nbf16x8, v)
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
-      const NFrag3& a = r.f[kc % NWD][blk];
+      const NFrag3& a = r.f[kc % D][blk];
 #pragma unroll
       for (int rg = 0; rg < NRG; ++rg) {
         const NFrag3& b = xf[kc & 1][rg];
@@ -309,8 +312,8 @@ __device__ __forceinline__ void tile_linear_x3(f32x4 (&acc)[2][NRG], NWRing& r, 
     }
 #undef SCGG_NB
     __builtin_amdgcn_sched_barrier(0);
-    if (kc + NWD < KC) w3_load<KC>(r.f[kc % NWD], w, kc + NWD);
-    else if (wnext != nullptr) w3_load<KCN>(r.f[kc % NWD], wnext, kc + NWD - KC);
+    if (kc + D < KC) w3_load<KC>(r.f[kc % D], w, kc + D);
+    else if (wnext != nullptr) w3_load<KCN>(r.f[kc % D], wnext, kc + D - KC);
   }
   r.next = wnext;
 }
@@ -513,9 +516,9 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
 // C[row, :N] = act(A[row, :K] . W^T + bias) for the valid rows.  48-row tiles; the operand rows are split into planes once,
 // each wave walks output block pairs w, w + 8, ...
 // ---------------------------------------------------------------------------------------------------------
-template <int KC>
+template <int KC, int NRG, int D>
 __global__ __launch_bounds__(512) void node_linear_x3_kernel(NodeLinearArgs a, const f32x4* W3) {
-  constexpr int K = 32 * KC, TR = 48, NRG = 3, KS = K + 8, PLANE = TR * KS, RPW = TR / 8;
+  constexpr int K = 32 * KC, TR = 16 * NRG, KS = K + 8, PLANE = TR * KS, RPW = TR / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* S = reinterpret_cast<__bf16*>(smem);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, g = lane >> 4;
@@ -523,15 +526,58 @@ __global__ __launch_bounds__(512) void node_linear_x3_kernel(NodeLinearArgs a, c
   const int tile = blockIdx.x;
   if (tile * TR >= count) return;
   const int npairs = (a.N + 31) / 32;
-  NWRing ring;
+  NWRingT<D> ring;                                     // D chunks of this wave's weight stream in flight: the stream is what the kernel waits for
   ring.next = nullptr;
   if (wave < npairs) w3_prime<KC>(ring, w3_block(W3, 2 * wave, KC, lane));
+  if (K <= 256 && a.ln_h != nullptr) {                  // wave-uniform; one float4 per lane and row
+    constexpr int RH = RPW / 2;                         // rows per batch: every load of a batch is issued before its arithmetic
+    const int c = lane * 4;
+    const bool in = c < K;
 #pragma unroll
-  for (int t = 0; t < RPW; ++t) {
-    const int ridx = tile * TR + wave * RPW + t;
-    const long long row = a.rows[ridx < count ? ridx : count - 1];
-    for (int c = lane * 4; c < K; c += 256)
-      put_split4<KS, PLANE>(S, wave * RPW + t, c, *reinterpret_cast<const f32x4*>(a.A + row * a.lda + c));
+    for (int t0 = 0; t0 < RPW; t0 += RH) {
+      f32x4 v[RH], o[RH], gt[RH], sc[RH], sh[RH];
+      long long row[RH];
+#pragma unroll
+      for (int t = 0; t < RH; ++t) {
+        const int ridx = tile * TR + wave * RPW + t0 + t;
+        row[t] = a.rows[ridx < count ? ridx : count - 1];
+      }
+#pragma unroll
+      for (int t = 0; t < RH; ++t) {
+        const size_t tt = (size_t)(a.ln_t ? a.ln_t[row[t] / a.ln_n] : a.ln_tc) * a.ln_ld;
+        v[t] = o[t] = gt[t] = sc[t] = sh[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (in) {
+          v[t] = *reinterpret_cast<const f32x4*>(a.ln_h + row[t] * K + c);
+          if (a.ln_o != nullptr) {
+            o[t] = *reinterpret_cast<const f32x4*>(a.ln_o + row[t] * K + c);
+            gt[t] = *reinterpret_cast<const f32x4*>(a.ln_gate + tt + c);
+          }
+          sc[t] = *reinterpret_cast<const f32x4*>(a.ln_scale + tt + c);
+          sh[t] = *reinterpret_cast<const f32x4*>(a.ln_shift + tt + c);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < RH; ++t) {
+        const int ridx = tile * TR + wave * RPW + t0 + t;
+        v[t] += gt[t] * o[t];
+        if (in && a.ln_o != nullptr && ridx < count)      // the filler rows of the last tile repeat a row
+          *reinterpret_cast<f32x4*>(a.ln_h + row[t] * K + c) = v[t];
+        const float mean = wave_sum64((v[t][0] + v[t][1]) + (v[t][2] + v[t][3])) * (1.0f / K);
+        f32x4 d = v[t] - mean;
+        if (!in) d = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float rstd = 1.0f / sqrtf(wave_sum64((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / K) + a.ln_eps);
+        if (in) put_split4<KS, PLANE>(S, wave * RPW + t0 + t, c, d * rstd * (sc[t] + 1.0f) + sh[t]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < RPW; ++t) {
+      const int ridx = tile * TR + wave * RPW + t;
+      const long long row = a.rows[ridx < count ? ridx : count - 1];
+      for (int c = lane * 4; c < K; c += 256)
+        put_split4<KS, PLANE>(S, wave * RPW + t, c, *reinterpret_cast<const f32x4*>(a.A + row * a.lda + c));
+    }
   }
   long long qrow[NRG];
   bool qok[NRG];
@@ -558,23 +604,31 @@ __global__ __launch_bounds__(512) void node_linear_x3_kernel(NodeLinearArgs a, c
 #pragma unroll
       for (int rg = 0; rg < NRG; ++rg) {
         f32x4 o = acc[blk][rg];
-        if (a.relu) {
+        if (a.relu == 1) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        } else if (a.relu == 2) {                     // tanh-approximated GELU (the SiT MLP)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = 0.5f * o[e] * (1.0f + tanhf(0.7978845608028654f * (o[e] + 0.044715f * o[e] * o[e] * o[e])));
         }
-        if (qok[rg] && c0 < a.N) *reinterpret_cast<f32x4*>(a.C + qrow[rg] * a.ldc + c0) = o;
+        if (qok[rg] && c0 < a.N) {
+          float* dst = a.C + qrow[rg] * a.ldc + c0;
+          if (a.relu == 3) o += *reinterpret_cast<const f32x4*>(dst);      // accumulate: one K slice of a longer product
+          *reinterpret_cast<f32x4*>(dst) = o;
+        }
       }
     }
   }
 }
 
-template <int KC>
+template <int KC, int NRG = 3, int D = NWD>
 static int launch_linear_x3(const NodeLinearArgs& a, const f32x4* W3, int M, hipStream_t st) {
-  constexpr size_t lds = (size_t)3 * 48 * (32 * KC + 8) * 2;
+  constexpr int TR = 16 * NRG;
+  constexpr size_t lds = (size_t)3 * TR * (32 * KC + 8) * 2;
   static LdsAttrOnce attr;
-  auto kern = node_linear_x3_kernel<KC>;
+  auto kern = node_linear_x3_kernel<KC, NRG, D>;
   if (set_max_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds)) return -2;
-  hipLaunchKernelGGL(kern, dim3((M + 47) / 48), dim3(512), lds, st, a, W3);
+  hipLaunchKernelGGL(kern, dim3((M + TR - 1) / TR), dim3(512), lds, st, a, W3);
   return 0;
 }
 
@@ -605,12 +659,15 @@ bool node_layer_x3_enabled() { return node_x3(); }
 
 bool node_layer_supported(int dx, int ffx) { return (dx == 256 && ffx == 256) || (dx == 128 && ffx == 128); }
 
-// row-list Linear through the x3 kernel when the shape allows (K = 128, 256 or 512, N a multiple of 4, padded bias), else -1
+// row-list Linear through the x3 kernel when the shape allows (K = 128, 192, 256, 512 or 768, N a multiple of 4, padded bias), else -1
 int launch_node_linear_x3(const NodeLinearArgs& a, const f32x4_t* W3, int M, hipStream_t st) {
   if (!node_x3() || W3 == nullptr || a.lda % 4 != 0 || a.ldc % 4 != 0 || a.N % 4 != 0) return -1;
+  if (a.ln_h != nullptr && a.K > 256) return -1;
+  if (a.K == 768) return launch_linear_x3<24, 2, 6>(a, W3, M, st);    // 32-row tiles: three planes of 48 rows do not fit LDS
   if (a.K == 512) return launch_linear_x3<16>(a, W3, M, st);
-  if (a.K == 256) return launch_linear_x3<8>(a, W3, M, st);
-  if (a.K == 128) return launch_linear_x3<4>(a, W3, M, st);
+  if (a.K == 256) return launch_linear_x3<8, 3, 4>(a, W3, M, st);
+  if (a.K == 192) return launch_linear_x3<6, 3, 3>(a, W3, M, st);
+  if (a.K == 128) return launch_linear_x3<4, 3, 4>(a, W3, M, st);
   return -1;
 }
 

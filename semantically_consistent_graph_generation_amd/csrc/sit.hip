@@ -70,6 +70,10 @@ struct LnModArgs {
   const int* row_count;
   const int32_t* t;      // [B] timestep per graph, or null: t_const for all
   int t_const, n;
+  const float* x;        // block 0 only: [M,cin] sample; h = pos_embedder(x) is formed (and stored) here    (sit_model.py:182)
+  const float* We;       // [H,cin]
+  const float* be;       // [H]
+  int cin;
 };
 
 // 16 lanes per row, F4 float4 per lane (H = 64 F4)
@@ -86,7 +90,14 @@ __global__ __launch_bounds__(256) void sit_lnmod_kernel(LnModArgs a) {
 #pragma unroll
   for (int k = 0; k < F4; ++k) {
     const int c = 64 * k + 4 * p;
-    v[k] = ld4(a.h + row * H + c);
+    if (a.x != nullptr) {
+      v[k] = ld4(a.be + c);
+      for (int j = 0; j < a.cin; ++j) {
+        const float xj = a.x[row * a.cin + j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[k][e] += xj * a.We[(c + e) * a.cin + j];
+      }
+    } else v[k] = ld4(a.h + row * H + c);
     if (a.o != nullptr) v[k] += ld4(a.tab_gate + (size_t)t * a.ld + a.off_gate + c) * ld4(a.o + row * H + c);
     s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
   }
@@ -101,7 +112,7 @@ __global__ __launch_bounds__(256) void sit_lnmod_kernel(LnModArgs a) {
 #pragma unroll
   for (int k = 0; k < F4; ++k) {
     const int c = 64 * k + 4 * p;
-    if (a.o != nullptr) *reinterpret_cast<f32x4*>(a.h + row * H + c) = v[k];
+    if (a.o != nullptr || a.x != nullptr) *reinterpret_cast<f32x4*>(a.h + row * H + c) = v[k];
     const f32x4 sh = ld4(a.tab + (size_t)t * a.ld + a.off_shift + c), sc = ld4(a.tab + (size_t)t * a.ld + a.off_scale + c);
     f32x4 u;
 #pragma unroll
@@ -110,21 +121,29 @@ __global__ __launch_bounds__(256) void sit_lnmod_kernel(LnModArgs a) {
   }
 }
 
-// One wave per (graph, head): lane = query token (64 per pass), the head's K / V rows of up to 64 valid keys in LDS, online
-// softmax.  qkv row = [q | k | v][heads][HD] (sit_model.py:87-88); out[row][head HD + d].
+// One wave per (graph, head).  The head's K / V rows of up to 64 valid keys are staged into LDS by the whole wave (HD/4
+// lanes per row, float4 each); lane = (query token, half of the head's channels): both halves of a query form the full
+// score from broadcast K reads and accumulate their own half of the weighted V sum, online softmax over the key chunks.
+// qkv row = [q | k | v][heads][HD] (sit_model.py:87-88); out[row][head HD + d].
 template <int HD>
 __global__ __launch_bounds__(64) void sit_attn_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ mask,
                                                       float* __restrict__ out, int n, int H, float scale) {
-  __shared__ float ks[64][HD + 1], vs[64][HD + 1];
+  constexpr int LD = HD + 4, Q4 = HD / 4, HV = HD / 2, LPR = HD / 4, RPP = 64 / LPR;
+  __shared__ __align__(16) float ks[64 * LD], vs[64 * LD];
+  __shared__ int slot_of[64];
   const int b = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
+  const int qi = lane & 31, half = lane >> 5;
   const uint8_t* mb = mask + (long long)b * n;
   const float* base = qkv + (long long)b * n * 3 * H + head * HD;
-  for (int i0 = 0; i0 < n; i0 += 64) {
-    const int i = i0 + lane;
+  for (int i0 = 0; i0 < n; i0 += 32) {
+    const int i = i0 + qi;
     const bool qon = i < n && mb[i] != 0;
-    float q[HD], acc[HD];
+    f32x4 q[Q4];
+    float acc[HV];
 #pragma unroll
-    for (int d = 0; d < HD; ++d) { q[d] = qon ? base[(long long)i * 3 * H + d] * scale : 0.f; acc[d] = 0.f; }
+    for (int k = 0; k < Q4; ++k) q[k] = qon ? ld4(base + (long long)i * 3 * H + 4 * k) * scale : splat4(0.f);
+#pragma unroll
+    for (int d = 0; d < HV; ++d) acc[d] = 0.f;
     float m = -INFINITY, l = 0.f;
     for (int j0 = 0; j0 < n; j0 += 64) {
       const int j = j0 + lane;
@@ -132,29 +151,45 @@ __global__ __launch_bounds__(64) void sit_attn_kernel(const float* __restrict__ 
       const unsigned long long bal = __ballot(kon);
       const int cnt = __popcll(bal);
       __syncthreads();
-      if (kon) {
-        const int slot = __popcll(bal & ((1ull << lane) - 1ull));
-        const float* kr = base + (long long)j * 3 * H + H;
-#pragma unroll
-        for (int d = 0; d < HD; ++d) { ks[slot][d] = kr[d]; vs[slot][d] = kr[H + d]; }
+      slot_of[lane] = kon ? __popcll(bal & ((1ull << lane) - 1ull)) : -1;
+      __syncthreads();
+      const int rows_here = min(64, n - j0);
+      for (int r0 = 0; r0 < rows_here; r0 += RPP) {
+        const int r = r0 + lane / LPR, c4 = (lane % LPR) * 4;
+        const int sl = r < rows_here ? slot_of[r] : -1;
+        if (sl >= 0) {
+          const float* kr = base + (long long)(j0 + r) * 3 * H + H + c4;
+          *reinterpret_cast<f32x4*>(&ks[sl * LD + c4]) = ld4(kr);
+          *reinterpret_cast<f32x4*>(&vs[sl * LD + c4]) = ld4(kr + H);
+        }
       }
       __syncthreads();
       for (int c = 0; c < cnt; ++c) {
-        float s = 0.f;
+        f32x4 s4 = splat4(0.f);
 #pragma unroll
-        for (int d = 0; d < HD; ++d) s += q[d] * ks[c][d];
+        for (int k = 0; k < Q4; ++k) s4 += q[k] * *reinterpret_cast<const f32x4*>(&ks[c * LD + 4 * k]);
+        const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
         const float mn = fmaxf(m, s), fo = __expf(m - mn), fn = __expf(s - mn);
         l = l * fo + fn;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) acc[d] = acc[d] * fo + fn * vs[c][d];
+        for (int k = 0; k < HV / 4; ++k) {
+          const f32x4 vv = *reinterpret_cast<const f32x4*>(&vs[c * LD + half * HV + 4 * k]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[4 * k + e] = acc[4 * k + e] * fo + fn * vv[e];
+        }
         m = mn;
       }
     }
     if (qon) {
-      float* o = out + ((long long)b * n + i) * H + head * HD;
+      float* o = out + ((long long)b * n + i) * H + head * HD + half * HV;
       const float inv = 1.0f / l;
 #pragma unroll
-      for (int d = 0; d < HD; ++d) o[d] = acc[d] * inv;
+      for (int k = 0; k < HV / 4; ++k) {
+        f32x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = acc[4 * k + e] * inv;
+        *reinterpret_cast<f32x4*>(o + 4 * k) = ov;
+      }
     }
   }
 }
@@ -263,6 +298,10 @@ struct scgg_sit {
   float* tabF = nullptr;       // [T][2H]
   float *emb = nullptr, *t1 = nullptr, *cemb = nullptr, *csilu = nullptr;
   std::vector<float> beta, alpha, alpha_hat;   // host copies of the schedule
+  struct Lin { f32x4_t* W3 = nullptr; float* b = nullptr; int N = 0, K = 0; };   // row-list bf16x3 image + padded bias
+  struct Blk { Lin qkv, proj, fc1; std::vector<Lin> fc2; float* Wslice = nullptr; float* zero_b = nullptr; };
+  std::vector<Blk> lin;
+  int fc2_slice = 256;
 };
 
 namespace {
@@ -300,8 +339,52 @@ int buildS(scgg_sit* h, bool fill, hipStream_t st) {
   h->tab.resize(c.n_blocks);
   for (int i = 0; i < c.n_blocks; ++i) h->tab[i] = ar.take<float>((size_t)T * 6 * H);
   h->tabF = ar.take<float>((size_t)T * 2 * H);
+  // row-list bf16x3 images of the four Linears of every block (K = hidden must be one of the built widths; fc2 in K slices
+  // of 256 accumulated into the output: its whole K does not fit the kernel's LDS)
+  auto built_k = [](int k) { return k == 128 || k == 192 || k == 256 || k == 512 || k == 768; };
+  const int sw = built_k(c.mlp_hidden) ? c.mlp_hidden : 256;      // K slice of fc2
+  const bool rowlin = (H == 128 || H == 192 || H == 256) && c.mlp_hidden % sw == 0;
+  h->fc2_slice = sw;
+  h->lin.assign(c.n_blocks, scgg_sit::Blk());
+  auto take_lin = [&](scgg_sit::Lin& L, int N, int K) {
+    const int NB = (N + 31) / 32;
+    L.N = N; L.K = K;
+    L.W3 = ar.take<f32x4_t>((size_t)NB * (K / 16) * 192);
+    L.b = ar.take<float>((size_t)NB * 32);
+  };
+  if (rowlin)
+    for (int i = 0; i < c.n_blocks; ++i) {
+      scgg_sit::Blk& Bk = h->lin[i];
+      take_lin(Bk.qkv, 3 * H, H); take_lin(Bk.proj, H, H); take_lin(Bk.fc1, c.mlp_hidden, H);
+      Bk.fc2.assign(c.mlp_hidden / sw, scgg_sit::Lin());
+      for (auto& L : Bk.fc2) take_lin(L, H, sw);
+      Bk.Wslice = ar.take<float>((size_t)H * sw);
+      Bk.zero_b = ar.take<float>((size_t)(H + 31) / 32 * 32);
+    }
   h->arena_bytes = (ar.off + 255) / 256 * 256;
   if (!fill) return 0;
+  if (rowlin) {
+    auto fill_lin = [&](scgg_sit::Lin& L, const float* W, const float* b) {
+      PackArgs p3{W, L.W3, L.N, L.K, (L.N + 31) / 32, L.K / 32};
+      launch_pack_linear_x3(p3, st);
+      launch_pad_vec(b, L.b, L.N, (L.N + 31) / 32 * 32, 0.f, st);
+    };
+    for (int i = 0; i < c.n_blocks; ++i) {
+      const std::string p = "blocks." + std::to_string(i) + ".";
+      scgg_sit::Blk& Bk = h->lin[i];
+      const ParamS *wq = findS(h, p + "attn.qkv.weight", (int64_t)3 * H * H), *bq = findS(h, p + "attn.qkv.bias", 3 * H),
+                   *wp = findS(h, p + "attn.proj.weight", (int64_t)H * H), *bp = findS(h, p + "attn.proj.bias", H),
+                   *w1 = findS(h, p + "mlp.fc1.weight", (int64_t)c.mlp_hidden * H), *b1 = findS(h, p + "mlp.fc1.bias", c.mlp_hidden),
+                   *w2 = findS(h, p + "mlp.fc2.weight", (int64_t)H * c.mlp_hidden), *b2 = findS(h, p + "mlp.fc2.bias", H);
+      if (!wq || !bq || !wp || !bp || !w1 || !b1 || !w2 || !b2) return -1;
+      fill_lin(Bk.qkv, wq->p, bq->p); fill_lin(Bk.proj, wp->p, bp->p); fill_lin(Bk.fc1, w1->p, b1->p);
+      if (hipMemsetAsync(Bk.zero_b, 0, (size_t)(H + 31) / 32 * 32 * sizeof(float), st) != hipSuccess) return fail("memset failed");
+      for (size_t s2 = 0; s2 < Bk.fc2.size(); ++s2) {          // slice s: columns [sw s, sw s + sw) of fc2.weight [H, mlp_hidden]
+        launch_copy_cols(w2->p + sw * s2, c.mlp_hidden, Bk.Wslice, sw, H, sw, st);
+        fill_lin(Bk.fc2[s2], Bk.Wslice, s2 == 0 ? b2->p : Bk.zero_b);
+      }
+    }
+  }
   hipLaunchKernelGGL(sit_temb_kernel, dim3((T * (TEMB / 2) + 255) / 256), dim3(256), 0, st, h->emb, T, TEMB);
   if (gemmS(h, h->emb, TEMB, "t_embedder.mlp.0", h->t1, H, T, H, TEMB, st)) return -1;
   hipLaunchKernelGGL(sit_silu_kernel, dim3((T * H + 255) / 256), dim3(256), 0, st, h->t1, h->t1, (long long)T * H);
@@ -358,9 +441,11 @@ int stepS(scgg_sit* h, const WorkS& w, const float* x, const uint8_t* mask, int 
           uint32_t step, uint32_t graph_id_base, hipStream_t st) {
   const scgg_sit_config& c = h->c;
   const int M = B * n, H = c.hidden, F4 = H / 64;
-  TRYS(gemmS(h, x, c.in_channels, "pos_embedder", w.h, H, M, H, c.in_channels, st));
+  const ParamS *We = findS(h, "pos_embedder.weight", (int64_t)H * c.in_channels), *be = findS(h, "pos_embedder.bias", H);
+  if (!We || !be) return -1;
   auto lnmod = [&](const float* o, const float* tab_gate, int off_gate, const float* tab, int off_shift, int off_scale) -> int {
-    LnModArgs a{w.h, o, tab, 6 * H, off_gate, off_shift, off_scale, tab_gate, w.u, w.rows, w.row_count, t_ptr, t_const, n};
+    LnModArgs a{w.h, o, tab, 6 * H, off_gate, off_shift, off_scale, tab_gate, w.u, w.rows, w.row_count, t_ptr, t_const, n,
+                o == nullptr ? x : nullptr, We->p, be->p, c.in_channels};
     const dim3 grid((M + 15) / 16), blk(256);
     if (F4 == 3) hipLaunchKernelGGL(sit_lnmod_kernel<3>, grid, blk, 0, st, a);
     else if (F4 == 1) hipLaunchKernelGGL(sit_lnmod_kernel<1>, grid, blk, 0, st, a);
@@ -372,19 +457,49 @@ int stepS(scgg_sit* h, const WorkS& w, const float* x, const uint8_t* mask, int 
   const int hd = H / c.n_heads;
   for (int i = 0; i < c.n_blocks; ++i) {
     const std::string p = "blocks." + std::to_string(i) + ".";
-    // [gate_mlp of block i-1 (.) its MLP output] + LN + modulate(shift_msa, scale_msa)      (sit_model.py:129-132)
-    TRYS(lnmod(i == 0 ? nullptr : w.o, i == 0 ? nullptr : h->tab[i - 1], 5 * H, h->tab[i], 0, H));
-    TRYS(gemmS(h, w.u, H, p + "attn.qkv", w.qkv, 3 * H, M, 3 * H, H, st));
+    const scgg_sit::Blk& Bk = h->lin[i];
+    // row-list bf16x3 Linear on the valid rows; -1: shape not built or the x3 node kernels are switched off -> generic GEMM
+    auto lin = [&](const scgg_sit::Lin& L, const float* A, int lda, float* Cc, int ldc, int mode) -> int {
+      if (L.W3 == nullptr) return -1;
+      NodeLinearArgs a{A, nullptr, L.b, Cc, w.rows, w.row_count, L.N, L.K, (L.N + 31) / 32, lda, ldc, 1, mode};
+      return launch_node_linear_x3(a, L.W3, M, st);
+    };
+    // the same with the sub-layer's entry ([gate (.) o] + h -> h, LN, modulate) formed in the Linear's prologue instead of
+    // by sit_lnmod_kernel
+    auto lin_ln = [&](const scgg_sit::Lin& L, const float* o, const float* tab_gate, int off_gate, const float* tab, int off_shift,
+                      int off_scale, float* Cc, int ldc, int mode) -> int {
+      if (L.W3 == nullptr || H > 256) return -1;
+      NodeLinearArgs a{w.u, nullptr, L.b, Cc, w.rows, w.row_count, L.N, L.K, (L.N + 31) / 32, H, ldc, 1, mode};
+      a.ln_h = w.h; a.ln_o = o; a.ln_gate = o ? tab_gate + off_gate : nullptr; a.ln_shift = tab + off_shift; a.ln_scale = tab + off_scale;
+      a.ln_t = t_ptr; a.ln_ld = 6 * H; a.ln_n = n; a.ln_tc = t_const; a.ln_eps = 1e-6f;
+      return launch_node_linear_x3(a, L.W3, M, st);
+    };
+    // [gate_mlp of block i-1 (.) its MLP output] + LN + modulate(shift_msa, scale_msa), then q|k|v      (sit_model.py:129-132)
+    if (i == 0 || lin_ln(Bk.qkv, w.o, h->tab[i - 1], 5 * H, h->tab[i], 0, H, w.qkv, 3 * H, 0) != 0) {
+      TRYS(lnmod(i == 0 ? nullptr : w.o, i == 0 ? nullptr : h->tab[i - 1], 5 * H, h->tab[i], 0, H));
+      if (lin(Bk.qkv, w.u, H, w.qkv, 3 * H, 0) != 0) TRYS(gemmS(h, w.u, H, p + "attn.qkv", w.qkv, 3 * H, M, 3 * H, H, st));
+    }
     if (hd == 32) hipLaunchKernelGGL(sit_attn_kernel<32>, dim3(B, c.n_heads), dim3(64), 0, st, w.qkv, mask, w.att, n, H, 1.0f / sqrtf((float)hd));
     else if (hd == 16) hipLaunchKernelGGL(sit_attn_kernel<16>, dim3(B, c.n_heads), dim3(64), 0, st, w.qkv, mask, w.att, n, H, 1.0f / sqrtf((float)hd));
     else if (hd == 64) hipLaunchKernelGGL(sit_attn_kernel<64>, dim3(B, c.n_heads), dim3(64), 0, st, w.qkv, mask, w.att, n, H, 1.0f / sqrtf((float)hd));
     else return fail("sit: head dim %d not built (16, 32, 64)", hd);
-    TRYS(gemmS(h, w.att, H, p + "attn.proj", w.o, H, M, H, H, st));
-    TRYS(lnmod(w.o, h->tab[i], 2 * H, h->tab[i], 3 * H, 4 * H));          // gate_msa; shift_mlp, scale_mlp
-    TRYS(gemmS(h, w.u, H, p + "mlp.fc1", w.f, c.mlp_hidden, M, c.mlp_hidden, H, st));
-    const long long nf = (long long)M * c.mlp_hidden;
-    hipLaunchKernelGGL(sit_gelu_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, w.f, nf);
-    TRYS(gemmS(h, w.f, c.mlp_hidden, p + "mlp.fc2", w.o, H, M, H, c.mlp_hidden, st));
+    if (lin(Bk.proj, w.att, H, w.o, H, 0) != 0) TRYS(gemmS(h, w.att, H, p + "attn.proj", w.o, H, M, H, H, st));
+    // gate_msa (.) attention + h, LN, modulate(shift_mlp, scale_mlp), then fc1 + GELU
+    if (lin_ln(Bk.fc1, w.o, h->tab[i], 2 * H, h->tab[i], 3 * H, 4 * H, w.f, c.mlp_hidden, 2) != 0) {
+      TRYS(lnmod(w.o, h->tab[i], 2 * H, h->tab[i], 3 * H, 4 * H));
+      if (lin(Bk.fc1, w.u, H, w.f, c.mlp_hidden, 2) != 0) {
+        TRYS(gemmS(h, w.u, H, p + "mlp.fc1", w.f, c.mlp_hidden, M, c.mlp_hidden, H, st));
+        const long long nf = (long long)M * c.mlp_hidden;
+        hipLaunchKernelGGL(sit_gelu_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, w.f, nf);
+      }
+    }
+    bool sliced = !Bk.fc2.empty();
+    for (size_t s2 = 0; sliced && s2 < Bk.fc2.size(); ++s2)
+      if (lin(Bk.fc2[s2], w.f + h->fc2_slice * s2, c.mlp_hidden, w.o, H, s2 == 0 ? 0 : 3) != 0) {
+        if (s2 != 0) return fail("sit: fc2 slice launch failed");
+        sliced = false;
+      }
+    if (!sliced) TRYS(gemmS(h, w.f, c.mlp_hidden, p + "mlp.fc2", w.o, H, M, H, c.mlp_hidden, st));
   }
   const ParamS *Wf = findS(h, "final_layer.linear.weight", (int64_t)c.in_channels * H), *bf = findS(h, "final_layer.linear.bias", c.in_channels);
   if (!Wf || !bf) return -1;
