@@ -177,6 +177,29 @@ int launch_node_linear(const NodeLinearArgs& a, int M, hipStream_t st);
 // the same Linear on the bf16x3 scheme (node_layer.hip; W3 from launch_pack_linear_x3); -1: shape not covered, use the above
 int launch_node_linear_x3(const NodeLinearArgs& a, const f32x4_t* W3, int M, hipStream_t st);
 
+struct SitBlockArgs {     // one SiT block between two attention launches (sit_block.hip); weights as bf16x3 images
+  const float* att;       // [M,H] attention output of this block
+  float* h;               // [M,H] residual stream, updated in place
+  float* o;               // [M,H] last block only: the MLP output (gate_mlp is then applied by the caller)
+  const f32x4_t* W3_proj; // [H x H]
+  const f32x4_t* W3_fc1;  // [4H x H]
+  const f32x4_t* W3_fc2;  // nslices images [H x 256], fc2_stride f32x4 apart: K slice s of fc2
+  const f32x4_t* W3_qkv;  // the NEXT block's [3H x H], or null after the last block
+  const float* b_proj;    // biases padded to a multiple of 32
+  const float* b_fc1;
+  const float* b_fc2;
+  const float* b_qkv;
+  const float* tab;       // this block's modulation table [T][6H]: shift_msa | scale_msa | gate_msa | shift_mlp | scale_mlp | gate_mlp
+  const float* tab_next;  // the next block's
+  float* qkv;             // [M,3H] the next block's q | k | v
+  const int* rows;
+  const int* row_count;
+  const int32_t* t;       // [B] timestep per graph, or null: t_const
+  int t_const, n, nslices;
+  long long fc2_stride;
+};
+int launch_sit_block(const SitBlockArgs& a, int H, int M, hipStream_t st);
+
 struct NodeLayerArgs {    // fused node part of one layer (node_layer.hip); packed weights as for NodeLinearArgs
   const float* attn_part; // [B*n*nch, 3, dx] per-unit attention partials of this layer's edge kernel
   const uint8_t* mask;

@@ -15,6 +15,7 @@
 // linX1, linX2, LN) and the separate q|k|v launch, and the activations make no HBM round trip between them.
 #include "mfma_chain.h"
 #include "kernels.h"
+#include "x3_tile.h"
 #include <stdlib.h>
 
 namespace scgg {
@@ -50,11 +51,6 @@ __device__ __forceinline__ void tile_linear(f32x16& acc, const f32x4* __restrict
   }
 }
 
-__device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
-  return v;
-}
 
 // rows 4w..4w+3 of the tile: res <- LN(res + lin) * gamma + beta (eps 1e-5, biased variance); the residual stream stays in
 // this wave's registers (lane = 4 channels), the normalised rows also go to LDS `dst` (next operand) and optionally global
@@ -195,9 +191,6 @@ __global__ __launch_bounds__(512) void node_layer_kernel(NodeLayerArgs a) {
 // -linX2-> fp32(R1) -LN2-> planes(R2) -qkv-> global.  A wave owns two 16-channel output blocks at a time; their weight
 // blocks (3 x 16 B per lane per 32-channel K chunk) stream from L2 two chunks ahead, across Linear boundaries.
 // =========================================================================================================
-typedef unsigned nu32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned nu32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 nbf16x8 __attribute__((ext_vector_type(8)));
 
 template <int DXB, int FXB>
 struct NodeGeomX3 {
@@ -211,112 +204,6 @@ struct NodeGeomX3 {
   static constexpr size_t REGION = SPLIT_BYTES > F_BYTES ? SPLIT_BYTES : F_BYTES;
   static constexpr size_t LDS_BYTES = 2 * REGION;
 };
-
-// exact three-way bf16 split of 4 consecutive channels -> 8 bytes per term
-__device__ __forceinline__ void split3_4(const f32x4& x, nu32x2& hi, nu32x2& mid, nu32x2& lo) {
-#pragma unroll
-  for (int d = 0; d < 2; ++d) {
-    const float x0 = x[2 * d], x1 = x[2 * d + 1];
-    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-    hi[d] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
-    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-    mid[d] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
-    lo[d] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
-  }
-}
-// write 4 consecutive channels of tile row `r` starting at channel c into the three planes
-template <int KS, int PLANE>
-__device__ __forceinline__ void put_split4(__bf16* planes, int r, int c, const f32x4& x) {
-  nu32x2 h, m, l;
-  split3_4(x, h, m, l);
-  __bf16* d = planes + r * KS + c;
-  *reinterpret_cast<nu32x2*>(d) = h;
-  *reinterpret_cast<nu32x2*>(d + PLANE) = m;
-  *reinterpret_cast<nu32x2*>(d + 2 * PLANE) = l;
-}
-
-struct NFrag3 { nu32x4 h, m, l; };
-constexpr int NWD = 2;                                       // K chunks of weights in flight per wave
-template <int D>
-struct NWRingT {
-  NFrag3 f[D][2];                                            // [chunk slot][output block of the pair]
-  const nu32x4* next;                                        // block pair whose first D chunks the ring holds (null: none)
-};
-using NWRing = NWRingT<NWD>;
-
-// slot pointer of 16-channel output block ob of an x3 image with KC 32-channel chunks per block
-__device__ __forceinline__ const nu32x4* w3_block(const f32x4* w3, int ob, int KC, int lane) {
-  return reinterpret_cast<const nu32x4*>(w3) + (size_t)ob * KC * 192 + lane;
-}
-template <int KC>
-__device__ __forceinline__ void w3_load(NFrag3 (&f)[2], const nu32x4* w, int kc) {
-#pragma unroll
-  for (int blk = 0; blk < 2; ++blk) {
-    f[blk].h = w[(blk * KC + kc) * 192];
-    f[blk].m = w[(blk * KC + kc) * 192 + 64];
-    f[blk].l = w[(blk * KC + kc) * 192 + 128];
-  }
-}
-// start the stream of a block pair: its first NWD chunks (L2 latency ~1 us: issued ahead of whatever precedes the Linear)
-template <int KC, int D>
-__device__ __forceinline__ void w3_prime(NWRingT<D>& r, const nu32x4* w) {
-#pragma unroll
-  for (int d = 0; d < D; ++d) w3_load<KC>(r.f[d], w, d);
-  r.next = w;
-}
-
-// acc[blk][rg] (C layout of the 16x16 MFMA: tile row 16 rg + (lane & 15) on the lane, output channels 4 (lane >> 4) + r
-// of block blk in the registers) += W . X^T for the pair of 16-channel output blocks at w (consecutive in the image).
-// The ring holds the pair's first NWD chunks on entry when r.next == w (else they are fetched here); on exit it holds
-// those of `wnext` (KCN chunks per block; when not null).
-template <int KC, int KCN, int KS, int PLANE, int NRG, int D>
-__device__ __forceinline__ void tile_linear_x3(f32x4 (&acc)[2][NRG], NWRingT<D>& r, const nu32x4* w, const nu32x4* wnext,
-                                               const __bf16* planes, int p, int g) {
-  static_assert(KC >= D && KCN >= D, "K too small for the weight ring");
-  static_assert(KC % D == 0, "chunk j of the next pair has to land in ring slot j % D");
-  const __bf16* x = planes + p * KS + 8 * g;
-  NFrag3 xf[2][NRG];
-  auto xload = [&](NFrag3 (&f)[NRG], int kc) {
-#pragma unroll
-    for (int rg = 0; rg < NRG; ++rg) {
-      const __bf16* q = x + rg * 16 * KS + 32 * kc;
-      f[rg].h = *reinterpret_cast<const nu32x4*>(q);
-      f[rg].m = *reinterpret_cast<const nu32x4*>(q + PLANE);
-      f[rg].l = *reinterpret_cast<const nu32x4*>(q + 2 * PLANE);
-    }
-  };
-  if (r.next != w) w3_prime<KC>(r, w);                       // wave-uniform
-  xload(xf[0], 0);
-#pragma unroll
-  for (int kc = 0; kc < KC; ++kc) {
-    if (kc + 1 < KC) xload(xf[(kc + 1) & 1], kc + 1);
-    __builtin_amdgcn_sched_barrier(0);
-#define SCGG_NB(v) __builtin_bit_cast(nbf16x8, v)
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-      const NFrag3& a = r.f[kc % D][blk];
-#pragma unroll
-      for (int rg = 0; rg < NRG; ++rg) {
-        const NFrag3& b = xf[kc & 1][rg];
-        f32x4 c = acc[blk][rg];
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_NB(a.l), SCGG_NB(b.h), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_NB(a.h), SCGG_NB(b.l), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_NB(a.m), SCGG_NB(b.m), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_NB(a.m), SCGG_NB(b.h), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_NB(a.h), SCGG_NB(b.m), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_NB(a.h), SCGG_NB(b.h), c, 0, 0, 0);
-        acc[blk][rg] = c;
-      }
-    }
-#undef SCGG_NB
-    __builtin_amdgcn_sched_barrier(0);
-    if (kc + D < KC) w3_load<KC>(r.f[kc % D], w, kc + D);
-    else if (wnext != nullptr) w3_load<KCN>(r.f[kc % D], wnext, kc + D - KC);
-  }
-  r.next = wnext;
-}
 
 // rows RPW w .. RPW w + RPW - 1 of the tile: res <- LN(res + lin) * gamma + beta (eps 1e-5, biased variance); the residual
 // stream stays in this wave's registers (lane = 4 channels), the normalised rows are written as split planes (the next
@@ -659,11 +546,10 @@ bool node_layer_x3_enabled() { return node_x3(); }
 
 bool node_layer_supported(int dx, int ffx) { return (dx == 256 && ffx == 256) || (dx == 128 && ffx == 128); }
 
-// row-list Linear through the x3 kernel when the shape allows (K = 128, 192, 256, 512 or 768, N a multiple of 4, padded bias), else -1
+// row-list Linear through the x3 kernel when the shape allows (K = 128, 192, 256 or 512, N a multiple of 4, padded bias), else -1
 int launch_node_linear_x3(const NodeLinearArgs& a, const f32x4_t* W3, int M, hipStream_t st) {
   if (!node_x3() || W3 == nullptr || a.lda % 4 != 0 || a.ldc % 4 != 0 || a.N % 4 != 0) return -1;
   if (a.ln_h != nullptr && a.K > 256) return -1;
-  if (a.K == 768) return launch_linear_x3<24, 2, 6>(a, W3, M, st);    // 32-row tiles: three planes of 48 rows do not fit LDS
   if (a.K == 512) return launch_linear_x3<16>(a, W3, M, st);
   if (a.K == 256) return launch_linear_x3<8, 3, 4>(a, W3, M, st);
   if (a.K == 192) return launch_linear_x3<6, 3, 3>(a, W3, M, st);

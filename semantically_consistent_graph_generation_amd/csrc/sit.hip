@@ -341,8 +341,7 @@ int buildS(scgg_sit* h, bool fill, hipStream_t st) {
   h->tabF = ar.take<float>((size_t)T * 2 * H);
   // row-list bf16x3 images of the four Linears of every block (K = hidden must be one of the built widths; fc2 in K slices
   // of 256 accumulated into the output: its whole K does not fit the kernel's LDS)
-  auto built_k = [](int k) { return k == 128 || k == 192 || k == 256 || k == 512 || k == 768; };
-  const int sw = built_k(c.mlp_hidden) ? c.mlp_hidden : 256;      // K slice of fc2
+  const int sw = 256;                                             // K slice of fc2
   const bool rowlin = (H == 128 || H == 192 || H == 256) && c.mlp_hidden % sw == 0;
   h->fc2_slice = sw;
   h->lin.assign(c.n_blocks, scgg_sit::Blk());
@@ -455,6 +454,10 @@ int stepS(scgg_sit* h, const WorkS& w, const float* x, const uint8_t* mask, int 
     return 0;
   };
   const int hd = H / c.n_heads;
+  // SCGG_SIT_FUSED=0 keeps the separate kernels (development A/B switch)
+  static const bool fused_on = [] { const char* e = getenv("SCGG_SIT_FUSED"); return !(e != nullptr && e[0] == '0'); }();
+  const bool fused = fused_on && node_layer_x3_enabled() && H == 192 && !h->lin.empty() && h->lin[0].qkv.W3 != nullptr &&
+                     h->fc2_slice == 256;
   for (int i = 0; i < c.n_blocks; ++i) {
     const std::string p = "blocks." + std::to_string(i) + ".";
     const scgg_sit::Blk& Bk = h->lin[i];
@@ -475,7 +478,9 @@ int stepS(scgg_sit* h, const WorkS& w, const float* x, const uint8_t* mask, int 
       return launch_node_linear_x3(a, L.W3, M, st);
     };
     // [gate_mlp of block i-1 (.) its MLP output] + LN + modulate(shift_msa, scale_msa), then q|k|v      (sit_model.py:129-132)
-    if (i == 0 || lin_ln(Bk.qkv, w.o, h->tab[i - 1], 5 * H, h->tab[i], 0, H, w.qkv, 3 * H, 0) != 0) {
+    if (fused && i > 0) {
+      // q|k|v of this block came out of the previous block's fused launch
+    } else if (i == 0 || lin_ln(Bk.qkv, w.o, h->tab[i - 1], 5 * H, h->tab[i], 0, H, w.qkv, 3 * H, 0) != 0) {
       TRYS(lnmod(i == 0 ? nullptr : w.o, i == 0 ? nullptr : h->tab[i - 1], 5 * H, h->tab[i], 0, H));
       if (lin(Bk.qkv, w.u, H, w.qkv, 3 * H, 0) != 0) TRYS(gemmS(h, w.u, H, p + "attn.qkv", w.qkv, 3 * H, M, 3 * H, H, st));
     }
@@ -483,6 +488,15 @@ int stepS(scgg_sit* h, const WorkS& w, const float* x, const uint8_t* mask, int 
     else if (hd == 16) hipLaunchKernelGGL(sit_attn_kernel<16>, dim3(B, c.n_heads), dim3(64), 0, st, w.qkv, mask, w.att, n, H, 1.0f / sqrtf((float)hd));
     else if (hd == 64) hipLaunchKernelGGL(sit_attn_kernel<64>, dim3(B, c.n_heads), dim3(64), 0, st, w.qkv, mask, w.att, n, H, 1.0f / sqrtf((float)hd));
     else return fail("sit: head dim %d not built (16, 32, 64)", hd);
+    if (fused) {                                                 // everything up to the next attention in one launch
+      const bool last = i + 1 == c.n_blocks;
+      SitBlockArgs fa{w.att, w.h, w.o, Bk.proj.W3, Bk.fc1.W3, Bk.fc2[0].W3, last ? nullptr : h->lin[i + 1].qkv.W3, Bk.proj.b, Bk.fc1.b,
+                      Bk.fc2[0].b, last ? nullptr : h->lin[i + 1].qkv.b, h->tab[i], last ? nullptr : h->tab[i + 1], w.qkv, w.rows,
+                      w.row_count, t_ptr, t_const, n, (int)Bk.fc2.size(),
+                      Bk.fc2.size() > 1 ? (long long)(Bk.fc2[1].W3 - Bk.fc2[0].W3) : 0};
+      if (launch_sit_block(fa, H, M, st) != 0) return fail("sit: fused block launch failed");
+      continue;
+    }
     if (lin(Bk.proj, w.att, H, w.o, H, 0) != 0) TRYS(gemmS(h, w.att, H, p + "attn.proj", w.o, H, M, H, H, st));
     // gate_msa (.) attention + h, LN, modulate(shift_mlp, scale_mlp), then fc1 + GELU
     if (lin_ln(Bk.fc1, w.o, h->tab[i], 2 * H, h->tab[i], 3 * H, 4 * H, w.f, c.mlp_hidden, 2) != 0) {
