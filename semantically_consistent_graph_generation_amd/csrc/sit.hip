@@ -10,12 +10,16 @@
 //   * everything that depends on t only -- the timestep embedding, its MLP, the SiLU and the adaLN Linear of every block
 //     and of the final layer -- is computed for ALL timesteps once per weight set (finalize: GEMMs with M = noise_steps)
 //     into tables; a step reads its six vectors per block from them.
-//   * per step the dense Linears (qkv, proj, fc1, fc2) run as fp32-MFMA GEMMs over all B n rows; the glue between them is
-//     fused: [gated residual of the previous sub-layer + LayerNorm + modulate] is one kernel (16 lanes per row), attention
-//     is one wave per (graph, head) with the head's keys / values of a 64-key chunk in LDS and an online softmax (padded
-//     keys are skipped, which is exact: the reference gives them -1e9 and a valid query always has itself as a key), and
-//     [last gated residual + final LayerNorm / modulate + the 192 -> 3 Linear + the DDPM update x_{t-1} = ... + sqrt(beta) z]
-//     is one kernel.  45 launches per step, no synchronisation, no allocation.
+//   * a step works on the valid rows only (row list from the mask).  Block 0's entry is [pos_embedder + LayerNorm +
+//     modulate] (16 lanes per row) and a row-list bf16x3 Linear for q|k|v; attention is one wave per (graph, head) on the
+//     matrix pipe for n <= 64 (transposed scores, so the normalised P^T registers are the operand of P.V), else with the
+//     head's keys / values of a 64-key chunk in LDS and an online softmax (padded keys are skipped, which is exact: the
+//     reference gives them -1e9 and a valid query always has itself as a key); everything from an attention to the next
+//     one -- proj, gated residual, LayerNorm-modulate, fc1 + GELU, fc2, gated residual, the next block's LayerNorm-modulate
+//     and q|k|v -- is ONE launch (sit_block.hip); [last gated residual + final LayerNorm / modulate + the 192 -> 3 Linear +
+//     the DDPM update x_{t-1} = ... + sqrt(beta) z] is one kernel.  15 launches per step, no synchronisation, no
+//     allocation.  Widths the fused kernel is not built for run as separate row-list Linears (with the LayerNorm-modulate
+//     as their prologue and GELU / accumulate epilogues) or, below those, through the generic fp32-MFMA GEMM.
 //   * the normal draws are Philox4x32-10 + Box-Muller keyed by (seed, graph id, node, step), or a caller-provided buffer
 //     (tests: the oracle takes the same draws).  The reference draws torch.randn from the global generator.
 // Padded tokens: the reference lets them evolve too (they attend uniformly to every slot); nothing downstream reads them
@@ -190,6 +194,103 @@ __global__ __launch_bounds__(64) void sit_attn_kernel(const float* __restrict__ 
         for (int e = 0; e < 4; ++e) ov[e] = acc[4 * k + e] * inv;
         *reinterpret_cast<f32x4*>(o + 4 * k) = ov;
       }
+    }
+  }
+}
+
+// The same attention on the matrix pipe for n <= 64 (v_mfma_f32_16x16x4_f32, fp32 operands): one wave per (graph, head), no
+// LDS.  Scores are formed transposed, S^T[key][query] = K . Q^T (A = K tile, B = Q tile; a lane holds HD/4 consecutive
+// channels of its key / query row, two float4 loads), so a lane ends up with query (lane & 15) and keys 4 (lane >> 4) + r
+// of every 16-key tile: the softmax over keys is in-lane plus two lane exchanges, and the normalised P^T registers are, as
+// they stand, the A operand of P . V (k index <-> key 4 g + r); V is read as the B operand (lane = channel, 4 keys).
+// Masked keys: score -inf, V taken as 0 (their q|k|v rows are never written).
+template <int HD>
+__global__ __launch_bounds__(256) void sit_attn_mfma_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ mask,
+                                                            float* __restrict__ out, int n, int H, int n_heads, int total, float scale) {
+  constexpr int KST = HD / 4, DT = HD / 16, MAXT = 4;
+  const int widx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (widx >= total) return;                                   // wave-uniform
+  const int b = widx / n_heads, head = widx % n_heads, lane = threadIdx.x & 63, x = lane & 15, g = lane >> 4;
+  const int nt = (n + 15) >> 4;
+  const uint8_t* mb = mask + (long long)b * n;
+  const float* base = qkv + (long long)b * n * 3 * H + head * HD;
+  float kf[MAXT][KST], vf[MAXT][DT][4];
+  bool kv[MAXT][4];                                            // validity of key 16 kt + 4 g + r
+#pragma unroll
+  for (int kt = 0; kt < MAXT; ++kt) {
+    if (kt >= nt) continue;
+    const int key = 16 * kt + x;
+    const bool ok = key < n && mb[key] != 0;
+#pragma unroll
+    for (int q4 = 0; q4 < KST / 4; ++q4) {
+      f32x4 t = splat4(0.f);
+      if (ok) t = ld4(base + (long long)key * 3 * H + H + KST * g + 4 * q4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) kf[kt][4 * q4 + e] = t[e];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kr = 16 * kt + 4 * g + r;
+      kv[kt][r] = kr < n && mb[kr] != 0;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) vf[kt][dt][r] = kv[kt][r] ? base[(long long)kr * 3 * H + 2 * H + 16 * dt + x] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int qt = 0; qt < MAXT; ++qt) {
+    if (qt >= nt) continue;
+    const int qi = 16 * qt + x;
+    const bool qok = qi < n && mb[qi] != 0;
+    float qf[KST];
+#pragma unroll
+    for (int q4 = 0; q4 < KST / 4; ++q4) {
+      f32x4 t = splat4(0.f);
+      if (qok) t = ld4(base + (long long)qi * 3 * H + KST * g + 4 * q4) * scale;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qf[4 * q4 + e] = t[e];
+    }
+    f32x4 sT[MAXT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < MAXT; ++kt) {
+      if (kt >= nt) continue;
+      f32x4 acc = splat4(0.f);
+#pragma unroll
+      for (int s = 0; s < KST; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][s], qf[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[r] = kv[kt][r] ? acc[r] : -INFINITY;
+        m = fmaxf(m, acc[r]);
+      }
+      sT[kt] = acc;
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < MAXT; ++kt) {
+      if (kt >= nt) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sT[kt][r] = __expf(sT[kt][r] - m);                     // masked keys: exp(-inf) = 0
+        l += sT[kt][r];
+      }
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      f32x4 acc = splat4(0.f);
+#pragma unroll
+      for (int kt = 0; kt < MAXT; ++kt) {
+        if (kt >= nt) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sT[kt][r] * inv, vf[kt][dt][r], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)                              // acc[r]: query 16 qt + 4 g + r, channel 16 dt + x
+        if (kv[qt][r]) out[((long long)b * n + 16 * qt + 4 * g + r) * H + head * HD + 16 * dt + x] = acc[r];
     }
   }
 }
@@ -484,7 +585,13 @@ int stepS(scgg_sit* h, const WorkS& w, const float* x, const uint8_t* mask, int 
       TRYS(lnmod(i == 0 ? nullptr : w.o, i == 0 ? nullptr : h->tab[i - 1], 5 * H, h->tab[i], 0, H));
       if (lin(Bk.qkv, w.u, H, w.qkv, 3 * H, 0) != 0) TRYS(gemmS(h, w.u, H, p + "attn.qkv", w.qkv, 3 * H, M, 3 * H, H, st));
     }
-    if (hd == 32) hipLaunchKernelGGL(sit_attn_kernel<32>, dim3(B, c.n_heads), dim3(64), 0, st, w.qkv, mask, w.att, n, H, 1.0f / sqrtf((float)hd));
+    // SCGG_SIT_ATTN=valu keeps the LDS / vector-unit kernel for every size (development A/B switch)
+    static const bool attn_mfma = [] { const char* e = getenv("SCGG_SIT_ATTN"); return !(e != nullptr && e[0] == 'v'); }();
+    if (hd == 32 && n <= 64 && attn_mfma) {
+      const int total = B * c.n_heads;
+      hipLaunchKernelGGL(sit_attn_mfma_kernel<32>, dim3((total + 3) / 4), dim3(256), 0, st, w.qkv, mask, w.att, n, H, c.n_heads, total,
+                         1.0f / sqrtf((float)hd));
+    } else if (hd == 32) hipLaunchKernelGGL(sit_attn_kernel<32>, dim3(B, c.n_heads), dim3(64), 0, st, w.qkv, mask, w.att, n, H, 1.0f / sqrtf((float)hd));
     else if (hd == 16) hipLaunchKernelGGL(sit_attn_kernel<16>, dim3(B, c.n_heads), dim3(64), 0, st, w.qkv, mask, w.att, n, H, 1.0f / sqrtf((float)hd));
     else if (hd == 64) hipLaunchKernelGGL(sit_attn_kernel<64>, dim3(B, c.n_heads), dim3(64), 0, st, w.qkv, mask, w.att, n, H, 1.0f / sqrtf((float)hd));
     else return fail("sit: head dim %d not built (16, 32, 64)", hd);

@@ -43,6 +43,21 @@ def test_sit_forward_matches_reference(name):
     assert float(out.cpu()[~m].abs().max()) == 0.0 if (~m).any() else True
 
 
+def test_sit_forward_beyond_64_nodes_matches_oracle():
+    """n > 64 takes the LDS / vector-unit attention kernel (the matrix-pipe one holds at most four 16-key tiles); checked
+    against the oracle's forward, which the h1 fixtures pin."""
+    model, sd, _ = build(604)
+    m = fx.ragged_mask([70, 33, 1])
+    B, n = m.shape
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, n, 3, generator=g)
+    t = torch.tensor([999, 500, 1])
+    out = model(x.cuda(), t.cuda(), m.cuda())
+    torch.cuda.synchronize()
+    want = S.sit_forward(sd, x, t, m) * m[..., None]
+    assert rel_err(out, want) < REL
+
+
 def test_sampler_matches_oracle_under_the_same_draws():
     """8 ancestral steps from i = 999 and, with noise_steps = 6, a whole chain down to i = 1 (the step without noise)."""
     from semantically_consistent_graph_generation_amd.node_coordinate_diffusion import SiT_models
