@@ -506,6 +506,12 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   // input MLP, beside the X chain on the second stream.  The caller's stream first waits until the second stream has
   // caught up with whatever the caller queued there (the producers of y, scgg_denoiser_side_stream).
   const bool y_on_main = y_layer_supported(dy, c.dim_ffy, dy + 4 * dx + 4 * de) && n_run_layers > 0;
+  // One stream: the y round takes the pooled statistics of X(l) and E(l) itself (pool_stats.h) -- the separate statistics
+  // kernels exist to run BESIDE other work, and here they would only add two launches per layer in front of it.
+  // SCGG_Y_POOL=0 keeps them (development A/B switch).
+  static const bool y_pool_on = [] { const char* e = getenv("SCGG_Y_POOL"); return !(e != nullptr && e[0] == '0'); }();
+  const bool y_pools = !two_streams && y_pool_on && y_layer_supported(dy, c.dim_ffy, kcat) && dx % 4 == 0 && dx <= 512 &&
+                       256 % (dx / 4) == 0 && de % 4 == 0 && de <= 256 && 256 % (de / 4) == 0 && n <= 512;
   bool pooled_e0 = false;
   bool head_fused = false;   // the last node kernel also ran mlp_out_X.0
   {
@@ -513,7 +519,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     if (launch_edge_mlp_in(a, c.in_E, c.hid_E, de, st)) return fail("edge_mlp_in: unsupported dims");
     // Etoy of E(0) for the fused y path: on the caller's stream, which idles from here until the FiLM vectors of layer 0
     // are ready (the second stream is still busy with the X / y prologue)
-    pooled_e0 = y_layer_supported(dy, c.dim_ffy, kcat) && n_run_layers > 0 && h->layers[0].predicts_y;
+    pooled_e0 = !y_pools && y_layer_supported(dy, c.dim_ffy, kcat) && n_run_layers > 0 && h->layers[0].predicts_y;
     if (pooled_e0) {
       EdgePoolArgs ep{w.E0, mask, w.epool, B, n, de, 4 * de, 0};
       if (launch_edge_pool_stats(ep, st)) return fail("edge_pool_stats: unsupported de=%d or n=%d", de, n);
@@ -575,7 +581,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
                           2 * dx, 3 * dx, 4 * dx)) return -1;
       if (!(fused_y && y_on_main) && signal(ev(l, EV_FILM), ax)) return fail("event record failed");
     }
-    if (L.predicts_y) {
+    if (L.predicts_y && !y_pools) {
       if (!fused_y) launch_copy_cols(w.y, dy, w.ycat, kcat, B, dy, ax);
       if (l > 0 && await(ax, ev(l - 1, EV_X))) return fail("stream wait failed");
       NodeStatsArgs ns{Xcur, mask, w.ycat, B, n, dx, kcat, dy};
@@ -585,7 +591,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     // Etoy of the layer INPUT E(l) (:239-243).  Fused y path: E(0) here, E(l+1) at the end of round l (beside the node
     // kernel); unfused: every layer here, straight into the ycat row.
     if (l == 0 && await(ax, ev_e0)) return fail("stream wait failed");
-    if (L.predicts_y && (l == 0 || !fused_y) && !(l == 0 && pooled_e0)) {
+    if (L.predicts_y && !y_pools && (l == 0 || !fused_y) && !(l == 0 && pooled_e0)) {
       EdgePoolArgs ep{Ecur, mask, fused_y ? w.epool : w.ycat, B, n, de, fused_y ? 4 * de : kcat, fused_y ? 0 : dy + 4 * dx};
       if (launch_edge_pool_stats(ep, ax)) return fail("edge_pool_stats: unsupported de=%d or n=%d", de, n);
     }
@@ -624,6 +630,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
         ya.y = w.y; ya.ycat = w.ycat; ya.etoy = w.epool + (size_t)(l & 1) * B * 4 * de;
         ya.B = B; ya.dy = dy; ya.ffy = c.dim_ffy; ya.kcat = kcat; ya.dx = dx;
         ya.update = L.predicts_y ? 1 : 0;
+        if (y_pools && L.predicts_y) { ya.pool_X = Xcur; ya.pool_E = Ecur; ya.mask = mask; ya.n = n; ya.de = de; }
         // The y round needs nothing from edge kernel l and is not held back for it: one y workgroup (50 VGPRs, 36 KB of
         // LDS at ConStruct dims) fits on a CU beside one edge workgroup (2 x 200 VGPRs per SIMD lane, 122 KB).
         if (L.predicts_y) {
@@ -641,7 +648,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
         if (launch_y_layer(ya, ax)) return fail("y_layer launch failed");
         if (next_layer && signal(ev(l + 1, EV_FILM), ax)) return fail("event record failed");
       }
-      if (next_layer && h->layers[l + 1].predicts_y) {   // Etoy of E(l+1), the tensor edge kernel l has just written
+      if (next_layer && h->layers[l + 1].predicts_y && !y_pools) {   // Etoy of E(l+1), the tensor edge kernel l has just written
         if (await(ax, ev(l, EV_EDGE))) return fail("stream wait failed");
         EdgePoolArgs ep{Enext, mask, w.epool + (size_t)((l + 1) & 1) * B * 4 * de, B, n, de, 4 * de, 0};
         if (launch_edge_pool_stats(ep, ax)) return fail("edge_pool_stats: unsupported de=%d or n=%d", de, n);

@@ -25,6 +25,7 @@
 // newX_pre.  If a channel underflows against M the unit falls back to exact per-channel maxima.
 #include <stdlib.h>
 
+#include "pool_stats.h"
 #include "mfma_chain.h"
 #include "c16.h"
 #include "kernels.h"
@@ -1492,112 +1493,12 @@ int launch_attn_finish(const AttnFinishArgs& a, int M, hipStream_t st) {
 // diagonal included.  One workgroup per graph; thread = (channel, slice of the unordered pairs); each stored element
 // is read once (pair {i,j} = 0.5 (E_ij + E_ji), weight 2); one pass, shifted sums merged pairwise (see below).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int POOL_T = 256;   // threads per graph; 9 KB of LDS: fits on a CU beside a 12-wave edge workgroup (23 KB free)
+constexpr int POOL_T = PS_T;  // threads per graph (pool_stats.h, where the arithmetic lives: y_layer_kernel shares it)
 __global__ __launch_bounds__(POOL_T) void edge_pool_stats_kernel(EdgePoolArgs a) {
-  __shared__ f32x4 red[2][POOL_T];
-  __shared__ short vidx[512];                                             // the valid nodes, in order
-  __shared__ int wcount[POOL_T / 64];
-  const int b = blockIdx.x, n = a.n, DE = a.de, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // thread = (4 channels c4, slice sl of the unordered pairs): one 16-byte load per stored element, 1 KiB per wave
-  const int G4 = DE / 4, S = POOL_T / G4, c4 = tid % G4, sl = tid / G4;
-  const uint8_t* m = a.mask + (long long)b * n;
-  int nv = 0;
-  for (int i0 = 0; i0 < n; i0 += POOL_T) {                                // compaction of the mask
-    const int i = i0 + tid;
-    const bool v = i < n && m[i] != 0;
-    const unsigned long long bal = __ballot(v);
-    if (lane == 0) wcount[wave] = __popcll(bal);
-    __syncthreads();
-    int off = nv, tot = 0;
-    for (int w = 0; w < POOL_T / 64; ++w) {
-      if (w < wave) off += wcount[w];
-      tot += wcount[w];
-    }
-    if (v) vidx[off + __popcll(bal & ((1ull << lane) - 1ull))] = (short)i;
-    nv += tot;
-    __syncthreads();
-  }
-  const float* E = a.E + (long long)b * n * n * DE + 4 * c4;
-  const float cnt = (float)nv * (float)nv;
-  // the unordered pairs ii < jj in row-major order; slice sl takes pairs sl, sl + S, ...: (ii, r) walks that sequence,
-  // r = position inside row ii (jj = ii + 1 + r), row ii holds nv - 1 - ii pairs
-  auto walk = [&](auto&& use) {
-    int ii = 0, r = sl;
-    while (true) {
-      while (ii < nv - 1 && r >= nv - 1 - ii) { r -= nv - 1 - ii; ++ii; }
-      if (ii >= nv - 1) break;
-      const long long i = vidx[ii], j = vidx[ii + 1 + r];
-      const f32x4 x = *reinterpret_cast<const f32x4*>(E + (i * n + j) * DE);
-      const f32x4 y = *reinterpret_cast<const f32x4*>(E + (j * n + i) * DE);
-      use(0.5f * (x + y));
-      r += S;
-    }
-  };
-  // ---- one pass.  Thread t keeps, for its slice of the pairs, the sum and the sum of squares of (v - k_t), k_t = the
-  //      first value it sees: the differences are of the size of the spread, so M2_t = q - s^2 / n_t loses nothing to
-  //      cancellation; the slices are then merged with the pairwise-variance update (Chan et al.), which is as accurate
-  //      as the two-pass form this replaces and reads E once instead of twice.
-  f32x4 k = splat4(0.f), s1 = splat4(0.f), q = splat4(0.f), mn = splat4(INFINITY), mx = splat4(-INFINITY);
-  int cnt_t = 0;
-  walk([&](const f32x4& v) {
-    if (cnt_t == 0) k = v;
-    ++cnt_t;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float d = v[e] - k[e];
-      s1[e] += d; q[e] += d * d;
-      mn[e] = fminf(mn[e], v[e]); mx[e] = fmaxf(mx[e], v[e]);
-    }
-  });
-  if (nv > 0) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { mn[e] = fminf(mn[e], 0.f); mx[e] = fmaxf(mx[e], 0.f); }   // the diagonal
-  }
-  const float nt = (float)cnt_t, inv_nt = cnt_t > 0 ? 1.f / nt : 0.f;
-  f32x4 mean_t, m2_t;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { mean_t[e] = k[e] + s1[e] * inv_nt; m2_t[e] = q[e] - s1[e] * s1[e] * inv_nt; }
-  red[0][tid] = mean_t; red[1][tid] = m2_t;
-  __syncthreads();
-  f32x4 mean = mean_t, m2 = m2_t;
-  const int np_all = nv * (nv - 1) / 2;
-  if (sl == 0) {
-    float na = nt;
-    for (int t = 1; t < S; ++t) {
-      const int c = t < np_all ? (np_all - t + S - 1) / S : 0;        // pairs of slice t: t, t + S, ...
-      if (c == 0) break;
-      const float nb = (float)c, nab = na + nb;
-      const f32x4 mb = red[0][t * G4 + c4], qb = red[1][t * G4 + c4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float d = mb[e] - mean[e];
-        mean[e] += d * (nb / nab);
-        m2[e] += qb[e] + d * d * (na * nb / nab);
-      }
-      na = nab;
-    }
-  }
-  __syncthreads();
-  red[0][tid] = mn; red[1][tid] = mx;
-  __syncthreads();
-  if (sl == 0) {
-    for (int t = 1; t < S; ++t) {
-      const f32x4 n2 = red[0][t * G4 + c4], x2 = red[1][t * G4 + c4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { mn[e] = fminf(mn[e], n2[e]); mx[e] = fmaxf(mx[e], x2[e]); }
-    }
-    // from the unordered pairs (mean, M2 about it, np_all of them) to all nv x nv entries: every pair counts twice, the
-    // nv diagonal entries are zero
-    float* z = a.z + (long long)b * a.z_stride + a.z_offset + 4 * c4;
-    const float npf = (float)np_all;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float m = 2.f * npf * mean[e] / cnt;
-      const float dm = mean[e] - m;
-      const float qq = 2.f * (m2[e] + npf * dm * dm) + (float)nv * m * m;
-      z[e] = m; z[DE + e] = mn[e]; z[2 * DE + e] = mx[e]; z[3 * DE + e] = qq / cnt;
-    }
-  }
+  __shared__ PoolScratch ps;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int nv = pool_compact_mask(ps, a.mask + (long long)b * a.n, a.n, tid);
+  pool_etoy_graph(ps, a.E + (long long)b * a.n * a.n * a.de, a.n, nv, a.de, a.z + (long long)b * a.z_stride + a.z_offset, tid);
 }
 
 int launch_edge_pool_stats(const EdgePoolArgs& a, hipStream_t st) {

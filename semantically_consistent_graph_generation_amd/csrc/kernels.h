@@ -246,6 +246,12 @@ struct YLayerArgs {       // fused global-feature part of one layer (y_layer.hip
   int B, dy, ffy, kcat, dx;
   int update;             // 0: only the FiLM vectors of the current y
   int film_n;             // 0: 4 dx FiLM outputs with +1 on the "mul" quarters (2D block); > 0: film_n raw outputs
+  // Optional (update = 1): the workgroup takes the pooled statistics of its graph itself instead of reading ycat / etoy
+  // (pool_stats.h; the forward on one stream: nothing runs beside the y round that could have produced them earlier)
+  const float* pool_X;    // [B,n,dx] the layer's input X, or null: Xtoy from ycat
+  const float* pool_E;    // [B,n,n,de] the layer's input E (hidden, unsymmetrised), or null: Etoy from etoy
+  const uint8_t* mask;    // [B,n]
+  int n, de;
 };
 
 bool y_layer_supported(int dy, int ffy, int kcat);

@@ -4,6 +4,7 @@
 // These serve q/k/v, x_out, linX1/2, the y-FiLM vectors, the whole y path and the X in/out MLPs
 // (transformer_model.py:179-180,218,230-246,88-92,101-106,281-305,322-342); they are O(B*n*d^2) and small next
 // to the edge path, but still dense contractions, so they run on the matrix cores in exact fp32.
+#include "pool_stats.h"
 #include "mfma_chain.h"
 #include "c16.h"
 #include "kernels.h"
@@ -309,73 +310,13 @@ int launch_add_layernorm(const AddLnArgs& a, hipStream_t st) {
 // One workgroup per graph; thread = (4 channels, slice of the rows): float4 loads, the rows of a slice are independent
 // loads in flight together (the kernel runs beside the edge kernel's start and sits in front of the y round, so its
 // latency chain matters, not its bytes).  dx % 4 == 0, dx / 4 divides NS_T; the valid nodes come first in a list in LDS.
-constexpr int NS_T = 256;      // 14 KB of LDS: has to fit on a CU beside a 12-wave edge workgroup (23 KB free)
+constexpr int NS_T = PS_T;     // pool_stats.h, where the arithmetic lives (y_layer_kernel shares it)
 __global__ __launch_bounds__(NS_T) void node_stats_kernel(NodeStatsArgs a) {
-  __builtin_amdgcn_s_setprio(3);   // runs beside the edge kernel and in front of the y round: issue first
-  __shared__ f32x4_t red[3][NS_T];
-  __shared__ f32x4_t smean[128];
-  __shared__ short vidx[512];
-  __shared__ int nvs;
-  const int b = blockIdx.x, n = a.n, dx = a.dx, tid = threadIdx.x;
-  const int G4 = dx / 4, S = NS_T / G4, c4 = tid % G4, sl = tid / G4;
-  const uint8_t* m = a.mask + (long long)b * n;
-  if (tid < 64) {                                    // wave 0 compacts the mask (n <= 512: 8 rounds of 64)
-    int nv = 0;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-      const int i = i0 + tid;
-      const bool v = i < n && m[i] != 0;
-      const unsigned long long bal = __ballot(v);
-      if (v) vidx[nv + __popcll(bal & ((1ull << tid) - 1ull))] = (short)i;
-      nv += __popcll(bal);
-    }
-    if (tid == 0) nvs = nv;
-  }
-  __syncthreads();
-  const int nv = nvs;
-  const float* X = a.X + (long long)b * n * dx + 4 * c4;
-  f32x4_t s = {0.f, 0.f, 0.f, 0.f}, mn = {INFINITY, INFINITY, INFINITY, INFINITY}, mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-  if (sl < S) {
-#pragma unroll 4
-    for (int k = sl; k < nv; k += S) {
-      const f32x4_t v = *reinterpret_cast<const f32x4_t*>(X + (long long)vidx[k] * dx);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { s[e] += v[e]; mn[e] = fminf(mn[e], v[e]); mx[e] = fmaxf(mx[e], v[e]); }
-    }
-  }
-  red[0][tid] = s; red[1][tid] = mn; red[2][tid] = mx;
-  __syncthreads();
-  if (sl == 0) {
-    for (int t = 1; t < S; ++t) {
-      const f32x4_t s2 = red[0][t * G4 + c4], n2 = red[1][t * G4 + c4], x2 = red[2][t * G4 + c4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { s[e] += s2[e]; mn[e] = fminf(mn[e], n2[e]); mx[e] = fmaxf(mx[e], x2[e]); }
-    }
-    smean[c4] = s / (float)nv;
-    red[1][c4] = mn; red[2][c4] = mx;
-  }
-  __syncthreads();
-  const f32x4_t mean = smean[c4];
-  f32x4_t q = {0.f, 0.f, 0.f, 0.f};
-  if (sl < S) {
-#pragma unroll 4
-    for (int k = sl; k < nv; k += S) {
-      const f32x4_t v = *reinterpret_cast<const f32x4_t*>(X + (long long)vidx[k] * dx);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { const float d = v[e] - mean[e]; q[e] += d * d; }
-    }
-  }
-  __syncthreads();
-  red[0][tid] = q;
-  __syncthreads();
-  if (sl == 0) {
-    for (int t = 1; t < S; ++t) q += red[0][t * G4 + c4];
-    float* z = a.z + (long long)b * a.z_stride + a.z_offset + 4 * c4;
-    const f32x4_t mnv = red[1][c4], mxv = red[2][c4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      z[e] = mean[e]; z[dx + e] = mnv[e]; z[2 * dx + e] = mxv[e]; z[3 * dx + e] = q[e] / (float)nv;
-    }
-  }
+  __builtin_amdgcn_s_setprio(3);   // two-stream schedule: runs beside the edge kernel and in front of the y round: issue first
+  __shared__ PoolScratch ps;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int nv = pool_compact_mask(ps, a.mask + (long long)b * a.n, a.n, tid);
+  pool_xtoy_graph(ps, a.X + (long long)b * a.n * a.dx, nv, a.dx, a.z + (long long)b * a.z_stride + a.z_offset, tid);
 }
 
 int launch_node_stats(const NodeStatsArgs& a, hipStream_t st) {

@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "kernels.h"
+#include "pool_stats.h"
 
 namespace scgg {
 
@@ -150,12 +151,20 @@ __global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
   const int b0 = blockIdx.x * YG;
 
   if (a.update) {
+    const int e0 = dy + 4 * a.dx;
+    const bool own_x = YG == 1 && YT == PS_T && a.pool_X != nullptr, own_e = YG == 1 && YT == PS_T && a.pool_E != nullptr;
     for (int idx = tid; idx < YG * kcat; idx += YT) {
       const int g = idx / kcat, c = idx - g * kcat;
       const int b = min(b0 + g, a.B - 1);
-      const int e0 = dy + 4 * a.dx;
-      cat[idx] = c < dy ? a.y[(size_t)b * dy + c]
-                        : (c < e0 ? a.ycat[(size_t)b * kcat + c] : a.etoy[(size_t)b * (kcat - e0) + (c - e0)]);
+      if (c < dy) cat[idx] = a.y[(size_t)b * dy + c];
+      else if (c < e0) { if (!own_x) cat[idx] = a.ycat[(size_t)b * kcat + c]; }
+      else if (!own_e) cat[idx] = a.etoy[(size_t)b * (kcat - e0) + (c - e0)];
+    }
+    if (own_x || own_e) {                                          // wave-uniform; the statistics of this graph, straight into cat
+      __shared__ PoolScratch ps;
+      const int nv = pool_compact_mask(ps, a.mask + (size_t)b0 * a.n, a.n, tid);
+      if (own_x) pool_xtoy_graph(ps, a.pool_X + (size_t)b0 * a.n * a.dx, nv, a.dx, cat + dy, tid);
+      if (own_e) pool_etoy_graph(ps, a.pool_E + (size_t)b0 * a.n * a.n * a.de, a.n, nv, a.de, cat + e0, tid);
     }
   }
   for (int idx = tid; idx < YG * dy; idx += YT) {
@@ -210,6 +219,9 @@ bool y_layer_supported(int dy, int ffy, int kcat) {
 
 int launch_y_layer(const YLayerArgs& a, hipStream_t st) {
   if (!y_layer_supported(a.dy, a.ffy, a.kcat)) return -1;
+  if (a.pool_X != nullptr && (YG != 1 || a.dx % 4 != 0 || a.dx > 512 || PS_T % (a.dx / 4) != 0 || a.n > 512 || a.mask == nullptr)) return -1;
+  if (a.pool_E != nullptr && (YG != 1 || a.de % 4 != 0 || a.de > 256 || PS_T % (a.de / 4) != 0 || a.n > 512 || a.mask == nullptr ||
+                              a.kcat != a.dy + 4 * a.dx + 4 * a.de)) return -1;
   const size_t lds = y_layer_lds(a.dy, a.ffy, a.kcat);
   static size_t attr_lds[MAX_DEVICES] = {};   // per device: the largest size asked for so far (engines of different widths share the kernel)
   const int dev = current_device();
