@@ -451,7 +451,10 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   //      bit-identical -- so the schedule stays available (SCGG_TWO_STREAMS=1) but is not the default until the cause is
   //      known.  In one-stream mode `ax` is `st`, the events are not needed, and the aux stream is only joined at the start
   //      (the caller may have queued the producers of X / y there: scgg_denoiser_side_stream).
-  static const bool two_streams = getenv("SCGG_TWO_STREAMS") != nullptr;
+  // SCGG_TWO_STREAMS: unset = one stream; "y" = only the y round of a layer on the second stream, beside that layer's edge
+  // kernel (it needs X(l), E(l) and y only); anything else = the round-1 schedule (not reproducible)
+  static const int stream_mode = [] { const char* e = getenv("SCGG_TWO_STREAMS"); return e == nullptr ? 0 : (e[0] == 'y' ? 2 : 1); }();
+  const bool two_streams = stream_mode == 1;
   hipStream_t ax = two_streams ? h->aux : st;
   if (!two_streams && (hipEventRecord(h->sync_ev[0], h->aux) != hipSuccess || hipStreamWaitEvent(st, h->sync_ev[0], 0) != hipSuccess))
     return fail("stream join failed");
@@ -509,6 +512,9 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   // One stream: the y round takes the pooled statistics of X(l) and E(l) itself (pool_stats.h) -- the separate statistics
   // kernels exist to run BESIDE other work, and here they would only add two launches per layer in front of it.
   // SCGG_Y_POOL=0 keeps them (development A/B switch).
+  const bool y_beside = stream_mode == 2 && y_layer_supported(dy, c.dim_ffy, kcat);
+  auto rec = [&](hipEvent_t e, hipStream_t s2) { return hipEventRecord(e, s2) != hipSuccess; };
+  auto hold = [&](hipStream_t s2, hipEvent_t e) { return hipStreamWaitEvent(s2, e, 0) != hipSuccess; };
   static const bool y_pool_on = [] { const char* e = getenv("SCGG_Y_POOL"); return !(e != nullptr && e[0] == '0'); }();
   const bool y_pools = !two_streams && y_pool_on && y_layer_supported(dy, c.dim_ffy, kcat) && dx % 4 == 0 && dx <= 512 &&
                        256 % (dx / 4) == 0 && de % 4 == 0 && de <= 256 && 256 % (de / 4) == 0 && n <= 512;
@@ -588,6 +594,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       if (launch_node_stats(ns, ax)) return fail("node_stats: unsupported dx=%d or n=%d", dx, n);
     }
     if (signal(ev(l, EV_NS), ax)) return fail("event record failed");
+    if (y_beside && rec(ev(l, EV_NS), st)) return fail("event record failed");      // X(l), E(l), y are final here
     // Etoy of the layer INPUT E(l) (:239-243).  Fused y path: E(0) here, E(l+1) at the end of round l (beside the node
     // kernel); unfused: every layer here, straight into the ycat row.
     if (l == 0 && await(ax, ev_e0)) return fail("stream wait failed");
@@ -645,8 +652,10 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
           ya.Wt_l1 = L.Wt_l1; ya.b_l1 = l1b->p; ya.Wt_l2 = L.Wt_l2; ya.b_l2 = l2b->p;
         }
         if (next_layer) { ya.Wt_film = h->layers[l + 1].Wt_film; ya.b_film = h->layers[l + 1].bfilm; ya.film = film_next; }
-        if (launch_y_layer(ya, ax)) return fail("y_layer launch failed");
+        if (y_beside && hold(h->aux, ev(l, EV_NS))) return fail("stream wait failed");
+        if (launch_y_layer(ya, y_beside ? h->aux : ax)) return fail("y_layer launch failed");
         if (next_layer && signal(ev(l + 1, EV_FILM), ax)) return fail("event record failed");
+        if (y_beside && next_layer && rec(ev(l + 1, EV_FILM), h->aux)) return fail("event record failed");
       }
       if (next_layer && h->layers[l + 1].predicts_y && !y_pools) {   // Etoy of E(l+1), the tensor edge kernel l has just written
         if (await(ax, ev(l, EV_EDGE))) return fail("stream wait failed");
@@ -678,6 +687,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       const Param* g2 = P_(h, p + "normX2.weight", dx); const Param* b2 = P_(h, p + "normX2.bias", dx);
       if (!g1 || !b1 || !g2 || !b2) return -1;
       if (fused_y && l + 1 < n_run_layers && await(st, ev(l + 1, EV_FILM))) return fail("stream wait failed");
+      if (y_beside && l + 1 < n_run_layers && hold(st, ev(l + 1, EV_FILM))) return fail("stream wait failed");
       // in place: X is overwritten from here on, its pooled statistics must have been taken; double-buffered: nothing
       // to wait for (the buffer written now was last read two layers ago)
       if (!dbl_X && await(st, ev(l, EV_NS))) return fail("stream wait failed");
@@ -715,6 +725,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     float* t = Ecur; Ecur = Enext; Enext = t;
     if (check_launch("layer")) return -1;
   }
+  if (y_beside && (rec(ev_join, h->aux) || hold(st, ev_join))) return fail("stream join failed");   // the last y round
   // the aux stream needs the final X (the main stream's last node kernel) for the X output head
   if (!tap && c.out_X > 0 && n_run_layers > 0 && await(ax, ev(n_run_layers - 1, EV_X))) return fail("stream wait failed");
 

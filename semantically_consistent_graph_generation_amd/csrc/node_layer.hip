@@ -265,44 +265,78 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
   long long grow[RPW];
   bool gok[RPW];
   __bf16* S1 = reinterpret_cast<__bf16*>(R1);
+  const int c = lane * 4;
 #pragma unroll
   for (int t = 0; t < RPW; ++t) {
     const int ridx = tile * TR + wave * RPW + t;
     gok[t] = ridx < count;
-    const long long row = a.rows[gok[t] ? ridx : count - 1];
-    grow[t] = row;
-    const int b = (int)(row / n);
-    const uint8_t* mb = a.mask + (long long)b * n;
-    const float* film = a.film + (long long)b * (4 * DX);
-    const int c = lane * 4;
-    if (c < DX && a.newX_in != nullptr) {
-      put_split4<KS, PLANE>(S1, wave * RPW + t, c, *reinterpret_cast<const f32x4*>(a.newX_in + row * DX + c));
-      res[t] = *reinterpret_cast<const f32x4*>(a.X + row * DX + c);
-    } else if (c < DX) {
-      f32x4 M = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, S = {0.f, 0.f, 0.f, 0.f}, A = {0.f, 0.f, 0.f, 0.f};
+    grow[t] = a.rows[gok[t] ? ridx : count - 1];
+  }
+  if (a.newX_in != nullptr) {
+#pragma unroll
+    for (int t = 0; t < RPW; ++t)
+      if (c < DX) {
+        put_split4<KS, PLANE>(S1, wave * RPW + t, c, *reinterpret_cast<const f32x4*>(a.newX_in + grow[t] * DX + c));
+        res[t] = *reinterpret_cast<const f32x4*>(a.X + grow[t] * DX + c);
+      }
+  } else {
+    // merge of the attention partials of a row's units: the rows of this wave advance together, one key chunk at a time,
+    // so the partials of all RPW rows are in flight at once (row by row it was a chain of RPW * nch round trips)
+    unsigned bits[RPW];                                         // chunks of the row's graph that hold a valid key
+#pragma unroll
+    for (int t = 0; t < RPW; ++t) {
+      const uint8_t* mb = a.mask + (grow[t] / n) * n;
+      unsigned bt = 0;
       for (int jc = 0; jc < nch; ++jc) {
         bool any = false;
         for (int j = jc * 16; j < min(n, jc * 16 + 16); ++j) any |= mb[j] != 0;      // wave-uniform
-        if (!any) continue;
-        const float* pt = a.attn_part + (row * nch + jc) * (3 * DX) + c;
-        const f32x4 m = *reinterpret_cast<const f32x4*>(pt), s = *reinterpret_cast<const f32x4*>(pt + DX),
-                    ac = *reinterpret_cast<const f32x4*>(pt + 2 * DX);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float mn = fmaxf(M[e], m[e]);
-          const float fo = M[e] == -INFINITY ? 0.f : __expf(M[e] - mn);
-          const float fn = m[e] == -INFINITY ? 0.f : __expf(m[e] - mn);
-          S[e] = S[e] * fo + s[e] * fn;
-          A[e] = A[e] * fo + ac[e] * fn;
-          M[e] = mn;
+        bt |= any ? (1u << (jc & 31)) : 0u;
+        if ((jc & 31) == 31 || jc == nch - 1) {                 // n <= 512: one word
+          bits[t] = bt;
         }
       }
-      const f32x4 fa = *reinterpret_cast<const f32x4*>(film + 2 * DX + c), fm = *reinterpret_cast<const f32x4*>(film + 3 * DX + c);
-      f32x4 o;
+      res[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < DX) res[t] = *reinterpret_cast<const f32x4*>(a.X + grow[t] * DX + c);
+    }
+    constexpr int RH = RPW / 2;                                 // rows per batch (register budget)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = fa[e] + fm[e] * (A[e] / S[e]);
-      put_split4<KS, PLANE>(S1, wave * RPW + t, c, o);
-      res[t] = *reinterpret_cast<const f32x4*>(a.X + row * DX + c);
+    for (int t0 = 0; t0 < RPW; t0 += RH) {
+      f32x4 Mx[RH], Sx[RH], Ax[RH];
+#pragma unroll
+      for (int t = 0; t < RH; ++t) { Mx[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}; Sx[t] = f32x4{0.f, 0.f, 0.f, 0.f}; Ax[t] = Sx[t]; }
+      for (int jc = 0; jc < nch; ++jc) {
+        f32x4 m[RH], s2[RH], ac[RH];
+#pragma unroll
+        for (int t = 0; t < RH; ++t) {
+          m[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}; s2[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ac[t] = s2[t];
+          if (c < DX && ((bits[t0 + t] >> jc) & 1u)) {
+            const float* pt = a.attn_part + (grow[t0 + t] * nch + jc) * (3 * DX) + c;
+            m[t] = *reinterpret_cast<const f32x4*>(pt); s2[t] = *reinterpret_cast<const f32x4*>(pt + DX);
+            ac[t] = *reinterpret_cast<const f32x4*>(pt + 2 * DX);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < RH; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float mn = fmaxf(Mx[t][e], m[t][e]);
+            const float fo = Mx[t][e] == -INFINITY ? 0.f : __expf(Mx[t][e] - mn);
+            const float fn = m[t][e] == -INFINITY ? 0.f : __expf(m[t][e] - mn);
+            Sx[t][e] = Sx[t][e] * fo + s2[t][e] * fn;
+            Ax[t][e] = Ax[t][e] * fo + ac[t][e] * fn;
+            Mx[t][e] = mn;
+          }
+      }
+#pragma unroll
+      for (int t = 0; t < RH; ++t)
+        if (c < DX) {
+          const float* film = a.film + (grow[t0 + t] / n) * (4 * DX);
+          const f32x4 fa = *reinterpret_cast<const f32x4*>(film + 2 * DX + c), fm = *reinterpret_cast<const f32x4*>(film + 3 * DX + c);
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = fa[e] + fm[e] * (Ax[t][e] / Sx[t][e]);
+          put_split4<KS, PLANE>(S1, wave * RPW + t0 + t, c, o);
+        }
     }
   }
   __syncthreads();
@@ -551,9 +585,9 @@ int launch_node_linear_x3(const NodeLinearArgs& a, const f32x4_t* W3, int M, hip
   if (!node_x3() || W3 == nullptr || a.lda % 4 != 0 || a.ldc % 4 != 0 || a.N % 4 != 0) return -1;
   if (a.ln_h != nullptr && a.K > 256) return -1;
   if (a.K == 512) return launch_linear_x3<16>(a, W3, M, st);
-  if (a.K == 256) return launch_linear_x3<8, 3, 4>(a, W3, M, st);
-  if (a.K == 192) return launch_linear_x3<6, 3, 3>(a, W3, M, st);
-  if (a.K == 128) return launch_linear_x3<4, 3, 4>(a, W3, M, st);
+  if (a.K == 256) return launch_linear_x3<8>(a, W3, M, st);
+  if (a.K == 192) return launch_linear_x3<6>(a, W3, M, st);
+  if (a.K == 128) return launch_linear_x3<4>(a, W3, M, st);
   return -1;
 }
 
