@@ -456,8 +456,13 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   static const int stream_mode = [] { const char* e = getenv("SCGG_TWO_STREAMS"); return e == nullptr ? 0 : (e[0] == 'y' ? 2 : 1); }();
   const bool two_streams = stream_mode == 1;
   hipStream_t ax = two_streams ? h->aux : st;
-  if (!two_streams && (hipEventRecord(h->sync_ev[0], h->aux) != hipSuccess || hipStreamWaitEvent(st, h->sync_ev[0], 0) != hipSuccess))
-    return fail("stream join failed");
+  // One stream: what the caller queued on the engine's second stream (the producers of X / y: scgg_denoiser_side_stream) is
+  // joined in front of the first kernel that reads X or y, i.e. BEHIND the work lists and the edge input MLP, which need E
+  // and the mask only.  SCGG_LATE_JOIN=0 joins at the start.
+  static const bool late_join_on = [] { const char* e = getenv("SCGG_LATE_JOIN"); return !(e != nullptr && e[0] == '0'); }();
+  const bool late_join = !two_streams && late_join_on;
+  if (!two_streams && hipEventRecord(h->sync_ev[0], h->aux) != hipSuccess) return fail("stream join failed");
+  if (!two_streams && !late_join && hipStreamWaitEvent(st, h->sync_ev[0], 0) != hipSuccess) return fail("stream join failed");
   enum { EV_FILM = 0, EV_EDGE = 1, EV_NS = 2, EV_X = 3, EV_PER_LAYER = 4 };
   auto ev = [&](int l, int k) { return h->sync_ev[(size_t)(l + 1) * EV_PER_LAYER + k]; };
   auto signal = [&](hipEvent_t e, hipStream_t s) { return two_streams && hipEventRecord(e, s) != hipSuccess; };
@@ -488,23 +493,6 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   if (signal(ev_pro, ax)) return fail("event record failed");
   if (signal(ev_fork, st) || await(ax, ev_fork)) return fail("stream fork failed");
 
-  // ---- input MLPs (transformer_model.py:358-366): E on the main stream, X and y beside it on the aux stream
-  {
-    const Param* w0 = P_(h, "mlp_in_X.0.weight", (int64_t)c.hid_X * c.in_X); const Param* b0 = P_(h, "mlp_in_X.0.bias", c.hid_X);
-    const Param* w3 = P_(h, "mlp_in_X.3.weight", (int64_t)dx * c.hid_X); const Param* b3 = P_(h, "mlp_in_X.3.bias", dx);
-    if (!w0 || !b0 || !w3 || !b3) return -1;
-    if (h->in_X2.W != nullptr && c.in_X <= 64 && c.hid_X % 4 == 0) {
-      NarrowLinearArgs na{X, w0->p, b0->p, w.hidX, w.rows, w.row_count, c.hid_X, c.in_X, c.in_X, c.hid_X, 1};
-      if (launch_narrow_linear(na, M, ax)) return fail("narrow_linear rejected");
-      NodeLinearArgs la{w.hidX, h->in_X2.W, h->in_X2.b, w.Xh, w.rows, w.row_count, dx, c.hid_X, (dx + 31) / 32, c.hid_X, dx,
-                        (dx + 31) / 32 >= 4 ? 2 : 1, 1};
-      if (launch_node_linear_x3(la, h->in_X2.W3, M, ax) != 0 && launch_node_linear(la, M, ax))
-        return fail("node_linear(mlp_in_X.3) rejected");
-    } else {
-      if (gemm(X, c.in_X, w0, b0, w.hidX, c.hid_X, M, c.hid_X, c.in_X, GEMM_RELU, nullptr, ax)) return -1;
-      if (gemm(w.hidX, c.hid_X, w3, b3, w.Xh, dx, M, dx, c.hid_X, GEMM_RELU | GEMM_ROWMASK, mask, ax)) return -1;
-    }
-  }
   // The y input MLP and the FiLM vectors of layer 0 (fused y path): on the caller's stream, which idles after the edge
   // input MLP, beside the X chain on the second stream.  The caller's stream first waits until the second stream has
   // caught up with whatever the caller queued there (the producers of y, scgg_denoiser_side_stream).
@@ -539,6 +527,24 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     if (c.out_X > 0 && o1 && hipMemsetAsync(o1, 0, (size_t)M * c.out_X * sizeof(float), st) != hipSuccess) return fail("memset failed");
     if (hipMemsetAsync(o2, 0, (size_t)M * n * c.out_E * sizeof(float), st) != hipSuccess) return fail("memset failed");
     out_zeroed = true;
+  }
+  if (late_join && hipStreamWaitEvent(st, h->sync_ev[0], 0) != hipSuccess) return fail("stream join failed");
+  // ---- input MLPs (transformer_model.py:358-366): E on the main stream, X and y beside it on the aux stream
+  {
+    const Param* w0 = P_(h, "mlp_in_X.0.weight", (int64_t)c.hid_X * c.in_X); const Param* b0 = P_(h, "mlp_in_X.0.bias", c.hid_X);
+    const Param* w3 = P_(h, "mlp_in_X.3.weight", (int64_t)dx * c.hid_X); const Param* b3 = P_(h, "mlp_in_X.3.bias", dx);
+    if (!w0 || !b0 || !w3 || !b3) return -1;
+    if (h->in_X2.W != nullptr && c.in_X <= 64 && c.hid_X % 4 == 0) {
+      NarrowLinearArgs na{X, w0->p, b0->p, w.hidX, w.rows, w.row_count, c.hid_X, c.in_X, c.in_X, c.hid_X, 1};
+      if (launch_narrow_linear(na, M, ax)) return fail("narrow_linear rejected");
+      NodeLinearArgs la{w.hidX, h->in_X2.W, h->in_X2.b, w.Xh, w.rows, w.row_count, dx, c.hid_X, (dx + 31) / 32, c.hid_X, dx,
+                        (dx + 31) / 32 >= 4 ? 2 : 1, 1};
+      if (launch_node_linear_x3(la, h->in_X2.W3, M, ax) != 0 && launch_node_linear(la, M, ax))
+        return fail("node_linear(mlp_in_X.3) rejected");
+    } else {
+      if (gemm(X, c.in_X, w0, b0, w.hidX, c.hid_X, M, c.hid_X, c.in_X, GEMM_RELU, nullptr, ax)) return -1;
+      if (gemm(w.hidX, c.hid_X, w3, b3, w.Xh, dx, M, dx, c.hid_X, GEMM_RELU | GEMM_ROWMASK, mask, ax)) return -1;
+    }
   }
   {
     hipStream_t ys = y_on_main ? st : ax;
