@@ -98,3 +98,57 @@ def test_3d_edge_layer_x3_pair_agrees_with_the_one_kernel_fp32_form(tmp_path):
         scale = float(np.abs(b[k]).max())
         err = float(np.abs(a[k] - b[k]).max()) / scale
         assert err < 2e-5, f"{k}: x3 pair vs fp32 kernel differ by {err:.2e} of the output scale"
+
+
+@pytest.mark.gpu
+def test_one_stream_schedule_switches_agree_bit_for_bit(tmp_path):
+    """SCGG_Y_POOL=0 (the pooled statistics as separate kernels in front of the y round instead of inside it), SCGG_LATE_JOIN=0
+    (side stream joined at the start of the forward) and SCGG_TWO_STREAMS=y (y round on the second stream): the same
+    kernels' arithmetic in another launch arrangement (pool_stats.h is shared), so the results are identical."""
+    a = _run(tmp_path, "default", {})
+    for tag, env in (("ypool0", {"SCGG_Y_POOL": "0"}), ("join0", {"SCGG_LATE_JOIN": "0"}), ("ybeside", {"SCGG_TWO_STREAMS": "y"})):
+        b = _run(tmp_path, tag, env)
+        for k in ("X", "E"):
+            assert np.array_equal(a[k], b[k]), f"{tag}: {k} differs by {float(np.abs(a[k] - b[k]).max()):.2e}"
+
+
+SCRIPT_SIT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from oracle import fixtures as fx
+from semantically_consistent_graph_generation_amd.node_coordinate_diffusion import SiT_models
+model = SiT_models["SiT-T"](in_channels=3)
+model.load_state_dict(fx.make_state_dict({{k: tuple(v.shape) for k, v in model.state_dict().items()}}, seed=611))
+model = model.cuda()
+m = fx.ragged_mask([29, 7, 48, 1, 16])
+B, n = m.shape
+g = torch.Generator().manual_seed(4)
+x = torch.randn(B, n, 3, generator=g)
+t = torch.tensor([999, 3, 500, 1, 77])
+eps = model(x.cuda(), t.cuda(), m.cuda())
+noise = torch.randn(6, B, n, 3, generator=g)
+xs = model.sample(x.cuda(), m.cuda(), steps=6, noise=noise.cuda())
+torch.cuda.synchronize()
+np.savez(sys.argv[1], X=eps.cpu().numpy(), E=xs.cpu().numpy())
+"""
+
+
+@pytest.mark.gpu
+def test_sit_fused_block_and_mfma_attention_agree_with_the_separate_kernels(tmp_path):
+    """SCGG_SIT_FUSED=0 (row-list Linears with the LayerNorm-modulate prologue and GELU / accumulate epilogues instead of
+    sit_block_x3_kernel) and SCGG_SIT_ATTN=valu (LDS / vector-unit attention instead of the matrix-pipe one): the same network
+    through other kernels, equal to fp32 round-off over 6 blocks (forward) and 6 ancestral steps (sampler)."""
+    def run(tag, env_extra):
+        out = tmp_path / f"{tag}.npz"
+        r = subprocess.run([sys.executable, "-c", SCRIPT_SIT.format(root=ROOT), str(out)], env=dict(os.environ, **env_extra),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return np.load(out)
+    a = run("default", {})
+    for tag, env in (("unfused", {"SCGG_SIT_FUSED": "0"}), ("valu", {"SCGG_SIT_ATTN": "valu"}),
+                     ("gemm", {"SCGG_SIT_FUSED": "0", "SCGG_NODE_MODE": "f32"})):
+        b = run(tag, env)
+        for k in ("X", "E"):
+            scale = float(np.abs(a[k]).max())
+            err = float(np.abs(a[k] - b[k]).max()) / scale
+            assert err < 3e-5, f"{tag}: {k} differs by {err:.2e} of the output scale"
