@@ -647,9 +647,15 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
   const int full = count / per_iter, rest = count - full * per_iter;
   const int iters = full + (rest > 0 ? 1 : 0);
   const int q_last = (rest + (int)gridDim.x - 1) / (int)gridDim.x;
+  // Workgroups go to the 8 XCDs round-robin (workgroup w on XCD w % 8), and every XCD has its own L2.  The unit list is in
+  // graph order, so the workgroups of ONE XCD take consecutive stretches of it: a graph's K / V rows and both orientations
+  // of its E tiles (E_ij of one unit is E_ji of another unit of the same graph) are then fetched into one L2 instead of four
+  // or more.  SCGG_EDGE_XCD=0 (a.xcd_map == 0) keeps the plain order for A/B runs.
+  const int nwg = (int)gridDim.x;
+  const int wg = (a.xcd_map && nwg % 8 == 0) ? ((int)blockIdx.x % 8) * (nwg / 8) + (int)blockIdx.x / 8 : (int)blockIdx.x;
   auto slot = [&](int it) -> int {                                     // unit-list index of this wave in round `it`
-    if (it < full) return (it * (int)gridDim.x + (int)blockIdx.x) * NW + wave;
-    const int r = (int)blockIdx.x * q_last + wave;
+    if (it < full) return (it * nwg + wg) * NW + wave;
+    const int r = wg * q_last + wave;
     return (it == full && wave < q_last && r < rest) ? full * per_iter + r : count;
   };
   constexpr float LOG2E = 1.4426950408889634f;
@@ -1581,9 +1587,12 @@ static int launch_one(const EdgeLayerArgs& a, int n_cu, hipStream_t st) {
   return 0;
 }
 
-int launch_edge_layer(const EdgeLayerArgs& a, int dx, int de, int ffe, hipStream_t st) {
+int launch_edge_layer(const EdgeLayerArgs& a_in, int dx, int de, int ffe, hipStream_t st) {
   const int n_cu = device_cu_count();
   if (n_cu <= 0) return -2;
+  static const bool xcd_on = [] { const char* e = getenv("SCGG_EDGE_XCD"); return !(e != nullptr && e[0] == '0'); }();
+  EdgeLayerArgs a = a_in;
+  a.xcd_map = xcd_on ? 1 : 0;
 #define CASE(NXB, NEB, NFB) \
   if (dx == 32 * NXB && de == 32 * NEB && ffe == 32 * NFB) return launch_one<NXB, NEB, NFB>(a, n_cu, st);
   SCGG_UNIT_CASES

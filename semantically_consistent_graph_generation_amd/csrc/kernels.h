@@ -78,6 +78,7 @@ struct EdgeLayerArgs {
   const int* unit_count;  // device scalar
   float inv_sqrt_df;
   int B, n;
+  int xcd_map = 1;          // x3 kernel: workgroups of one XCD take consecutive stretches of the unit list (0: plain order)
 };
 
 struct EdgeUnitPackArgs {   // raw (torch layout) weights of one layer's edge path -> phase images for edge_unit_layer_kernel
