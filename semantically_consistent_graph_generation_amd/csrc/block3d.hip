@@ -25,6 +25,7 @@
 
 #include <type_traits>
 
+#include "pool_stats.h"
 #include "mfma_chain.h"
 #include "c16.h"
 #include "kernels.h"
@@ -800,10 +801,9 @@ __global__ __launch_bounds__(256) void block3d_newx_kernel(const float* __restri
 // same number of keys), Xtoy inputs of the UNMASKED newX (layers.py:15: the mean's numerator runs over every row of the
 // padded batch, the divisor, minimum, maximum and variance over the valid ones) -> zcat[b] columns [dy, dy + 4dx + 8de).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void block3d_graph_merge_kernel(GraphMerge3DArgs a) {
-  const int b = blockIdx.x, n = a.n, DE = a.de, DX = a.dx;
+__global__ __launch_bounds__(256) void block3d_graph_merge_kernel(GraphMerge3DArgs a) {   // arithmetic: pool_stats.h (shared with the y kernel)
+  const int b = blockIdx.x, n = a.n;
   const uint8_t* m = a.mask + (long long)b * n;
-  float* z = a.zcat + (long long)b * a.ldz + a.dy;
   __shared__ int s_nv;
   if (threadIdx.x == 0) {
     int c = 0;
@@ -811,48 +811,9 @@ __global__ __launch_bounds__(256) void block3d_graph_merge_kernel(GraphMerge3DAr
     s_nv = c;
   }
   __syncthreads();
-  const int nv = s_nv;
-  if (nv == 0) return;
-  // loads are unconditional and unrolled (8 rows in flight per thread): the loops are chains of L2 round trips otherwise
-  for (int t = threadIdx.x; t < DX; t += 256) {
-    const float* col = a.newX + (long long)b * n * DX + t;
-    float s = 0.f;
-#pragma unroll 8
-    for (int i = 0; i < n; ++i) s += col[(long long)i * DX];
-    const float mean = s / (float)nv;
-    float q = 0.f, mn = INFINITY, mx = -INFINITY;
-#pragma unroll 8
-    for (int i = 0; i < n; ++i) {
-      const float v = col[(long long)i * DX], d = v - mean;
-      const bool on = m[i] != 0;
-      q += on ? d * d : 0.f;
-      mn = fminf(mn, on ? v : INFINITY);
-      mx = fmaxf(mx, on ? v : -INFINITY);
-    }
-    z[t] = mean; z[DX + t] = mn; z[2 * DX + t] = mx; z[3 * DX + t] = q / (float)nv;
-  }
-  for (int t = threadIdx.x; t < 2 * DE; t += 256) {
-    const int which = t / DE, ch = t - which * DE;
-    float N = 0.f, mean = 0.f, m2 = 0.f, mn = INFINITY, mx = -INFINITY;
-    const float k = (float)nv;
-    const int ld = which ? 4 * DE : 8 * DE;
-    const float* col = (which ? a.rowaggD : a.rowagg) + (long long)b * n * ld + ch;
-#pragma unroll 4
-    for (int i = 0; i < n; ++i) {
-      const float* ag = col + (long long)i * ld;
-      const float r_mean = ag[0], r_m2 = ag[DE], r_mn = ag[2 * DE], r_mx = ag[3 * DE];
-      if (m[i]) {
-        const float dl = r_mean - mean, nn = N + k;
-        mean += dl * (k / nn);
-        m2 += r_m2 + dl * dl * (N * k / nn);
-        mn = fminf(mn, r_mn);
-        mx = fmaxf(mx, r_mx);
-        N = nn;
-      }
-    }
-    float* zz = a.etoy + (long long)b * (8 * DE) + which * 4 * DE + ch;
-    zz[0] = mean; zz[DE] = mn; zz[2 * DE] = mx; zz[3 * DE] = m2 / N;
-  }
+  if (s_nv == 0) return;
+  pool_graph3d(a.rowagg + (long long)b * n * 8 * a.de, a.rowaggD + (long long)b * n * 4 * a.de, a.newX + (long long)b * n * a.dx, m, n,
+               s_nv, a.dx, a.de, a.zcat + (long long)b * a.ldz + a.dy, a.etoy + (long long)b * (8 * a.de), threadIdx.x, 256);
 }
 
 // ---------------------------------------------------------------------------------------------------------

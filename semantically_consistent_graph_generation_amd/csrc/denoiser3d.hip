@@ -433,9 +433,15 @@ int run3(scgg_denoiser3d* h, const float* X, const float* E, const float* y, con
   }
   float *Ecur = w.E0, *Enext = w.E1;
   const int L_run = tap ? n_run_layers : c.n_layers;
+  // SCGG_Y_POOL=0: the graph merge as a kernel of its own in front of the y round (development A/B switch)
+  static const bool y_pool_on = [] { const char* e = getenv("SCGG_Y_POOL"); return !(e != nullptr && e[0] == '0'); }();
   auto y_round = [&](int l, bool update, float* film_dst) -> int {   // y(l) -> y(l+1) (update) and the FiLM vectors of `film_of`
     const int film_of = update ? l + 1 : l;
     YLayerArgs ya{};
+    if (update && y_pool_on) {        // the y workgroup of a graph merges its graph's row aggregates itself (pool_stats.h)
+      ya.gm_rowagg = w.rowagg; ya.gm_rowaggD = w.rowaggD + (size_t)l * M * 4 * de; ya.gm_newX = w.newX; ya.mask = mask; ya.n = n;
+      ya.de = de;
+    }
     ya.y = w.y; ya.ycat = w.zcat; ya.etoy = w.etoy; ya.B = B; ya.dy = dy; ya.ffy = c.dim_ffy; ya.kcat = kcat; ya.dx = dx;
     ya.update = update ? 1 : 0;
     ya.film_n = FL;
@@ -486,8 +492,10 @@ int run3(scgg_denoiser3d* h, const float* X, const float* E, const float* y, con
       TRY(rowlin_named(L.px, sa + "pos_x_mul.lin", w.rowstatD + (size_t)l * M * 4 * de, 4 * de, w.t_px, dx, dx, 4 * de, false));
       TRY(launch_block3d_newx(w.t_out, w.t_ex, w.t_px, mask, film, FL, 2 * de, w.newX, M, n, dx, st));
       if (L.predicts_y) {   // y(l+1) and the FiLM vectors of layer l+1 (into the other buffer: film(l) is still being read)
-        GraphMerge3DArgs g{w.rowagg, w.rowaggD + (size_t)l * M * 4 * de, mask, w.newX, w.zcat, w.etoy, kcat, n, dx, de, dy};
-        TRY(launch_block3d_graph_merge(g, B, st));
+        if (!y_pool_on) {
+          GraphMerge3DArgs g{w.rowagg, w.rowaggD + (size_t)l * M * 4 * de, mask, w.newX, w.zcat, w.etoy, kcat, n, dx, de, dy};
+          TRY(launch_block3d_graph_merge(g, B, st));
+        }
         TRY(y_round(l, true, film_buf[(l + 1) & 1]));
       }
       // x_out, normX1, linX1 / linX2, normX2 and the next layer's q | k | v | x_e_mul1 | x_e_mul2: one fused launch of the 2D

@@ -253,6 +253,11 @@ struct YLayerArgs {       // fused global-feature part of one layer (y_layer.hip
   const float* pool_E;    // [B,n,n,de] the layer's input E (hidden, unsymmetrised), or null: Etoy from etoy
   const uint8_t* mask;    // [B,n]
   int n, de;
+  // Position-aware block: the graph merge of block3d (Xtoy inputs of the unmasked newX, Etoy inputs of Y and dist1 from the
+  // row aggregates) taken by the y workgroup of the graph itself; kcat = dy + 4 dx + 8 de.  null: from ycat / etoy.
+  const float* gm_rowagg;   // [B*n, 8 de]
+  const float* gm_rowaggD;  // [B*n, 4 de]
+  const float* gm_newX;     // [B,n,dx]
 };
 
 bool y_layer_supported(int dy, int ffy, int kcat);

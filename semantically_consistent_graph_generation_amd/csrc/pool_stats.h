@@ -196,4 +196,57 @@ __device__ __forceinline__ void pool_etoy_graph(PoolScratch& ps, const float* Eg
   __syncthreads();
 }
 
+// Position-aware block (pos_transformer_model.py Xtoy / Etoy inputs of the y update), one graph: Xtoy inputs of the UNMASKED
+// newX (layers.py:15: the mean's numerator runs over every row of the padded batch, the divisor, minimum, maximum and
+// variance over the valid ones) -> zx[4 dx]; Etoy inputs of Y and of dist1 from the row aggregates (every valid row holds
+// the same number of keys) -> ze[8 de].  An empty graph gets zeros.  Any number of threads; no barrier inside.
+__device__ __forceinline__ void pool_graph3d(const float* rowagg, const float* rowaggD, const float* newX, const uint8_t* m,
+                                             int n, int nv, int DX, int DE, float* zx, float* ze, int tid, int nthreads) {
+  if (nv == 0) {
+    for (int t = tid; t < 4 * DX; t += nthreads) zx[t] = 0.f;
+    for (int t = tid; t < 8 * DE; t += nthreads) ze[t] = 0.f;
+    return;
+  }
+  // loads are unconditional and unrolled (8 rows in flight per thread): the loops are chains of L2 round trips otherwise
+  for (int t = tid; t < DX; t += nthreads) {
+    const float* col = newX + t;
+    float s = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < n; ++i) s += col[(long long)i * DX];
+    const float mean = s / (float)nv;
+    float q = 0.f, mn = INFINITY, mx = -INFINITY;
+#pragma unroll 8
+    for (int i = 0; i < n; ++i) {
+      const float v = col[(long long)i * DX], d = v - mean;
+      const bool on = m[i] != 0;
+      q += on ? d * d : 0.f;
+      mn = fminf(mn, on ? v : INFINITY);
+      mx = fmaxf(mx, on ? v : -INFINITY);
+    }
+    zx[t] = mean; zx[DX + t] = mn; zx[2 * DX + t] = mx; zx[3 * DX + t] = q / (float)nv;
+  }
+  for (int t = tid; t < 2 * DE; t += nthreads) {
+    const int which = t / DE, ch = t - which * DE;
+    float N = 0.f, mean = 0.f, m2 = 0.f, mn = INFINITY, mx = -INFINITY;
+    const float k = (float)nv;
+    const int ld = which ? 4 * DE : 8 * DE;
+    const float* col = (which ? rowaggD : rowagg) + ch;
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) {
+      const float* ag = col + (long long)i * ld;
+      const float r_mean = ag[0], r_m2 = ag[DE], r_mn = ag[2 * DE], r_mx = ag[3 * DE];
+      if (m[i]) {
+        const float dl = r_mean - mean, nn = N + k;
+        mean += dl * (k / nn);
+        m2 += r_m2 + dl * dl * (N * k / nn);
+        mn = fminf(mn, r_mn);
+        mx = fmaxf(mx, r_mx);
+        N = nn;
+      }
+    }
+    float* zz = ze + which * 4 * DE + ch;
+    zz[0] = mean; zz[DE] = mn; zz[2 * DE] = mx; zz[3 * DE] = m2 / N;
+  }
+}
+
 }  // namespace scgg

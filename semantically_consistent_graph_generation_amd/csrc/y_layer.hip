@@ -152,7 +152,8 @@ __global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
 
   if (a.update) {
     const int e0 = dy + 4 * a.dx;
-    const bool own_x = YG == 1 && YT == PS_T && a.pool_X != nullptr, own_e = YG == 1 && YT == PS_T && a.pool_E != nullptr;
+    const bool own3 = YG == 1 && a.gm_rowagg != nullptr;
+    const bool own_x = own3 || (YG == 1 && YT == PS_T && a.pool_X != nullptr), own_e = own3 || (YG == 1 && YT == PS_T && a.pool_E != nullptr);
     for (int idx = tid; idx < YG * kcat; idx += YT) {
       const int g = idx / kcat, c = idx - g * kcat;
       const int b = min(b0 + g, a.B - 1);
@@ -160,7 +161,18 @@ __global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
       else if (c < e0) { if (!own_x) cat[idx] = a.ycat[(size_t)b * kcat + c]; }
       else if (!own_e) cat[idx] = a.etoy[(size_t)b * (kcat - e0) + (c - e0)];
     }
-    if (own_x || own_e) {                                          // wave-uniform; the statistics of this graph, straight into cat
+    if (own3) {                                                    // position-aware block: the graph merge of this graph
+      __shared__ int s_nv3;
+      const uint8_t* m = a.mask + (size_t)b0 * a.n;
+      if (tid == 0) {
+        int c = 0;
+        for (int i = 0; i < a.n; ++i) c += m[i] != 0;
+        s_nv3 = c;
+      }
+      __syncthreads();
+      pool_graph3d(a.gm_rowagg + (size_t)b0 * a.n * 8 * a.de, a.gm_rowaggD + (size_t)b0 * a.n * 4 * a.de,
+                   a.gm_newX + (size_t)b0 * a.n * a.dx, m, a.n, s_nv3, a.dx, a.de, cat + dy, cat + e0, tid, YT);
+    } else if (own_x || own_e) {                                   // wave-uniform; the statistics of this graph, straight into cat
       __shared__ PoolScratch ps;
       const int nv = pool_compact_mask(ps, a.mask + (size_t)b0 * a.n, a.n, tid);
       if (own_x) pool_xtoy_graph(ps, a.pool_X + (size_t)b0 * a.n * a.dx, nv, a.dx, cat + dy, tid);
@@ -219,6 +231,8 @@ bool y_layer_supported(int dy, int ffy, int kcat) {
 
 int launch_y_layer(const YLayerArgs& a, hipStream_t st) {
   if (!y_layer_supported(a.dy, a.ffy, a.kcat)) return -1;
+  if (a.gm_rowagg != nullptr && (YG != 1 || a.gm_rowaggD == nullptr || a.gm_newX == nullptr || a.mask == nullptr ||
+                                 a.kcat != a.dy + 4 * a.dx + 8 * a.de)) return -1;
   if (a.pool_X != nullptr && (YG != 1 || a.dx % 4 != 0 || a.dx > 512 || PS_T % (a.dx / 4) != 0 || a.n > 512 || a.mask == nullptr)) return -1;
   if (a.pool_E != nullptr && (YG != 1 || a.de % 4 != 0 || a.de > 256 || PS_T % (a.de / 4) != 0 || a.n > 512 || a.mask == nullptr ||
                               a.kcat != a.dy + 4 * a.dx + 4 * a.de)) return -1;

@@ -98,6 +98,9 @@ def test_3d_edge_layer_x3_pair_agrees_with_the_one_kernel_fp32_form(tmp_path):
         scale = float(np.abs(b[k]).max())
         err = float(np.abs(a[k] - b[k]).max()) / scale
         assert err < 2e-5, f"{k}: x3 pair vs fp32 kernel differ by {err:.2e} of the output scale"
+    c = run("ypool0", {"SCGG_Y_POOL": "0"})      # graph merge as its own kernel instead of inside the y round: same arithmetic
+    for k in ("X", "E"):
+        assert np.array_equal(a[k], c[k]), f"SCGG_Y_POOL=0: {k} differs by {float(np.abs(a[k] - c[k]).max()):.2e}"
 
 
 @pytest.mark.gpu
