@@ -109,7 +109,8 @@ def test_one_stream_schedule_switches_agree_bit_for_bit(tmp_path):
     (side stream joined at the start of the forward) and SCGG_TWO_STREAMS=y (y round on the second stream): the same
     kernels' arithmetic in another launch arrangement (pool_stats.h is shared), so the results are identical."""
     a = _run(tmp_path, "default", {})
-    for tag, env in (("ypool0", {"SCGG_Y_POOL": "0"}), ("join0", {"SCGG_LATE_JOIN": "0"}), ("ybeside", {"SCGG_TWO_STREAMS": "y"})):
+    for tag, env in (("ypool0", {"SCGG_Y_POOL": "0"}), ("join0", {"SCGG_LATE_JOIN": "0"}), ("ybeside", {"SCGG_TWO_STREAMS": "y"}),
+                     ("xcd0", {"SCGG_EDGE_XCD": "0"})):      # plain instead of XCD-major unit order in the edge kernel
         b = _run(tmp_path, tag, env)
         for k in ("X", "E"):
             assert np.array_equal(a[k], b[k]), f"{tag}: {k} differs by {float(np.abs(a[k] - b[k]).max()):.2e}"
