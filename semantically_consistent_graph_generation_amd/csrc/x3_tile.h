@@ -11,10 +11,15 @@ typedef unsigned nu32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned nu32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 nbf16x8 __attribute__((ext_vector_type(8)));
 
+// sum over the 64 lanes, in every lane: four DPP steps inside the 16-lane rows, then the two row exchanges of gfx950
+// (v_permlane16_swap, v_permlane32_swap).  The six ds_bpermute round trips of a __shfl_xor butterfly were the latency chain of
+// the LayerNorm phases (two reductions per row, six rows per wave).
 __device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
-  return v;
+  v += SCGG_DPP(v, 0xB1);    // quad_perm [1,0,3,2]
+  v += SCGG_DPP(v, 0x4E);    // quad_perm [2,3,0,1]
+  v += SCGG_DPP(v, 0x141);   // row_half_mirror
+  v += SCGG_DPP(v, 0x140);   // row_mirror
+  return other_half_sum(swap_rows16_sum(v));
 }
 
 // exact three-way bf16 split of 4 consecutive channels -> 8 bytes per term
