@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void sit_attn_mfma_kernel(const float* __restr
       }
       sT[kt] = acc;
     }
-    m = fmaxf(m, __shfl_xor(m, 16));
+    m = swap_rows16_max(m);                                    // lane ^ 16 (v_permlane16_swap)
     m = fmaxf(m, __shfl_xor(m, 32));
     float l = 0.f;
 #pragma unroll
@@ -276,8 +276,7 @@ __global__ __launch_bounds__(256) void sit_attn_mfma_kernel(const float* __restr
         l += sT[kt][r];
       }
     }
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
+    l = other_half_sum(swap_rows16_sum(l));                    // lane ^ 16, lane ^ 32 (v_permlane16_swap / 32_swap)
     const float inv = 1.0f / l;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {

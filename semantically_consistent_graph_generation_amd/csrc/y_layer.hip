@@ -16,6 +16,7 @@
 
 #include "kernels.h"
 #include "pool_stats.h"
+#include "x3_tile.h"
 
 namespace scgg {
 
@@ -112,8 +113,7 @@ __device__ __forceinline__ void y_add_layernorm(float* y, const float* t, int ld
       v[i] = c < D ? y[g * ld + c] + t[g * ld + c] : 0.f;
       s += v[i];
     }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m);
+    s = wave_sum64(s);
     const float mean = s / (float)D;
     float q = 0.f;
 #pragma unroll
@@ -122,8 +122,7 @@ __device__ __forceinline__ void y_add_layernorm(float* y, const float* t, int ld
       const float d = c < D ? v[i] - mean : 0.f;
       q += d * d;
     }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) q += __shfl_xor(q, m);
+    q = wave_sum64(q);
     const float rstd = 1.0f / sqrtf(q / (float)D + 1e-5f);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
