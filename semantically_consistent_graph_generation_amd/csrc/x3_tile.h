@@ -111,6 +111,13 @@ __device__ __forceinline__ void tile_linear_x3(f32x4 (&acc)[2][NRG], NWRingT<D>&
       for (int rg = 0; rg < NRG; ++rg) {
         const NFrag3& b = xf[kc & 1][rg];
         f32x4 c = acc[blk][rg];
+#ifdef SCGG_ABL_TILE_NO_MFMA   // timing experiment: the operands stay live, the matrix pipe stays idle
+        c[0] += __uint_as_float((a.l[0] ^ b.h[0]) & 0x3f800000u);
+        c[1] += __uint_as_float((a.m[1] ^ b.m[1]) & 0x3f800000u);
+        c[2] += __uint_as_float((a.h[2] ^ b.l[2]) & 0x3f800000u);
+        acc[blk][rg] = c;
+        continue;
+#endif
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_NB(a.l), SCGG_NB(b.h), c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_NB(a.h), SCGG_NB(b.l), c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_NB(a.m), SCGG_NB(b.m), c, 0, 0, 0);
@@ -122,8 +129,10 @@ __device__ __forceinline__ void tile_linear_x3(f32x4 (&acc)[2][NRG], NWRingT<D>&
     }
 #undef SCGG_NB
     __builtin_amdgcn_sched_barrier(0);
+#ifndef SCGG_ABL_TILE_NO_W     // timing experiment: no weight stream beyond the first D chunks of a pair
     if (kc + D < KC) w3_load<KC>(r.f[kc % D], w, kc + D);
     else if (wnext != nullptr) w3_load<KCN>(r.f[kc % D], wnext, kc + D - KC);
+#endif
   }
   r.next = wnext;
 }
