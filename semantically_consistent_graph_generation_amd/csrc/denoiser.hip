@@ -330,6 +330,7 @@ int build(scgg_denoiser* h, bool fill, hipStream_t st) {
 struct Workspace {
   float *Xh, *qkv, *newX, *t1, *t2, *E0, *E1, *y, *ycat, *yt1, *yt2, *film, *hidX, *hidy, *xo;
   int *rows, *row_count, *units, *unit_count, *goff;
+  unsigned* chunk_bits;   // [B] valid-chunk bits per graph (launch_build_lists)
   float *epool, *attn;
   size_t bytes;
 };
@@ -364,6 +365,7 @@ Workspace carve(const scgg_denoiser_config& c, int B, int n, char* base) {
   w.units = ar.take<int>(M * nch);
   w.unit_count = ar.take<int>(64);
   w.goff = ar.take<int>((size_t)2 * B);
+  w.chunk_bits = ar.take<unsigned>((size_t)B);
   w.bytes = align_up(ar.off, 256);
   return w;
 }
@@ -471,7 +473,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   hipEvent_t ev_y0 = h->sync_ev.back();
 
   // ---- work lists (valid rows, 16-key units), then fork
-  if (launch_build_lists(mask, B, n, w.goff, w.rows, w.row_count, w.units, w.unit_count, st))
+  if (launch_build_lists(mask, B, n, w.goff, w.rows, w.row_count, w.units, w.unit_count, st, w.chunk_bits))
     return fail("n=%d too large for the unit list (max 512)", n);
   // The residual stream X ping-pongs between two buffers when every layer runs the fused node kernel (w.t1 is only
   // used by the unfused path): node kernel l then never overwrites the X whose pooled statistics the y path is taking.
@@ -704,6 +706,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
                          next ? h->layers[l + 1].qkv.W : nullptr, next ? h->layers[l + 1].qkv.b : nullptr, w.qkv, n,
                          L.x_out.W3, L.linX1.W3, L.linX2.W3, next ? h->layers[l + 1].qkv.W3 : nullptr,
                          dbl_X ? Xalt : Xcur, 0, 0, 0};
+        na.chunk_bits = w.chunk_bits;
         // after the last layer the trailing Linear is mlp_out_X.0 (+ ReLU) into the hidden buffer of the X output head
         head_fused = false;
         if (!next && !tap && l + 1 == c.n_layers && c.out_X > 0 && c.out_X <= 16 && h->out_X1.W3 != nullptr &&

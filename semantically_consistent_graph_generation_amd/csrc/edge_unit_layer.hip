@@ -97,19 +97,22 @@ __global__ __launch_bounds__(1024) void graph_scan_kernel(const uint8_t* mask, i
 }
 
 __global__ __launch_bounds__(64) void graph_fill_kernel(const uint8_t* mask, int n, int nch, const int* goff, int* rows,
-                                                        int* units) {
+                                                        int* units, unsigned* chunk_bits) {
   __shared__ int chunk_rank[32];
   __shared__ int s_nvc;
   const int b = blockIdx.x, lane = threadIdx.x;
   const uint8_t* mb = mask + (size_t)b * n;
   if (lane == 0) {
     int k = 0;
+    unsigned bits = 0;
     for (int jc = 0; jc < nch; ++jc) {
       bool any = false;
       for (int j = jc * 16; j < min(n, jc * 16 + 16); ++j) any |= mb[j] != 0;
       chunk_rank[jc] = any ? k++ : -1;
+      bits |= any ? (1u << jc) : 0u;
     }
     s_nvc = k;
+    if (chunk_bits != nullptr) chunk_bits[b] = bits;          // which 16-key chunks of the graph hold a valid key (nch <= 32)
   }
   __syncthreads();
   const int nvc = s_nvc;
@@ -131,11 +134,11 @@ __global__ __launch_bounds__(64) void graph_fill_kernel(const uint8_t* mask, int
 }
 
 int launch_build_lists(const uint8_t* mask, int B, int n, int* goff, int* rows, int* row_count, int* units,
-                       int* unit_count, hipStream_t st) {
+                       int* unit_count, hipStream_t st, unsigned* chunk_bits) {
   const int nch = (n + 15) / 16;
   if (nch > 32) return -1;
   hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(1024), 0, st, mask, B, n, nch, goff, row_count, unit_count);
-  hipLaunchKernelGGL(graph_fill_kernel, dim3(B), dim3(64), 0, st, mask, n, nch, goff, rows, units);
+  hipLaunchKernelGGL(graph_fill_kernel, dim3(B), dim3(64), 0, st, mask, n, nch, goff, rows, units, chunk_bits);
   return 0;
 }
 

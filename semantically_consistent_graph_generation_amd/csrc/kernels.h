@@ -112,7 +112,7 @@ long long edge_phase_img_f4(int dx, int de, int ffe);   // float4 count of one l
 int launch_edge_unit_pack(const EdgeUnitPackArgs& a, int dx, int de, int ffe, hipStream_t st);
 // valid-row list and 16-key unit list of a node mask; goff: 2*B ints of scratch (per-graph offsets)
 int launch_build_lists(const uint8_t* mask, int B, int n, int* goff, int* rows, int* row_count, int* units,
-                       int* unit_count, hipStream_t st);
+                       int* unit_count, hipStream_t st, unsigned* chunk_bits = nullptr);
 int launch_attn_finish(const AttnFinishArgs& a, int M, hipStream_t st);
 int launch_edge_mlp_out(const EdgeMlpUnitArgs& a, int de, int hid, int C, hipStream_t st);
 
@@ -226,6 +226,7 @@ struct NodeLayerArgs {    // fused node part of one layer (node_layer.hip); pack
   // x3 kernel only: the block's node output before x_out, already complete ([B,n,dx]; the position-aware block, whose attention
   // merge and EtoX FiLMs happen in its own kernels).  Non-null: attn_part / film are not read.
   const float* newX_in;
+  const unsigned* chunk_bits;   // [B] bit jc: chunk jc of the graph holds a valid key (launch_build_lists), or null: from the mask
 };
 bool node_layer_supported(int dx, int ffx);
 bool node_layer_x3_enabled();   // the x3 kernels are selected (SCGG_NODE_MODE is not f32)

@@ -19,6 +19,15 @@
 #include <stdlib.h>
 
 namespace scgg {
+#ifdef SCGG_STAMP_NODE   // development aid: s_memtime at the phase boundaries of node_layer_x3_kernel (scripts/probe/node_stamps.py)
+__device__ unsigned long long scgg_node_stamps[4][2][16];
+#define SCGG_NSTAMP(k) do { if (lane == 0 && (wave == 0 || wave == 7) && (blockIdx.x == 0 || blockIdx.x == 57 || blockIdx.x == 130 || blockIdx.x == 200)) \
+  { unsigned long long* q_ = &scgg_node_stamps[blockIdx.x == 0 ? 0 : blockIdx.x == 57 ? 1 : blockIdx.x == 130 ? 2 : 3][wave == 7][k]; \
+    if (*q_ == 0) *q_ = __builtin_readcyclecounter(); } } while (0)   /* first launch after load only: layer 0, with the q|k|v tail */
+#else
+#define SCGG_NSTAMP(k) do {} while (0)
+#endif
+
 
 template <int DXB, int FXB>
 struct NodeGeom {
@@ -245,6 +254,7 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
   char* R2 = smem + G::REGION;
   f32x4 res[RPW];                                               // residual stream X of this wave's rows (lane = 4 channels)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  SCGG_NSTAMP(0);
   const int count = *a.row_count;
   const int tile = blockIdx.x;
   if (tile * TR >= count) return;
@@ -260,6 +270,7 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
   ring.next = nullptr;
   if (w_xout != nullptr) w3_prime<KCX>(ring, w_xout);
 
+  SCGG_NSTAMP(1);
   // ---- prologue: this wave's rows: newX_pre from the attention partials of the row's units, residual X
   const int n = a.n, nch = (n + 15) >> 4;
   long long grow[RPW];
@@ -287,7 +298,8 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
     for (int t = 0; t < RPW; ++t) {
       const uint8_t* mb = a.mask + (grow[t] / n) * n;
       unsigned bt = 0;
-      for (int jc = 0; jc < nch; ++jc) {
+      if (a.chunk_bits != nullptr) bits[t] = a.chunk_bits[grow[t] / n];   // (scanning the mask here: 32 dependent byte loads per row)
+      else for (int jc = 0; jc < nch; ++jc) {
         bool any = false;
         for (int j = jc * 16; j < min(n, jc * 16 + 16); ++j) any |= mb[j] != 0;      // wave-uniform
         bt |= any ? (1u << (jc & 31)) : 0u;
@@ -299,6 +311,51 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
       if (c < DX) res[t] = *reinterpret_cast<const f32x4*>(a.X + grow[t] * DX + c);
     }
     constexpr int RH = RPW / 2;                                 // rows per batch (register budget)
+    if (nch <= 2) {
+      // up to 32 nodes: the partials of a batch's rows for BOTH chunks and their FiLM vectors are requested together: one round
+      // trip per batch (96 registers; all six rows at once spill)
+#pragma unroll
+      for (int t0 = 0; t0 < RPW; t0 += RH) {
+        f32x4 m[RH][2], s2[RH][2], ac[RH][2], fa[RH], fm[RH];
+#pragma unroll
+        for (int t = 0; t < RH; ++t) {
+#pragma unroll
+          for (int jc = 0; jc < 2; ++jc) {
+            m[t][jc] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}; s2[t][jc] = f32x4{0.f, 0.f, 0.f, 0.f}; ac[t][jc] = s2[t][jc];
+            if (c < DX && jc < nch && ((bits[t0 + t] >> jc) & 1u)) {
+              const float* pt = a.attn_part + (grow[t0 + t] * nch + jc) * (3 * DX) + c;
+              m[t][jc] = *reinterpret_cast<const f32x4*>(pt); s2[t][jc] = *reinterpret_cast<const f32x4*>(pt + DX);
+              ac[t][jc] = *reinterpret_cast<const f32x4*>(pt + 2 * DX);
+            }
+          }
+          fa[t] = fm[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (c < DX) {
+            const float* film = a.film + (grow[t0 + t] / n) * (4 * DX);
+            fa[t] = *reinterpret_cast<const f32x4*>(film + 2 * DX + c); fm[t] = *reinterpret_cast<const f32x4*>(film + 3 * DX + c);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < RH; ++t) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {       // the same operations, in the same order, as the chunk loop below
+            float Mx = -INFINITY, Sx = 0.f, Ax = 0.f;
+#pragma unroll
+            for (int jc = 0; jc < 2; ++jc) {
+              const float mn = fmaxf(Mx, m[t][jc][e]);
+              const float fo = Mx == -INFINITY ? 0.f : __expf(Mx - mn);
+              const float fn = m[t][jc][e] == -INFINITY ? 0.f : __expf(m[t][jc][e] - mn);
+              Sx = Sx * fo + s2[t][jc][e] * fn;
+              Ax = Ax * fo + ac[t][jc][e] * fn;
+              Mx = mn;
+            }
+            o[e] = fa[t][e] + fm[t][e] * (Ax / Sx);
+          }
+          if (c < DX) put_split4<KS, PLANE>(S1, wave * RPW + t0 + t, c, o);
+        }
+      }
+    } else
 #pragma unroll
     for (int t0 = 0; t0 < RPW; t0 += RH) {
       f32x4 Mx[RH], Sx[RH], Ax[RH];
@@ -349,6 +406,7 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
       for (int rg = 0; rg < NRG; ++rg) acc[blk][rg] = bv;
     }
   };
+  SCGG_NSTAMP(2);
   // ---- x_out: planes(R1) -> fp32(R2)
   if (wave < NPX) {
     float* F = reinterpret_cast<float*>(R2);
@@ -362,10 +420,12 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
         *reinterpret_cast<f32x4*>(F + (16 * rg + p) * LD + 16 * (2 * wave + blk) + 4 * g) = acc[blk][rg];
   }
   __syncthreads();
+  SCGG_NSTAMP(3);
   // ---- X = normX1(X + newX): registers, and planes(R1) as the next operand
   tile_add_layernorm_x3<DX, LD, KS, PLANE, RPW>(res, reinterpret_cast<const float*>(R2), S1, a.ln1_g, a.ln1_b, wave, lane,
                                                 nullptr, grow, gok);
   __syncthreads();
+  SCGG_NSTAMP(4);
   // ---- linX1 + relu: planes(R1) -> planes(R2)
   __bf16* S2 = reinterpret_cast<__bf16*>(R2);
   if (wave < NPF) {
@@ -383,6 +443,7 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
       }
   }
   __syncthreads();
+  SCGG_NSTAMP(5);
   // ---- linX2: planes(R2) -> fp32(R1)
   if (wave < NPX) {
     float* F = reinterpret_cast<float*>(R1);
@@ -396,11 +457,14 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
         *reinterpret_cast<f32x4*>(F + (16 * rg + p) * LD + 16 * (2 * wave + blk) + 4 * g) = acc[blk][rg];
   }
   __syncthreads();
+  SCGG_NSTAMP(6);
   // ---- X = normX2(X + ff): global and planes(R2) (every row of the tile is a valid node, so the node mask is 1)
   tile_add_layernorm_x3<DX, LD, KS, PLANE, RPW>(res, reinterpret_cast<const float*>(R1), S2, a.ln2_g, a.ln2_b, wave, lane,
                                                 a.X_out, grow, gok);
+  SCGG_NSTAMP(8);
   if (!has_qkv) return;
   __syncthreads();
+  SCGG_NSTAMP(7);
   // ---- trailing Linear on the new X (q | k | v of the next layer, or mlp_out_X.0 + ReLU after the last): planes(R2) -> global
   {
     long long qrow[NRG];
@@ -430,6 +494,7 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
           }
     }
   }
+  SCGG_NSTAMP(9);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -577,6 +642,16 @@ static int launch_one(const NodeLayerArgs& a, int M, hipStream_t st) {
 }
 
 bool node_layer_x3_enabled() { return node_x3(); }
+
+#ifdef SCGG_STAMP_NODE
+extern "C" int scgg_debug_node_stamps_reset(void) {
+  static unsigned long long zero[4 * 2 * 16] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(scgg_node_stamps), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+extern "C" int scgg_debug_node_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(scgg_node_stamps), sizeof(unsigned long long) * 4 * 2 * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 
 bool node_layer_supported(int dx, int ffx) { return (dx == 256 && ffx == 256) || (dx == 128 && ffx == 128); }
 
