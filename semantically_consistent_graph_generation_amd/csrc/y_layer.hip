@@ -20,6 +20,20 @@
 
 namespace scgg {
 
+#ifdef SCGG_STAMP_Y   // development aid: s_memtime at the phase boundaries of y_layer_kernel (scripts/probe/y_stamps.py)
+__device__ unsigned long long scgg_y_stamps[4][16];
+#define SCGG_YSTAMP(k) do { if (threadIdx.x == 0 && a.update && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 300 || blockIdx.x == 500)) { \
+  unsigned long long* q_ = &scgg_y_stamps[blockIdx.x == 0 ? 0 : blockIdx.x == 100 ? 1 : blockIdx.x == 300 ? 2 : 3][k]; if (*q_ == 0) *q_ = __builtin_readcyclecounter(); } } while (0)
+extern "C" int scgg_debug_y_stamps(unsigned long long* out, int reset) {
+  static unsigned long long zero[4 * 16] = {};
+  if (reset) return hipMemcpyToSymbol(HIP_SYMBOL(scgg_y_stamps), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(scgg_y_stamps), sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#else
+#define SCGG_YSTAMP(k) do {} while (0)
+#endif
+
+
 #ifndef SCGG_YG
 #define SCGG_YG 1
 #endif
@@ -148,6 +162,7 @@ __global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
   float* t1 = yv + YG * ldy;                                      // [YG][dy]
   float* t2 = t1 + YG * ldy;                                      // [YG][ldf]   (y_out hidden, then the lin_y1 hidden)
   const int b0 = blockIdx.x * YG;
+  SCGG_YSTAMP(0);
 
   if (a.update) {
     const int e0 = dy + 4 * a.dx;
@@ -183,14 +198,20 @@ __global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
     yv[g * ldy + c] = a.y[(size_t)min(b0 + g, a.B - 1) * dy + c];
   }
   __syncthreads();
+  SCGG_YSTAMP(1);
   if (a.update) {
     y_dense(a.Wt_cat, a.b_cat, dy, kcat, cat, kcat, t1, ldy, false, red, tid);        // y_y + x_y + e_y
+    SCGG_YSTAMP(2);
     y_dense(a.Wt_o0, a.b_o0, dy, dy, t1, ldy, t2, ldf, true, red, tid);               // y_out.0 + relu
     y_dense(a.Wt_o2, a.b_o2, dy, dy, t2, ldf, t1, ldy, false, red, tid);              // y_out.2
+    SCGG_YSTAMP(3);
     y_add_layernorm(yv, t1, ldy, dy, a.ln1_g, a.ln1_b, tid);
     __syncthreads();
+    SCGG_YSTAMP(4);
     y_dense(a.Wt_l1, a.b_l1, a.ffy, dy, yv, ldy, t2, ldf, true, red, tid);            // lin_y1 + relu
+    SCGG_YSTAMP(5);
     y_dense(a.Wt_l2, a.b_l2, dy, a.ffy, t2, ldf, t1, ldy, false, red, tid);           // lin_y2
+    SCGG_YSTAMP(6);
     y_add_layernorm(yv, t1, ldy, dy, a.ln2_g, a.ln2_b, tid);
     __syncthreads();
     for (int idx = tid; idx < YG * dy; idx += YT) {
@@ -198,6 +219,7 @@ __global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
       if (b0 + g < a.B) a.y[(size_t)(b0 + g) * dy + c] = yv[g * ldy + c];
     }
   }
+  SCGG_YSTAMP(7);
   if (a.Wt_film != nullptr) {
     // FiLM vectors for the next edge / node kernels.  film_n == 0: the 2D block's four dx-wide vectors with +1 folded into
     // the two "mul" quarters; film_n > 0: film_n raw outputs (the position-aware block: y_e_add | y_e_mul | y_x_add | y_x_mul
@@ -218,6 +240,7 @@ __global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
         if (b0 + g < a.B) *reinterpret_cast<yf4*>(a.film + (size_t)(b0 + g) * FN + 4 * o4) = acc[g];
     }
   }
+  SCGG_YSTAMP(8);
 }
 
 static size_t y_layer_lds(int dy, int ffy, int kcat) {
