@@ -721,31 +721,48 @@ __global__ __launch_bounds__(NW * 64) void block3d_ffn_kernel(Block3DArgs a) {
 // per-channel affine map of the statistics of Y) and of dist1 (:183-187, layers.py:60-69).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void block3d_row_merge_kernel(RowMerge3DArgs a) {
+  // per wave: softmax weight of (head, chunk) = exp(m - M_head) / S_head, formed once by H * nch lanes; the channel loop then
+  // reads one value per chunk and its loads are independent of one another (they were a chain of round trips: three loads
+  // per chunk and channel behind a maximum that was re-read per channel)
+  __shared__ float wsm[4][8 * 32];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ridx = blockIdx.x * 4 + wave;
   if (ridx >= *a.row_count) return;
   const int row = a.rows[ridx];
   const int n = a.n, nch = (n + 15) >> 4, b = row / n;
   const int H = a.n_head, DX = a.dx, DE = a.de, AP = H * DX + 32;
-  const int* cc = a.chunk_cnt + b * nch;
-  const float* ap0 = a.attn_part + (long long)row * nch * AP;
+  const int* __restrict__ cc = a.chunk_cnt + b * nch;
+  const float* __restrict__ ap0 = a.attn_part + (long long)row * nch * AP;
+  float* __restrict__ wv = a.wvcat + (long long)row * (H * DX);
+  float* ws = wsm[wave];
+  for (int hc0 = 0; hc0 < H * nch; hc0 += 64) {            // (head, chunk) pairs, head-major; H <= 8, nch <= 32
+    const int hc = hc0 + lane, h = hc / nch;
+    if (hc < H * nch) {
+      float M = -INFINITY;
+      for (int c = 0; c < nch; ++c)
+        if (cc[c] > 0) M = fmaxf(M, ap0[(long long)c * AP + H * DX + h]);
+      float S = 0.f;
+      for (int c = 0; c < nch; ++c)
+        if (cc[c] > 0) S += ap0[(long long)c * AP + H * DX + 16 + h] * __expf(ap0[(long long)c * AP + H * DX + h] - M);
+      const int c = hc - h * nch;
+      ws[hc] = cc[c] > 0 ? __expf(ap0[(long long)c * AP + H * DX + h] - M) / S : 0.f;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): the LDS writes above, before other lanes read them
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
   for (int t = lane; t < H * DX; t += 64) {
     const int h = t / DX;
-    float M = -INFINITY;
-    for (int c = 0; c < nch; ++c)
-      if (cc[c] > 0) M = fmaxf(M, ap0[(long long)c * AP + H * DX + h]);
-    float S = 0.f, acc = 0.f;
-    for (int c = 0; c < nch; ++c)
-      if (cc[c] > 0) {
-        const float* ap = ap0 + (long long)c * AP;
-        const float w = __expf(ap[H * DX + h] - M);
-        S += ap[H * DX + 16 + h] * w;
-        acc += ap[t] * w;
-      }
-    a.wvcat[(long long)row * (H * DX) + t] = acc / S;
+    float acc = 0.f;
+    for (int c = 0; c < nch; ++c) {
+      const float w = ws[h * nch + c];
+      if (w != 0.f) acc += ap0[(long long)c * AP + t] * w;
+    }
+    wv[t] = acc;
   }
-  const float* sp0 = a.stat_part + (long long)row * nch * (8 * DE);
-  const float* fl = a.film + (long long)b * a.ldf;
+  const float* __restrict__ sp0 = a.stat_part + (long long)row * nch * (8 * DE);
+  const float* __restrict__ fl = a.film + (long long)b * a.ldf;
   for (int t = lane; t < DE; t += 64) {
     const int which = 0, ch = t;
     float N = 0.f, mean = 0.f, m2 = 0.f, mn = INFINITY, mx = -INFINITY;
