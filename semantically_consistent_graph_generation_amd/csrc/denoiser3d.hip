@@ -488,8 +488,20 @@ int run3(scgg_denoiser3d* h, const float* X, const float* E, const float* y, con
       RowMerge3DArgs r{w.attn, w.stat, w.chunk_cnt, film, FL, w.wvcat, w.rowstat, w.rowagg, w.rows, w.row_count, n, H, dx, de};
       TRY(launch_block3d_row_merge(r, M, st));
       TRY(rowlin_named(L.out, sa + "out", w.wvcat, H * dx, w.t_out, dx, dx, H * dx, false));
-      TRY(rowlin_named(L.ex, sa + "e_x_mul.lin", w.rowstat, 8 * de, w.t_ex, dx, dx, 4 * de, false));
-      TRY(rowlin_named(L.px, sa + "pos_x_mul.lin", w.rowstatD + (size_t)l * M * 4 * de, 4 * de, w.t_px, dx, dx, 4 * de, false));
+      {   // the two EtoX Linears (same K = 4 de, same rows) in one launch when both have their bf16x3 images
+        int rc = -1;
+        if (L.ex.W3 != nullptr && L.px.W3 != nullptr) {
+          NodeLinearArgs a0{w.rowstat, nullptr, L.ex.b, w.t_ex, w.rows, w.row_count, dx, 4 * de, (dx + 31) / 32, 8 * de, dx, 1, 0};
+          NodeLinearArgs a1{w.rowstatD + (size_t)l * M * 4 * de, nullptr, L.px.b, w.t_px, w.rows, w.row_count, dx, 4 * de,
+                            (dx + 31) / 32, 4 * de, dx, 1, 0};
+          rc = launch_node_linear_x3_pair(a0, L.ex.W3, a1, L.px.W3, M, st);
+          if (rc != 0 && rc != -1) return fail("row-list Linear pair launch failed");
+        }
+        if (rc != 0) {
+          TRY(rowlin_named(L.ex, sa + "e_x_mul.lin", w.rowstat, 8 * de, w.t_ex, dx, dx, 4 * de, false));
+          TRY(rowlin_named(L.px, sa + "pos_x_mul.lin", w.rowstatD + (size_t)l * M * 4 * de, 4 * de, w.t_px, dx, dx, 4 * de, false));
+        }
+      }
       TRY(launch_block3d_newx(w.t_out, w.t_ex, w.t_px, mask, film, FL, 2 * de, w.newX, M, n, dx, st));
       if (L.predicts_y) {   // y(l+1) and the FiLM vectors of layer l+1 (into the other buffer: film(l) is still being read)
         if (!y_pool_on) {

@@ -177,6 +177,8 @@ struct NodeLinearArgs {   // row-list Linear on pre-packed weights (node path)
 int launch_node_linear(const NodeLinearArgs& a, int M, hipStream_t st);
 // the same Linear on the bf16x3 scheme (node_layer.hip; W3 from launch_pack_linear_x3); -1: shape not covered, use the above
 int launch_node_linear_x3(const NodeLinearArgs& a, const f32x4_t* W3, int M, hipStream_t st);
+int launch_node_linear_x3_pair(const NodeLinearArgs& a0, const f32x4_t* W0, const NodeLinearArgs& a1, const f32x4_t* W1, int M,
+                               hipStream_t st);   // two Linears of the same K in one launch; -1: not covered
 
 struct SitBlockArgs {     // one SiT block between two attention launches (sit_block.hip); weights as bf16x3 images
   const float* att;       // [M,H] attention output of this block

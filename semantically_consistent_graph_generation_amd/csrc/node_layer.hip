@@ -503,7 +503,7 @@ __global__ __launch_bounds__(512) void node_layer_x3_kernel(NodeLayerArgs a) {
 // each wave walks output block pairs w, w + 8, ...
 // ---------------------------------------------------------------------------------------------------------
 template <int KC, int NRG, int D>
-__global__ __launch_bounds__(512) void node_linear_x3_kernel(NodeLinearArgs a, const f32x4* W3) {
+__device__ __forceinline__ void node_linear_x3_body(const NodeLinearArgs& a, const f32x4* W3) {
   constexpr int K = 32 * KC, TR = 16 * NRG, KS = K + 8, PLANE = TR * KS, RPW = TR / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __bf16* S = reinterpret_cast<__bf16*>(smem);
@@ -607,6 +607,29 @@ __global__ __launch_bounds__(512) void node_linear_x3_kernel(NodeLinearArgs a, c
   }
 }
 
+template <int KC, int NRG, int D>
+__global__ __launch_bounds__(512) void node_linear_x3_kernel(NodeLinearArgs a, const f32x4* W3) {
+  node_linear_x3_body<KC, NRG, D>(a, W3);
+}
+// two Linears of the same K on the same row list in one launch (blockIdx.y picks one): the e_x_mul / pos_x_mul pair of the
+// position-aware block
+template <int KC, int NRG, int D>
+__global__ __launch_bounds__(512) void node_linear_x3_pair_kernel(NodeLinearArgs a0, const f32x4* W0, NodeLinearArgs a1, const f32x4* W1) {
+  if (blockIdx.y == 0) node_linear_x3_body<KC, NRG, D>(a0, W0);
+  else node_linear_x3_body<KC, NRG, D>(a1, W1);
+}
+
+template <int KC, int NRG = 3, int D = NWD>
+static int launch_linear_x3_pair(const NodeLinearArgs& a0, const f32x4* W0, const NodeLinearArgs& a1, const f32x4* W1, int M, hipStream_t st) {
+  constexpr int TR = 16 * NRG;
+  constexpr size_t lds = (size_t)3 * TR * (32 * KC + 8) * 2;
+  static LdsAttrOnce attr;
+  auto kern = node_linear_x3_pair_kernel<KC, NRG, D>;
+  if (set_max_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds)) return -2;
+  hipLaunchKernelGGL(kern, dim3((M + TR - 1) / TR, 2), dim3(512), lds, st, a0, W0, a1, W1);
+  return 0;
+}
+
 template <int KC, int NRG = 3, int D = NWD>
 static int launch_linear_x3(const NodeLinearArgs& a, const f32x4* W3, int M, hipStream_t st) {
   constexpr int TR = 16 * NRG;
@@ -663,6 +686,17 @@ int launch_node_linear_x3(const NodeLinearArgs& a, const f32x4_t* W3, int M, hip
   if (a.K == 256) return launch_linear_x3<8>(a, W3, M, st);
   if (a.K == 192) return launch_linear_x3<6>(a, W3, M, st);
   if (a.K == 128) return launch_linear_x3<4>(a, W3, M, st);
+  return -1;
+}
+
+// two row-list Linears of the same K in one launch; -1: not covered (launch them one by one)
+int launch_node_linear_x3_pair(const NodeLinearArgs& a0, const f32x4_t* W0, const NodeLinearArgs& a1, const f32x4_t* W1, int M,
+                               hipStream_t st) {
+  if (!node_x3() || W0 == nullptr || W1 == nullptr || a0.K != a1.K || a0.ln_h != nullptr || a1.ln_h != nullptr) return -1;
+  for (const NodeLinearArgs* a : {&a0, &a1})
+    if (a->lda % 4 != 0 || a->ldc % 4 != 0 || a->N % 4 != 0) return -1;
+  if (a0.K == 256) return launch_linear_x3_pair<8>(a0, W0, a1, W1, M, st);
+  if (a0.K == 128) return launch_linear_x3_pair<4>(a0, W0, a1, W1, M, st);
   return -1;
 }
 
