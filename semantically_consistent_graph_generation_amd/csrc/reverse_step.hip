@@ -26,18 +26,21 @@ constexpr int MAXC = 32;
 constexpr int MAXK = 8;
 
 // sequential inverse-CDF draws without replacement; p is consumed.  Must match oracle/noise.py:inverse_cdf_draws.
-__device__ __forceinline__ void draw_sequence(float (&p)[MAXC], int C, const float* u, int k, int8_t* out) {
+// MC: compile-time bound of the class loops (>= C): 16 for the usual edge-class counts, MAXC otherwise; the operations on the
+// classes c < C and their order do not depend on it
+template <int MC>
+__device__ __forceinline__ void draw_sequence(float (&p)[MC], int C, const float* u, int k, int8_t* out) {
   uint32_t picked = 0;
   for (int r = 0; r < k; ++r) {
     float total = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
+    for (int c = 0; c < MC; ++c)
       if (c < C) total = total + p[c];
     const float thr = u[r] * total;
     float acc = 0.f;
     int sel = -1, last = -1;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
+    for (int c = 0; c < MC; ++c)
       if (c < C) {
         acc = acc + p[c];
         if (sel < 0 && thr < acc) sel = c;
@@ -47,7 +50,7 @@ __device__ __forceinline__ void draw_sequence(float (&p)[MAXC], int C, const flo
     if (sel < 0) sel = __ffs(~picked) - 1;
     out[r] = (int8_t)sel;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
+    for (int c = 0; c < MC; ++c)
       if (c == sel) p[c] = 0.f;
     picked |= 1u << sel;
   }
@@ -76,24 +79,33 @@ __device__ __forceinline__ void write_pair(const SampleOut& o, long long pij, lo
                                            const int8_t* cand) {
   o.labels[pij] = lab;
   o.labels[pji] = lab;
-  if (o.cands != nullptr)
-    for (int r = 0; r < top_k; ++r) {
-      o.cands[pij * top_k + r] = cand[r];
-      o.cands[pji * top_k + r] = cand[r];
+  if (o.cands != nullptr) {
+    if (top_k == 4 && (reinterpret_cast<uintptr_t>(o.cands) & 3) == 0) {      // the usual case: one 32-bit store per orientation
+      const uint32_t v = (uint32_t)(uint8_t)cand[0] | ((uint32_t)(uint8_t)cand[1] << 8) | ((uint32_t)(uint8_t)cand[2] << 16) |
+                         ((uint32_t)(uint8_t)cand[3] << 24);
+      reinterpret_cast<uint32_t*>(o.cands)[pij] = v;
+      reinterpret_cast<uint32_t*>(o.cands)[pji] = v;
+    } else {
+      for (int r = 0; r < top_k; ++r) {
+        o.cands[pij * top_k + r] = cand[r];
+        o.cands[pji * top_k + r] = cand[r];
+      }
     }
+  }
 }
 
 // sample one live pair from p (consumed) and write it
-__device__ __forceinline__ void sample_and_write(float (&p)[MAXC], int C, int top_k, const SampleRng& g, int b, int i,
+template <int MC>
+__device__ __forceinline__ void sample_and_write(float (&p)[MC], int C, int top_k, const SampleRng& g, int b, int i,
                                                  int j, long long pij, long long pji, const SampleOut& o) {
   float u[1 + MAXK];
   get_uniforms(g, b, i, j, pij, top_k, u);
   int8_t cand[MAXK];
   int8_t lab;
   if (top_k > 0) {
-    float p1[MAXC];
+    float p1[MC];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) p1[c] = p[c];
+    for (int c = 0; c < MC; ++c) p1[c] = p[c];
     draw_sequence(p1, C, u, 1, &lab);              // E_t = multinomial(1)            diffusion_utils.py:239
     draw_sequence(p, C, u + 1, top_k, cand);       // multinomial(top_k)              :246
     cand[0] = lab;                                 // slot 0 overwritten              :249
@@ -104,38 +116,21 @@ __device__ __forceinline__ void sample_and_write(float (&p)[MAXC], int C, int to
 }
 
 // --------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void reverse_step_kernel(ReverseStepArgs a) {
-  const long long idx = blockIdx.x * 256ll + threadIdx.x;
-  const long long nn = (long long)a.n * a.n;
-  if (idx >= a.B * nn) return;
-  const int b = idx / nn;
-  const int ij = idx - b * nn;
-  const int i = ij / a.n, j = ij - i * a.n;
+// one live pair: softmax of its logit row (lrow, in LDS), posterior, and for i < j the draws
+template <int MC>
+__device__ __forceinline__ void reverse_step_pair(const ReverseStepArgs& a, const float* lrow, long long pij, int b, int i, int j, int k) {
   const int C = a.C;
-  const long long pij = idx, pji = (long long)b * nn + (long long)j * a.n + i;
-  if (i > j && a.prob_out == nullptr) return;
-  const bool live = i != j && a.mask[b * a.n + i] != 0 && a.mask[b * a.n + j] != 0;
-  int k = live ? a.labels_t[pij] : -1;
-  if (k < 0) {   // diagonal / padded pair (or a pair the caller marked dead): zero one-hot row -> label -1
-    if (i <= j) {
-      int8_t zero[MAXK] = {0};
-      write_pair(a.out, pij, pji, a.top_k, -1, zero);
-    }
-    if (a.prob_out != nullptr)
-      for (int c = 0; c < C; ++c) a.prob_out[pij * C + c] = 1.0f / C;   // what the reference leaves there
-    return;
-  }
-  // softmax over the x0 logits
-  float pr[MAXC];
+  const long long pji = (long long)b * a.n * a.n + (long long)j * a.n + i;
+  float pr[MC];
   float mxl = -INFINITY;
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    pr[c] = c < C ? a.logits[pij * C + c] : -INFINITY;
+  for (int c = 0; c < MC; ++c) {
+    pr[c] = c < C ? lrow[c] : -INFINITY;
     mxl = fmaxf(mxl, pr[c]);
   }
   float se = 0.f;
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
+  for (int c = 0; c < MC; ++c) {
     pr[c] = c < C ? expf(pr[c] - mxl) : 0.f;
     se += pr[c];
   }
@@ -144,9 +139,9 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(ReverseStepArgs a) {
   const float beta_t = a.beta_tab[t], abar_t = a.abar_tab[t], abar_s = a.abar_tab[s];
   const float mk = a.marg[k];
   float S = 0.f;
-  float q[MAXC];   // pred[a]/den[a]
+  float q[MC];   // pred[a]/den[a]
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
+  for (int c = 0; c < MC; ++c) {
     q[c] = 0.f;
     if (c < C) {
       float den = (1.0f - abar_t) * mk + (c == k ? abar_t : 0.f);
@@ -157,7 +152,7 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(ReverseStepArgs a) {
   }
   float tot = 0.f;
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
+  for (int c = 0; c < MC; ++c) {
     float un = 0.f;
     if (c < C) {
       const float qt = beta_t * mk + (c == k ? 1.0f - beta_t : 0.f);
@@ -168,14 +163,72 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(ReverseStepArgs a) {
   }
   if (tot == 0.f) {
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) pr[c] = c < C ? 1e-5f : 0.f;
+    for (int c = 0; c < MC; ++c) pr[c] = c < C ? 1e-5f : 0.f;
     tot = 1e-5f * C;
   }
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) pr[c] = pr[c] / tot;
+  for (int c = 0; c < MC; ++c) pr[c] = pr[c] / tot;
   if (a.prob_out != nullptr)
     for (int c = 0; c < C; ++c) a.prob_out[pij * C + c] = pr[c];
   if (i < j) sample_and_write(pr, C, a.top_k, a.rng, b, i, j, pij, pji, a.out);
+}
+
+template <int MC>
+__global__ __launch_bounds__(256) void reverse_step_kernel(ReverseStepArgs a) {
+  // the workgroup's 256 logit rows (consecutive pairs) through LDS: coalesced reads; a thread's own row is C floats at a
+  // stride of C between lanes otherwise (28 cache lines per load instruction at C = 14)
+  __shared__ float lg[256 * MC];
+  __shared__ short queue[256];
+  __shared__ int wcount[4];
+  const long long idx = blockIdx.x * 256ll + threadIdx.x;
+  const long long nn = (long long)a.n * a.n;
+  const int C = a.C;
+  {
+    const long long base = blockIdx.x * 256ll * C, total = a.B * nn * C;
+    for (int k = threadIdx.x; k < 256 * C; k += 256) lg[k] = base + k < total ? a.logits[base + k] : 0.f;
+  }
+  // this thread's pair: dead pairs are written at once; a live pair that needs the arithmetic is queued
+  bool work = false;
+  int b = 0, i = 0, j = 0, k = -1;
+  if (idx < a.B * nn) {
+    b = (int)(idx / nn);
+    const int ij = (int)(idx - b * nn);
+    i = ij / a.n; j = ij - i * a.n;
+    if (!(i > j && a.prob_out == nullptr)) {
+      const bool live = i != j && a.mask[b * a.n + i] != 0 && a.mask[b * a.n + j] != 0;
+      k = live ? a.labels_t[idx] : -1;
+      if (k < 0) {   // diagonal / padded pair (or a pair the caller marked dead): zero one-hot row -> label -1
+        if (i <= j) {
+          int8_t zero[MAXK] = {0};
+          write_pair(a.out, idx, (long long)b * nn + (long long)j * a.n + i, a.top_k, -1, zero);
+        }
+        if (a.prob_out != nullptr)
+          for (int c = 0; c < C; ++c) a.prob_out[idx * C + c] = 1.0f / C;   // what the reference leaves there
+      } else {
+        work = true;
+      }
+    }
+  }
+  // Live pairs are a quarter of the threads in the sampling loop (upper triangle of the valid block): they are compacted
+  // over the workgroup so that the class loops and the Philox draws run in full waves and the other waves leave.
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long bal = __ballot(work);
+  if (lane == 0) wcount[wave] = __popcll(bal);
+  __syncthreads();                                           // also: lg is complete
+  int off = 0, total_work = 0;
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) off += wcount[w];
+    total_work += wcount[w];
+  }
+  if (work) queue[off + __popcll(bal & ((1ull << lane) - 1ull))] = (short)threadIdx.x;
+  __syncthreads();
+  if ((int)threadIdx.x >= total_work) return;
+  const int li = queue[threadIdx.x];
+  const long long pij = blockIdx.x * 256ll + li;
+  const int b2 = (int)(pij / nn);
+  const int ij2 = (int)(pij - b2 * nn);
+  const int i2 = ij2 / a.n, j2 = ij2 - i2 * a.n;
+  reverse_step_pair<MC>(a, lg + li * C, pij, b2, i2, j2, a.labels_t[pij]);
 }
 
 // generic form: probabilities supplied (any transition; also the training-time apply_noise draw)
@@ -228,7 +281,8 @@ static inline dim3 grid_for(long long total) { return dim3((unsigned)((total + 2
 
 int launch_reverse_step(const ReverseStepArgs& a, hipStream_t st) {
   if (a.C > MAXC || a.top_k > MAXK) return -1;
-  hipLaunchKernelGGL(reverse_step_kernel, grid_for((long long)a.B * a.n * a.n), dim3(256), 0, st, a);
+  if (a.C <= 16) hipLaunchKernelGGL(reverse_step_kernel<16>, grid_for((long long)a.B * a.n * a.n), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(reverse_step_kernel<MAXC>, grid_for((long long)a.B * a.n * a.n), dim3(256), 0, st, a);
   return 0;
 }
 int launch_sample_from_probs(const SampleProbsArgs& a, hipStream_t st) {
