@@ -29,3 +29,5 @@ assert dll.scgg_debug_y_stamps(buf, 0) == 0
 for wg in range(4):
     s = [buf[wg * 16 + k] for k in range(9)]
     print(f"wg{wg}: " + " ".join(f"{s[i + 1] - s[i]:6d}" for i in range(8)) + f"  total {s[8] - s[0]}")
+    p_ = [buf[wg * 16 + k] for k in (0, 9, 10, 11, 12)]
+    print("      inside phase 0->1: input fill %d, mask compaction %d, Xtoy %d, Etoy %d" % tuple(p_[i + 1] - p_[i] for i in range(4)))

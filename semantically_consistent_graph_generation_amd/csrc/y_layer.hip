@@ -188,9 +188,13 @@ __global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
                    a.gm_newX + (size_t)b0 * a.n * a.dx, m, a.n, s_nv3, a.dx, a.de, cat + dy, cat + e0, tid, YT);
     } else if (own_x || own_e) {                                   // wave-uniform; the statistics of this graph, straight into cat
       __shared__ PoolScratch ps;
+      SCGG_YSTAMP(9);
       const int nv = pool_compact_mask(ps, a.mask + (size_t)b0 * a.n, a.n, tid);
+      SCGG_YSTAMP(10);
       if (own_x) pool_xtoy_graph(ps, a.pool_X + (size_t)b0 * a.n * a.dx, nv, a.dx, cat + dy, tid);
+      SCGG_YSTAMP(11);
       if (own_e) pool_etoy_graph(ps, a.pool_E + (size_t)b0 * a.n * a.n * a.de, a.n, nv, a.de, cat + e0, tid);
+      SCGG_YSTAMP(12);
     }
   }
   for (int idx = tid; idx < YG * dy; idx += YT) {
