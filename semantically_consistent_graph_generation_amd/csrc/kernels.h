@@ -173,6 +173,12 @@ struct NodeLinearArgs {   // row-list Linear on pre-packed weights (node path)
   const int32_t* ln_t = nullptr;
   int ln_ld = 0, ln_n = 1, ln_tc = 0;
   float ln_eps = 0.f;
+  // with ln_x: the residual row is formed as ln_be + ln_We . ln_x[row] (a [K, ln_cin] embedding of the raw input row, ln_cin
+  // small) and stored to ln_h; ln_o is null then
+  const float* ln_x = nullptr;
+  const float* ln_We = nullptr;
+  const float* ln_be = nullptr;
+  int ln_cin = 0;
 };
 int launch_node_linear(const NodeLinearArgs& a, int M, hipStream_t st);
 // the same Linear on the bf16x3 scheme (node_layer.hip; W3 from launch_pack_linear_x3); -1: shape not covered, use the above

@@ -533,7 +533,14 @@ __device__ __forceinline__ void node_linear_x3_body(const NodeLinearArgs& a, con
         const size_t tt = (size_t)(a.ln_t ? a.ln_t[row[t] / a.ln_n] : a.ln_tc) * a.ln_ld;
         v[t] = o[t] = gt[t] = sc[t] = sh[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (in) {
-          v[t] = *reinterpret_cast<const f32x4*>(a.ln_h + row[t] * K + c);
+          if (a.ln_x != nullptr) {               // first block: the residual row is the embedding of the raw input row
+            v[t] = *reinterpret_cast<const f32x4*>(a.ln_be + c);
+            for (int j = 0; j < a.ln_cin; ++j) {
+              const float xj = a.ln_x[row[t] * a.ln_cin + j];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[t][e] += xj * a.ln_We[(c + e) * a.ln_cin + j];
+            }
+          } else v[t] = *reinterpret_cast<const f32x4*>(a.ln_h + row[t] * K + c);
           if (a.ln_o != nullptr) {
             o[t] = *reinterpret_cast<const f32x4*>(a.ln_o + row[t] * K + c);
             gt[t] = *reinterpret_cast<const f32x4*>(a.ln_gate + tt + c);
@@ -547,7 +554,7 @@ __device__ __forceinline__ void node_linear_x3_body(const NodeLinearArgs& a, con
       for (int t = 0; t < RH; ++t) {
         const int ridx = tile * TR + wave * RPW + t0 + t;
         v[t] += gt[t] * o[t];
-        if (in && a.ln_o != nullptr && ridx < count)      // the filler rows of the last tile repeat a row
+        if (in && (a.ln_o != nullptr || a.ln_x != nullptr) && ridx < count)      // the filler rows of the last tile repeat a row
           *reinterpret_cast<f32x4*>(a.ln_h + row[t] * K + c) = v[t];
         const float mean = wave_sum64((v[t][0] + v[t][1]) + (v[t][2] + v[t][3])) * (1.0f / K);
         f32x4 d = v[t] - mean;

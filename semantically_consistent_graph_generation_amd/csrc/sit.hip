@@ -10,14 +10,14 @@
 //   * everything that depends on t only -- the timestep embedding, its MLP, the SiLU and the adaLN Linear of every block
 //     and of the final layer -- is computed for ALL timesteps once per weight set (finalize: GEMMs with M = noise_steps)
 //     into tables; a step reads its six vectors per block from them.
-//   * a step works on the valid rows only (row list from the mask).  Block 0's entry is [pos_embedder + LayerNorm +
-//     modulate] (16 lanes per row) and a row-list bf16x3 Linear for q|k|v; attention is one wave per (graph, head) on the
+//   * a step works on the valid rows only (row list from the mask).  Block 0's entry is a row-list bf16x3 Linear for q|k|v with
+//     [pos_embedder + LayerNorm + modulate] as its prologue (sit_lnmod_kernel when that Linear's shape is not built); attention is one wave per (graph, head) on the
 //     matrix pipe for n <= 64 (transposed scores, so the normalised P^T registers are the operand of P.V), else with the
 //     head's keys / values of a 64-key chunk in LDS and an online softmax (padded keys are skipped, which is exact: the
 //     reference gives them -1e9 and a valid query always has itself as a key); everything from an attention to the next
 //     one -- proj, gated residual, LayerNorm-modulate, fc1 + GELU, fc2, gated residual, the next block's LayerNorm-modulate
 //     and q|k|v -- is ONE launch (sit_block.hip); [last gated residual + final LayerNorm / modulate + the 192 -> 3 Linear +
-//     the DDPM update x_{t-1} = ... + sqrt(beta) z] is one kernel.  15 launches per step, no synchronisation, no
+//     the DDPM update x_{t-1} = ... + sqrt(beta) z] is one kernel.  14 launches per step, no synchronisation, no
 //     allocation.  Widths the fused kernel is not built for run as separate row-list Linears (with the LayerNorm-modulate
 //     as their prologue and GELU / accumulate epilogues) or, below those, through the generic fp32-MFMA GEMM.
 //   * the normal draws are Philox4x32-10 + Box-Muller keyed by (seed, graph id, node, step), or a caller-provided buffer
@@ -578,8 +578,18 @@ int stepS(scgg_sit* h, const WorkS& w, const float* x, const uint8_t* mask, int 
       return launch_node_linear_x3(a, L.W3, M, st);
     };
     // [gate_mlp of block i-1 (.) its MLP output] + LN + modulate(shift_msa, scale_msa), then q|k|v      (sit_model.py:129-132)
+    // block 0: pos_embedder + LN + modulate as the prologue of its q|k|v Linear (x -> h is stored on the way)
+    auto lin_embed = [&]() -> int {
+      const scgg_sit::Lin& L = Bk.qkv;
+      if (i != 0 || L.W3 == nullptr || H > 256) return -1;
+      NodeLinearArgs a{w.u, nullptr, L.b, w.qkv, w.rows, w.row_count, L.N, L.K, (L.N + 31) / 32, H, 3 * H, 1, 0};
+      a.ln_h = w.h; a.ln_shift = h->tab[0]; a.ln_scale = h->tab[0] + H; a.ln_t = t_ptr; a.ln_ld = 6 * H; a.ln_n = n; a.ln_tc = t_const;
+      a.ln_eps = 1e-6f; a.ln_x = x; a.ln_We = We->p; a.ln_be = be->p; a.ln_cin = c.in_channels;
+      return launch_node_linear_x3(a, L.W3, M, st);
+    };
     if (fused && i > 0) {
       // q|k|v of this block came out of the previous block's fused launch
+    } else if (lin_embed() == 0) {
     } else if (i == 0 || lin_ln(Bk.qkv, w.o, h->tab[i - 1], 5 * H, h->tab[i], 0, H, w.qkv, 3 * H, 0) != 0) {
       TRYS(lnmod(i == 0 ? nullptr : w.o, i == 0 ? nullptr : h->tab[i - 1], 5 * H, h->tab[i], 0, H));
       if (lin(Bk.qkv, w.u, H, w.qkv, 3 * H, 0) != 0) TRYS(gemmS(h, w.u, H, p + "attn.qkv", w.qkv, 3 * H, M, 3 * H, H, st));
