@@ -183,6 +183,12 @@ int scgg_sit_sample(scgg_sit* h, const float* x_T, const uint8_t* node_mask, int
                     const float* noise, uint64_t seed, uint32_t graph_id_base, float* x_out, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* replaces the torch.randn start coordinates of sample_limit_dist (noise_model.py:313-325: `pos = torch.randn(...)`, and the
+ * randn x_T inside NodeCoordsDiffusionModel.sample, cow_diff_nodes_with_3d_checks.py:66): out[B,n,3] standard normals keyed
+ * by (seed, graph_id_base + b, node, step word) -- the GLOBAL graph id, so a graph's start does not depend on the shard it
+ * is sampled in.  `step`: a word no iteration of the chain uses (the SiT sampler uses 1 .. noise_steps-1). */
+int scgg_philox_normal_rows(float* out, int32_t B, int32_t n, uint64_t seed, uint32_t graph_id_base, uint32_t step, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Reverse step: NoiseModel.sample_zs_from_zt_and_pred (src/ConStruct/diffusion/noise_model.py:342-447) with
  * sample_discrete_features (src/ConStruct/diffusion/diffusion_utils.py:200-285).  Called at

@@ -28,7 +28,7 @@ from oracle import fixtures as fx
 from oracle.noise import inverse_cdf_draws
 
 REF = "/root/reference"
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+OUT = os.environ.get("SCGG_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
 def import_reference():
@@ -476,6 +476,8 @@ def gen_sample_plan(R):
     class _D:
         def __init__(self, *a, **k):
             pass
+    before = dict(sys.modules)
+    tg_path = sys.modules["torch_geometric"].__dict__.get("__path__", None)
     stub("pytorch_lightning", LightningModule=_D)
     stub("src.ConStruct.analysis.visualization", Visualizer=_D)
     stub("src.ConStruct.diffusion.extra_features_molecular", ExtraMolecularFeatures=_D)
@@ -516,6 +518,31 @@ def gen_sample_plan(R):
         arrays[f"{name}/batches_flat"] = np.array([v for c in calls for v in c])
         print(f"{name}: {len(calls)} batches, sizes {[len(c) for c in calls]}")
     save("f13_sample_plan", names=np.array([c[0] for c in cases]), **arrays)
+    # take the stand-ins out again: later generators import the REAL pos_transformer_model / train_metrics modules
+    for k in [k for k in sys.modules if k not in before]:
+        del sys.modules[k]
+    sys.modules.update(before)
+    if tg_path is None:
+        sys.modules["torch_geometric"].__dict__.pop("__path__", None)
+    for pkg, attr in (("src.ConStruct.models", "pos_transformer_model"), ("src.ConStruct.models", "equivariant_pos_transformer_model"),
+                      ("src.ConStruct.metrics", "train_metrics"), ("src.ConStruct.metrics", "abstract_metrics"),
+                      ("src.ConStruct.analysis", "visualization"), ("src.ConStruct.diffusion", "extra_features_molecular"),
+                      ("src.ConStruct", "diffusion_model_discrete_3d")):
+        m = sys.modules.get(pkg)
+        if m is not None and attr in m.__dict__ and (pkg + "." + attr) not in sys.modules:
+            delattr(m, attr)
+
+
+def _fresh_metrics_modules():
+    """(Re-)import the reference's train_metrics / abstract_metrics against the torchmetrics stand-in installed just before:
+    drop the cached modules AND the attributes on their package (``from pkg import mod`` would hand back the old object)."""
+    import importlib
+    pkg = sys.modules.get("src.ConStruct.metrics")
+    for mod in ("train_metrics", "abstract_metrics"):
+        sys.modules.pop("src.ConStruct.metrics." + mod, None)
+        if pkg is not None and mod in pkg.__dict__:
+            delattr(pkg, mod)
+    return importlib.import_module("src.ConStruct.metrics.train_metrics")
 
 
 def _spanning_tree_labels(n_nodes, n, C, seed):
@@ -562,9 +589,7 @@ def gen_training(R):
     sys.modules["torchmetrics"].Metric = Metric
     sys.modules["torchmetrics"].MeanSquaredError = Metric
     sys.modules["torchmetrics"].MetricCollection = Metric
-    for mod in ("src.ConStruct.metrics.train_metrics", "src.ConStruct.metrics.abstract_metrics"):
-        sys.modules.pop(mod, None)
-    from src.ConStruct.metrics import train_metrics as TL
+    TL = _fresh_metrics_modules()
     feed = _UniformFeed()
     for name, tr, C, n_nodes, dims, n_layers in (("atm_tiny", "absorbing_edges", 5, [11, 6, 9, 2], fx.TINY_DIMS, 2),
                                                  ("cow_marg_tiny", "marginal", 6, [8, 12, 5], fx.TINY_DIMS, 2)):
@@ -792,9 +817,7 @@ def gen_training_3d(R):
     sys.modules["torchmetrics"].Metric = Metric
     sys.modules["torchmetrics"].MeanSquaredError = MSE
     sys.modules["torchmetrics"].MetricCollection = Metric
-    for mod in ("src.ConStruct.metrics.train_metrics", "src.ConStruct.metrics.abstract_metrics"):
-        sys.modules.pop(mod, None)
-    from src.ConStruct.metrics import train_metrics as TL
+    TL = _fresh_metrics_modules()
     from src.ConStruct.models import pos_transformer_model as P3
     C, n_nodes, dims, n_layers = 5, [11, 6, 9, 2], fx.TINY_DIMS, 2
     mask = fx.ragged_mask(n_nodes)
@@ -838,13 +861,11 @@ def gen_training_3d(R):
     print(f"g10: loss {float(loss.detach()):.6f}, {len(unused)} parameters without gradient")
 
 
-def gen_sit(R):
-    """H1: the reference's SiT-T denoiser of the node-coordinate DDPM (sit_model.py) on ragged batches.  ``timm`` is absent
-    here; sit_model.py takes two things from it: the CONSTRUCTOR of ``Attention`` (the forward is the reference's own
-    ``AttentionWithPads.forward``) and ``Mlp``.  The stand-in below states their published layout -- qkv / proj Linears,
-    head scale, fc1 / activation / fc2 -- and nothing else; every line of arithmetic that runs, apart from Mlp's
-    fc2(act(fc1(x))), is the reference's.  Weights: make_state_dict (NOT the zero adaLN initialisation, which would make
-    every block the identity)."""
+def _timm_stand_in():
+    """``timm`` is absent here; sit_model.py takes two things from it: the CONSTRUCTOR of ``Attention`` (the forward is the
+    reference's own ``AttentionWithPads.forward``) and ``Mlp``.  The stand-in states their published layout -- qkv / proj
+    Linears, head scale, fc1 / activation / fc2 -- and nothing else; every line of arithmetic that runs, apart from Mlp's
+    fc2(act(fc1(x))), is the reference's."""
     import torch.nn as nn
 
     class Attention(nn.Module):
@@ -871,7 +892,15 @@ def gen_sit(R):
     timm.models.vision_transformer = types.ModuleType("timm.models.vision_transformer")
     timm.models.vision_transformer.Attention = Attention
     timm.models.vision_transformer.Mlp = Mlp
-    sys.modules.update({"timm": timm, "timm.models": timm.models, "timm.models.vision_transformer": timm.models.vision_transformer})
+    timm.optim = types.ModuleType("timm.optim")
+    sys.modules.update({"timm": timm, "timm.models": timm.models, "timm.models.vision_transformer": timm.models.vision_transformer,
+                        "timm.optim": timm.optim})
+
+
+def gen_sit(R):
+    """H1: the reference's SiT-T denoiser of the node-coordinate DDPM (sit_model.py) on ragged batches, with the timm
+    stand-in above.  Weights: make_state_dict (NOT the zero adaLN initialisation, which would make every block the identity)."""
+    _timm_stand_in()
     from src.bootstrap.node_coordinate_diffusion import sit_model as SM
     for name, n_nodes, seed in (("a", [9, 5, 2, 12], 501), ("b", [40, 33], 502)):
         torch.manual_seed(seed)
@@ -889,9 +918,76 @@ def gen_sit(R):
              shape_vals=np.array([",".join(map(str, shapes[k])) for k in sorted(shapes)]))
 
 
+def gen_sit_sample(R):
+    """H2: the reference's ancestral sampler itself -- ``NodeCoordsDiffusionModel.sample``
+    (cow_diff_nodes_with_3d_checks.py:63-81 and the identical atm_ twin) run from the REAL module.  Its module-level imports
+    that are absent here and untouched by ``__init__`` / ``sample`` (open3d, timm.optim, torch_geometric.loader / .utils,
+    the dataset class, environment_setup) are stubbed -- ordinary ModuleNotFoundErrors; the SiT network it builds is the
+    reference's with the timm stand-in of gen_sit.  ``torch.randn`` / ``torch.randn_like`` are wrapped for the duration of the
+    call so that every normal draw of the loop is RECORDED (the values are torch's own); the fixture holds x_T, the per-step
+    draws and the result, for a whole short chain (noise_steps = 10: down to i = 1, the step without noise) and for the
+    whole shipped 1000-step schedule on a tiny batch."""
+    _timm_stand_in()
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+    before = dict(sys.modules)
+    stub("open3d")
+    tgl = stub("torch_geometric.loader", DataLoader=object)
+    sys.modules["torch_geometric"].loader = tgl
+    sys.modules["torch_geometric.utils"].to_dense_batch = None
+    stub("src.ConStruct.datasets.cow_dataset", CoWGraphDataset=object)
+    stub("src.ConStruct.datasets.atm_dataset", ATMGraphDataset=object)
+    stub("src.environment_setup", PROJECT_ROOT_DIR="/nonexistent")
+    for ds in ("cow", "atm"):      # import_reference() registered a stand-in for NoiseModel's sake: take it out
+        sys.modules.pop(f"src.bootstrap.node_coordinate_diffusion.{ds}_diff_nodes_with_3d_checks", None)
+    import importlib
+    NC = importlib.import_module("src.bootstrap.node_coordinate_diffusion.cow_diff_nodes_with_3d_checks")
+    real_randn, real_like = torch.randn, torch.randn_like
+    for name, n_nodes, steps, seed in (("short", [9, 5, 12, 1], 10, 701), ("full", [7, 3], 1000, 702)):
+        torch.manual_seed(seed)
+        ncd = NC.NodeCoordsDiffusionModel(noise_steps=steps, device="cpu")
+        shapes = {k: tuple(v.shape) for k, v in ncd.model.state_dict().items()}
+        sd = fx.make_state_dict(shapes, seed=seed)
+        ncd.model.load_state_dict(sd)
+        mask = fx.ragged_mask(n_nodes)
+        B, n = mask.shape
+        draws = []
+
+        def rec_randn(*a, **k):
+            v = real_randn(*a, **k)
+            draws.append(v.clone())
+            return v
+
+        def rec_like(x, *a, **k):
+            v = real_like(x, *a, **k)
+            draws.append(v.clone())
+            return v
+        torch.randn, torch.randn_like = rec_randn, rec_like
+        seen = []                      # the state entering every iteration = the network's input (a pre-forward hook, no edit)
+        hook = ncd.model.register_forward_pre_hook(lambda _m, args: seen.append(args[0].clone()))
+        try:
+            out = ncd.sample(torch.zeros(B, n, 3), mask)
+        finally:
+            torch.randn, torch.randn_like = real_randn, real_like
+            hook.remove()
+        assert len(draws) == steps - 1 and len(seen) == steps - 1, (len(draws), steps)   # x_T + one per iteration with i > 1
+        at = [k for k in (1, 4, 8, 32, 128, 512) if k < steps - 1]
+        save(f"h2_sit_sample_{name}", node_mask=mask, noise_steps=steps, seed=seed, x_T=draws[0], noise=torch.stack(draws[1:]),
+             out=out, after_steps=np.array(at), x_after=torch.stack([seen[k] for k in at]), shape_keys=np.array(sorted(shapes)),
+             shape_vals=np.array([",".join(map(str, shapes[k])) for k in sorted(shapes)]))
+        print(f"h2 {name}: |out| max {float(out.abs().max()):.4f}")
+    for k in [k for k in sys.modules if k not in before]:
+        del sys.modules[k]
+    sys.modules.update(before)
+
+
 def main():
     R = import_reference()
-    extra = {"sit": gen_sit, "training_3d": gen_training_3d, "graph3d": gen_graph3d, "training": gen_training, "extra_large": gen_extra_features_large, "gt_large": gen_graph_transformer_large}
+    extra = {"sit": gen_sit, "sit_sample": gen_sit_sample, "training_3d": gen_training_3d, "graph3d": gen_graph3d, "training": gen_training, "extra_large": gen_extra_features_large, "gt_large": gen_graph_transformer_large}
     if len(sys.argv) == 2 and sys.argv[1] in extra:
         return extra[sys.argv[1]](R)
     if sys.argv[1:] == ["projector"]:
@@ -914,6 +1010,7 @@ def main():
     gen_graph3d(R)
     gen_training_3d(R)
     gen_sit(R)
+    gen_sit_sample(R)
 
 
 if __name__ == "__main__":

@@ -64,6 +64,7 @@ SIGNATURES = {
     "scgg_sit_finalize": (C.c_int, [_vp, _vp]),
     "scgg_sit_workspace_bytes": (_sz, [_vp, _i32, _i32]),
     "scgg_sit_forward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "scgg_philox_normal_rows": (C.c_int, [_vp, _i32, _i32, C.c_uint64, C.c_uint32, C.c_uint32, _vp]),
     "scgg_sit_sample": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, C.c_uint64, C.c_uint32, _vp, _vp, _sz, _vp]),
     "scgg_reverse_step_edges": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                                           C.POINTER(Rng), _vp, _vp, _vp, _vp]),

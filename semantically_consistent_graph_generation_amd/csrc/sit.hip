@@ -315,6 +315,25 @@ struct UpdateArgs {
   uint32_t k0, k1, step, graph_id_base;
 };
 
+// Three standard normals of (node, global graph id, step word): Philox4x32-10 + Box-Muller.  Keyed by the GLOBAL graph id, so
+// a graph's draws do not depend on which shard or batch slot it sits in.
+__device__ __forceinline__ void philox_normal3(uint32_t node, uint32_t graph, uint32_t step, uint32_t k0, uint32_t k1, float (&z)[3]) {
+  uint32_t r[4];
+  philox4x32_10(node, graph, step, 0x51u, k0, k1, r);
+  const float r0 = sqrtf(-2.0f * logf(1.0f - u01(r[0]))), r1 = sqrtf(-2.0f * logf(1.0f - u01(r[2])));
+  const float a0 = 6.283185307179586f * u01(r[1]), a1 = 6.283185307179586f * u01(r[3]);
+  z[0] = r0 * cosf(a0); z[1] = r0 * sinf(a0); z[2] = r1 * cosf(a1);
+}
+
+__global__ __launch_bounds__(256) void philox_normal_rows_kernel(float* out, int rows, int n, uint32_t k0, uint32_t k1, uint32_t step,
+                                                                 uint32_t graph_id_base) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  float z[3];
+  philox_normal3((uint32_t)(row % n), graph_id_base + (uint32_t)(row / n), step, k0, k1, z);
+  out[(size_t)row * 3] = z[0]; out[(size_t)row * 3 + 1] = z[1]; out[(size_t)row * 3 + 2] = z[2];
+}
+
 template <int F4>
 __global__ __launch_bounds__(256) void sit_update_kernel(UpdateArgs a) {
   constexpr int H = 64 * F4;
@@ -360,11 +379,7 @@ __global__ __launch_bounds__(256) void sit_update_kernel(UpdateArgs a) {
   if (a.c_noise != 0.f) {
     if (a.noise != nullptr) { z[0] = a.noise[row * 3]; z[1] = a.noise[row * 3 + 1]; z[2] = a.noise[row * 3 + 2]; }
     else {
-      uint32_t r[4];
-      philox4x32_10((uint32_t)i, a.graph_id_base + (uint32_t)b, a.step, 0x51u, a.k0, a.k1, r);
-      const float r0 = sqrtf(-2.0f * logf(1.0f - u01(r[0]))), r1 = sqrtf(-2.0f * logf(1.0f - u01(r[2])));
-      const float a0 = 6.283185307179586f * u01(r[1]), a1 = 6.283185307179586f * u01(r[3]);
-      z[0] = r0 * cosf(a0); z[1] = r0 * sinf(a0); z[2] = r1 * cosf(a1);
+      philox_normal3((uint32_t)i, a.graph_id_base + (uint32_t)b, a.step, a.k0, a.k1, z);
     }
   }
 #pragma unroll
@@ -739,4 +754,13 @@ extern "C" int scgg_sit_sample(scgg_sit* h, const float* x_T, const uint8_t* nod
   if (hipMemcpyAsync(x_out, cur, xbytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail("copy failed");
   launch_zero_masked_rows(x_out, node_mask, B * n, 3, st);      // padded slots: zero (the caller masks the positions anyway)
   return checkS("sit sample");
+}
+
+extern "C" int scgg_philox_normal_rows(float* out, int32_t B, int32_t n, uint64_t seed, uint32_t graph_id_base, uint32_t step,
+                                       void* stream) {
+  if (!out || B <= 0 || n <= 0) return fail("philox_normal_rows: bad arguments");
+  const int rows = B * n;
+  hipLaunchKernelGGL(philox_normal_rows_kernel, dim3((rows + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), out, rows, n,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), step, graph_id_base);
+  return checkS("philox normal rows");
 }

@@ -7,7 +7,8 @@ here: ``NoiseModel(cfg, node_coord_model=NodeCoordsDiffusionModel(...).sample)``
 The arithmetic runs in libscgg.so (``scgg_sit_forward`` / ``scgg_sit_sample``, csrc/sit.hip); there is no eager fallback.
 The reference's checkpoints (``cow_best_coord_model.pth``) are not in its repository: weights are whatever the caller loads.
 Parity: the network is checked against outputs of the reference's own module (fixtures h1_sit_*, made with a stand-in for
-the two ``timm`` constructors it imports); the sampler loop is restated from its source (parity unpinned for the loop)."""
+the two ``timm`` constructors it imports); the sampler loop against ``NodeCoordsDiffusionModel.sample`` run from the
+reference's real module with its normal draws recorded (fixtures h2_sit_sample_*)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -148,11 +149,12 @@ SiT_models = {"SiT-T": lambda **kw: SiT(num_transformer_blocks=6, hidden_size=19
 class NodeCoordsDiffusionModel:
     """cow_diff_nodes_with_3d_checks.py:22-81 (sampling side): ``.model`` (SiT-T), ``.to_cuda_device``, ``.sample``."""
 
+    takes_rng = True     # sample() accepts (seed, graph_id_base): NoiseModel.sample_limit_dist hands its Philox key on
+
     def __init__(self, noise_steps=1000, beta_start=1e-4, beta_end=0.02, coordinate_size=3, device="cuda"):
         self.model = SiT_models["SiT-T"](in_channels=coordinate_size, noise_steps=noise_steps, beta_start=beta_start,
                                          beta_end=beta_end).to(device)
         self.noise_steps, self.beta_start, self.beta_end, self.device = noise_steps, beta_start, beta_end, device
-        self.seed = 0
 
     def to_cuda_device(self, device):
         if not next(self.model.parameters()).is_cuda:
@@ -161,7 +163,10 @@ class NodeCoordsDiffusionModel:
     def sample(self, pos, node_mask, seed=None, graph_id_base=0):
         """``pos``: standard-normal start coordinates [B,n,3].  The reference ignores the values it is handed and draws
         torch.randn of the same shape again (:66); here the given draw IS x_T (same distribution, and the caller's
-        generator decides it).  The per-step normals come from Philox under ``seed`` (default: a counter per call)."""
+        generator decides it).  The per-step normals come from Philox keyed by (``seed``, ``graph_id_base`` + b, node, i);
+        ``NoiseModel.sample_limit_dist`` passes the chain's own key, so a graph's coordinates depend on its global id only,
+        not on the shard.  Called bare (the reference's signature), the seed is drawn from torch's global generator, which
+        the reference consumes here too: ``torch.manual_seed`` reproduces a run and two calls never share a stream."""
         if seed is None:
-            seed, self.seed = self.seed, self.seed + 1
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)))
         return self.model.sample(pos, node_mask, seed=seed, graph_id_base=graph_id_base)

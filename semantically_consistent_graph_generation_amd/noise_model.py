@@ -26,6 +26,7 @@ from . import _lib
 from .placeholder import PlaceHolder
 
 MAPPING = ("x", "c", "e", "y", "e_small", "e_mid", "e_large")
+POS_START_STEP = 0x70000000      # Philox step word of the start coordinates: no chain or SiT iteration uses it
 
 
 def _cfg_get(cfg, *path, default=None):
@@ -208,9 +209,21 @@ class NoiseModel:
             zr = Rng(seed=zr.seed, step=self.T + 1, graph_id_base=zr.graph_id_base)
             labels, cands = self.sample_edges_from_probs(prob, node_mask, top_k if top_k > 1 else 0, zr)
         t_int = torch.full((B, 1), self.T, dtype=torch.long, device=dev)
-        pos = torch.randn(B, n, 3, device=dev, generator=generator)
+        # Start coordinates (:313-325).  With ``rng`` they are Philox normals keyed by (seed, GLOBAL graph id, node): graph g
+        # starts from the same point whatever shard or batch slot samples it (sharding.py's invariant), and the coordinate
+        # model's per-step normals are keyed the same way.  Without ``rng``: torch.randn from ``generator`` / the global one.
+        if rng is not None:
+            pos = torch.empty(B, n, 3, device=dev)
+            _lib.check(_lib.lib().scgg_philox_normal_rows(_lib.ptr(pos), B, n, rng.seed, rng.graph_id_base, POS_START_STEP,
+                                                          _lib.stream_ptr()), "philox_normal_rows")
+        else:
+            pos = torch.randn(B, n, 3, device=dev, generator=generator)
         if self.node_coord_model is not None:      # reference :323-325: node_coord_model.sample(pos=start_pos_shape, node_mask=...)
-            pos = getattr(self.node_coord_model, "sample", self.node_coord_model)(pos, node_mask)
+            sample = getattr(self.node_coord_model, "sample", self.node_coord_model)
+            if rng is not None and getattr(self.node_coord_model, "takes_rng", False):
+                pos = sample(pos, node_mask, seed=rng.seed, graph_id_base=rng.graph_id_base)
+            else:
+                pos = sample(pos, node_mask)
         raw = pos * node_mask[..., None]
         radius = torch.zeros(B, n, n, 1, device=dev)
         ph = self._to_placeholder(labels, cands, node_mask, t_int, self.pos_after_masks(raw, node_mask, 1), B, radius,

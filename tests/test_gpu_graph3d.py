@@ -219,8 +219,8 @@ def test_chain_with_3d_denoiser_matches_cpu_oracle_bit_exactly():
     labels, cands, mask, pos_end = sampler.sample_batch(n_nodes, seed=seed, graph_id_base=base, return_state=True)
     radius = sampler.last_radius
     torch.cuda.synchronize()
-    gen = torch.Generator(device="cuda").manual_seed(seed)
-    raw = nm.sample_limit_dist(mask, generator=gen, with_onehot=False)._pos_raw.cpu()
+    from semantically_consistent_graph_generation_amd.noise_model import Rng
+    raw = nm.sample_limit_dist(mask, with_onehot=False, rng=Rng(seed=seed, graph_id_base=base))._pos_raw.cpu()
     m = fx.ragged_mask(n_nodes)
     B, n = m.shape
     live = (m[:, :, None] & m[:, None, :]) & ~torch.eye(n, dtype=torch.bool)[None]

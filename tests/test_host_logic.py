@@ -260,3 +260,25 @@ def test_graph3d_state_dict_layout_matches_reference(name, dims, eq):
         m(SimpleNamespace(X=T(g["X"]), E=T(g["E"]), y=T(g["y"]), pos=T(g["pos"]), node_mask=T(g["node_mask"]), radius=None))
     with pytest.raises(_lib.ScggError):
         cls(2, fx.dims_ns(1, 5, 1), dims["hidden_mlp_dims"], dims["hidden_dims"], fx.dims_ns(1, 5, 2))   # no mlp_out_y
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference only exists in the build container")
+def test_golden_recipe_leaves_no_stand_ins_behind():
+    """``python -m oracle.gen_golden`` crashed half way because gen_sample_plan left its stand-in modules in
+    sys.modules.  Runs that generator in a child process (output to a scratch directory) and checks that the modules it
+    shadowed are gone afterwards and that the real position-aware model still imports."""
+    import subprocess, sys, tempfile
+    code = ("import sys\n"
+            "from oracle import gen_golden as G\n"
+            "R = G.import_reference()\n"
+            "G.gen_sample_plan(R)\n"
+            "for k in ('pytorch_lightning', 'src.ConStruct.models.pos_transformer_model', 'src.ConStruct.metrics.train_metrics',\n"
+            "          'src.ConStruct.diffusion_model_discrete_3d', 'torch_geometric.loader'):\n"
+            "    assert k not in sys.modules, k\n"
+            "from src.ConStruct.models import pos_transformer_model as P3\n"
+            "assert hasattr(P3, 'NodeEdgeBlock') and hasattr(P3, 'Graph3DTransformer')\n")
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ, SCGG_GOLDEN_OUT=d)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]

@@ -327,3 +327,25 @@ def test_sit_forward(name):
     out = S.sit_forward(sd, T(g["x"]), T(g["t"]), m)
     # padded query rows attend uniformly over every slot in the reference (all their scores are -1e9); they are compared too
     close(out, g["out"], 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("name", ["h2_sit_sample_short", "h2_sit_sample_full"])
+def test_sit_sampler_loop_matches_reference(name):
+    """The ancestral loop (cow_diff_nodes_with_3d_checks.py:63-81) recorded from the REAL NodeCoordsDiffusionModel.sample with
+    its normal draws (oracle/gen_golden.py:gen_sit_sample): the oracle's restatement under the same draws, at the recorded
+    intermediate states and at the end of the chain (short: 9 iterations down to i = 1; full: the shipped 999)."""
+    from oracle import sit as S
+    g = load_golden(name)
+    sd = fx.make_state_dict(golden_shapes(g), seed=int(g["seed"]))
+    m, xT, nz, ns = T(g["node_mask"]), T(g["x_T"]), T(g["noise"]), int(g["noise_steps"])
+    assert nz.shape[0] == ns - 2
+
+    def rel_err(a, b):
+        return float((a - b).abs().max() / b.abs().max())
+    for k, want in zip(g["after_steps"], g["x_after"]):
+        if name.endswith("full") and int(k) > 32:
+            continue                                          # keep the CPU suite short: the end of the chain covers them
+        got = S.sample(sd, xT, m, nz, steps=int(k), noise_steps=ns)
+        assert rel_err(got, T(want)) < 1e-5
+    if name.endswith("short"):
+        assert rel_err(S.sample(sd, xT, m, nz, noise_steps=ns), T(g["out"])) < 1e-5
