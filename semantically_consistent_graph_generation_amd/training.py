@@ -336,20 +336,36 @@ def training_step(model, noise_model, extra_features, dense_data, true_E_labels,
     X = torch.cat((z_t.X, z_t.charges, extra.X), dim=2).float()
     E = torch.cat((z_t.E, extra.E), dim=3).float()
     y = torch.hstack((z_t.y, extra.y, z_t.t)).float()
-    pred = train_forward(model, X, E, y, z_t.node_mask, seed=dropout_seed)
     true_X = dense_data.X.argmax(dim=-1)
-    loss = loss_fn(pred, true_X, true_E_labels, z_t.node_mask)
+    if hasattr(model, "mlp_in_pos_high_dim"):      # Graph3DTransformer / EquivariantGraph3DTransformer: the classes the
+        # reference's driver builds (diffusion_model_discrete_3d.py:111-132); their loss carries the radius term (:223)
+        true_radius = getattr(dense_data, "radius", None)
+        pred = train_forward_3d(model, X, E, y, z_t.pos, z_t.node_mask, with_radius=true_radius is not None, seed=dropout_seed)
+        loss = loss_fn(pred, true_X, true_E_labels, z_t.node_mask, true_radius=true_radius)
+    else:
+        pred = train_forward(model, X, E, y, z_t.node_mask, seed=dropout_seed)
+        loss = loss_fn(pred, true_X, true_E_labels, z_t.node_mask)
     return loss, pred, z_t
 
 
 # ------------------------------------------------------------------------------------------------- data-parallel gradients
 class GradientBuckets:
     """Average the gradients of ``params`` over the ranks of ``group``: parameters in reverse registration order (the order
-    backward produces them) are packed into flat buckets of about ``bucket_mb`` and every bucket is one ``all_reduce``
+    backward produces them) are laid out in flat buckets of about ``bucket_mb`` and every bucket is one ``all_reduce``
     (RCCL over xGMI on the GPUs; the ring is per-link bound, so few large messages -- the default bucket holds the whole
-    4.6 M-parameter ConStruct model, 18 MB).  Parameters without a gradient on this rank contribute zeros (the reference runs
-    DDP with find_unused_parameters: the last layer's y modules have none).  ``hook=True`` starts a bucket's all_reduce from
-    the autograd hook of its last parameter, overlapped with the rest of backward; ``finish()`` waits and unpacks."""
+    4.6 M-parameter ConStruct model, 18 MB).
+
+    The flat buffers are PERSISTENT and every ``p.grad`` is a view into its bucket (``attach()``, done lazily): backward
+    accumulates straight into the buffer, the all_reduce runs in place, nothing is packed or unpacked per step.  Use
+    ``zero_grad()`` of this object (or ``optimizer.zero_grad(set_to_none=False)``) between steps; a ``set_to_none`` clears
+    the views and they are re-attached (with one copy) on the next ``finish()``.
+
+    Parameters that receive no gradient on ANY rank (the reference runs DDP with find_unused_parameters: ``pre_softmax``,
+    the last layer's y modules, ...) keep ``grad = None`` after ``finish()``, as under the reference's DDP, so AdamW gives them
+    neither weight decay nor state: a per-parameter "touched" flag is reduced with the last bucket.  ``hook=True`` starts a
+    bucket's all_reduce from the autograd hook of its last-arriving parameter, overlapped with the rest of backward;
+    buckets are always LAUNCHED in index order (a bucket whose turn has not come waits for its predecessors), so every rank
+    issues the same sequence of collectives even if their sets of unused parameters differ."""
 
     def __init__(self, params, group=None, bucket_mb=25.0, hook=False):
         import torch.distributed as dist
@@ -365,46 +381,95 @@ class GradientBuckets:
         if cur:
             self.buckets.append(cur)
         self._flat = [None] * len(self.buckets)
+        self._views = [None] * len(self.buckets)
         self._work = [None] * len(self.buckets)
-        self._pending = None
-        if hook:
-            self._pending = [len(b) for b in self.buckets]
-            for bi, b in enumerate(self.buckets):
-                for p in b:
-                    p.register_post_accumulate_grad_hook(lambda _p, bi=bi: self._ready(bi))
+        self._launched = [False] * len(self.buckets)
+        self._pending = [len(b) for b in self.buckets]
+        self._touched = None                     # [n_params] flags, reduced with MAX behind the last bucket
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._where = {id(p): (bi, k) for bi, b in enumerate(self.buckets) for k, p in enumerate(b)}
+        self._seen = set()                       # parameters whose gradient arrived in this backward
+        self._hook, self._finishing = bool(hook), False
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._arrived)
 
     def world(self):
         return self.dist.get_world_size(self.group) if self.dist.is_initialized() else 1
 
-    def _launch(self, bi):
-        b = self.buckets[bi]
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in b])
-        self._flat[bi] = flat
-        if self.world() > 1:
-            self._work[bi] = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
-
-    def _ready(self, bi):
-        self._pending[bi] -= 1
-        if self._pending[bi] == 0:
-            self._launch(bi)
-
-    def finish(self):
-        """Call after ``loss.backward()``: launches what the hooks have not, waits, writes the averaged gradients back."""
-        w = self.world()
+    def attach(self):
+        """Allocate the flat buffers (once) and make every existing ``p.grad`` a view into them."""
         for bi, b in enumerate(self.buckets):
             if self._flat[bi] is None:
-                self._launch(bi)
+                self._flat[bi] = torch.zeros(sum(p.numel() for p in b), device=b[0].device)
+                off, views = 0, []
+                for p in b:
+                    views.append(self._flat[bi][off: off + p.numel()].view_as(p))
+                    off += p.numel()
+                self._views[bi] = views
+            for p, v in zip(b, self._views[bi]):
+                if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+                    p.grad = v
+        if self._touched is None:
+            self._touched = torch.zeros(len(self.params), device=self.params[0].device)
+
+    def zero_grad(self):
+        """Zero the buffers and point every parameter's ``grad`` at its view: backward then accumulates in place."""
+        self.attach()
         for bi, b in enumerate(self.buckets):
+            self._flat[bi].zero_()
+            for p, v in zip(b, self._views[bi]):
+                p.grad = v
+        self._seen.clear()
+
+    def _launch_in_order(self):
+        for bi in range(len(self.buckets)):
+            if self._launched[bi]:
+                continue
+            if self._pending[bi] > 0 and not self._finishing:
+                return
+            self._launched[bi] = True
+            if self.world() > 1:
+                self._work[bi] = self.dist.all_reduce(self._flat[bi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _arrived(self, p):
+        self._seen.add(id(p))
+        bi, k = self._where[id(p)]
+        if not self._hook or self._flat[bi] is None or p.grad.data_ptr() != self._views[bi][k].data_ptr():
+            return                   # not overlapping, or not attached yet (first step / after set_to_none): finish() does it
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch_in_order()
+
+    def finish(self):
+        """Call after ``loss.backward()``: attaches / launches what the hooks have not, waits, scales by 1 / world, and
+        leaves ``grad = None`` on the parameters no rank produced a gradient for."""
+        w = self.world()
+        had = [id(p) in self._seen for p in self.params]
+        self.attach()
+        for bi, b in enumerate(self.buckets):          # no gradient on this rank: zeros in the sum
+            for p, v in zip(b, self._views[bi]):
+                if p.grad is None:
+                    v.zero_()
+        self._touched.copy_(torch.tensor([1.0 if h else 0.0 for h in had]))
+        self._finishing = True
+        self._launch_in_order()
+        self._finishing = False
+        twork = None
+        if w > 1:
+            twork = self.dist.all_reduce(self._touched, op=self.dist.ReduceOp.MAX, group=self.group, async_op=True)
+        for bi in range(len(self.buckets)):
             if self._work[bi] is not None:
                 self._work[bi].wait()
-            flat, off = self._flat[bi] / w, 0
-            for p in b:
-                g = flat[off: off + p.numel()].view_as(p)
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
-                off += p.numel()
-            self._flat[bi] = self._work[bi] = None
-        if self._pending is not None:
-            self._pending = [len(b) for b in self.buckets]
+            if w > 1:
+                self._flat[bi].div_(w)
+        if twork is not None:
+            twork.wait()
+        touched = self._touched.cpu().tolist()
+        for bi, b in enumerate(self.buckets):
+            for p, v in zip(b, self._views[bi]):
+                p.grad = v if touched[self._index[id(p)]] > 0 else None
+            self._work[bi] = None
+            self._launched[bi] = False
+        self._pending = [len(b) for b in self.buckets]
+        self._seen.clear()

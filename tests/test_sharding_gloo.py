@@ -139,7 +139,16 @@ def _ddp_worker(rank, world, port, out):
         sl = slice(rank * 4, rank * 4 + 4)                           # this rank's half of the global batch
         ((net(X[sl]) - Y[sl]) ** 2).mean().backward()
         gb.finish()
-        out[(rank, hook)] = [p.grad.clone() for p in params]
+        out[(rank, hook, 0)] = [(p.grad.clone() if p.grad is not None else None) for p in params]
+        # second step on the persistent buffers: grads are views, backward accumulates in place, nothing is re-packed
+        gb.zero_grad()
+        ptrs = [p.grad.data_ptr() for p in params]
+        ((net(X[sl]) - Y[sl]) ** 2).mean().backward()
+        assert [p.grad.data_ptr() for p in params] == ptrs
+        gb.finish()
+        out[(rank, hook, 1)] = [(p.grad.clone() if p.grad is not None else None) for p in params]
+        w0 = params[0]
+        assert any(f.data_ptr() <= w0.grad.data_ptr() < f.data_ptr() + f.numel() * 4 for f in gb._flat)
     if rank == 0:
         for p in params:
             p.grad = None
@@ -150,7 +159,8 @@ def _ddp_worker(rank, world, port, out):
 
 def test_gradient_buckets_average_equals_single_process_gradient():
     """World size 2 on gloo: the bucketed all-reduce of two half batches == the gradient of the whole batch in one process
-    (mean loss, equal shard sizes), with and without the backward hooks; parameters without a gradient come back as zeros."""
+    (mean loss, equal shard sizes), with and without the backward hooks, on the first step (gradients packed once) and on a
+    second one (gradients are views into the persistent flat buffers); parameters without a gradient on any rank keep None."""
     import torch
     import torch.multiprocessing as mp
     port = _free_port()
@@ -159,6 +169,9 @@ def test_gradient_buckets_average_equals_single_process_gradient():
         mp.spawn(_ddp_worker, args=(2, port, out), nprocs=2, join=True)
         full = out["full"]
         for hook in (False, True):
-            for r in range(2):
-                for a, b in zip(out[(r, hook)], full):
-                    torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+            for step in (0, 1):
+                for r in range(2):
+                    got = out[(r, hook, step)]
+                    for a, b in zip(got[:-2], full[:-2]):
+                        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+                    assert got[-1] is None and got[-2] is None      # unused on every rank: grad stays None (as under DDP)
