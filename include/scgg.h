@@ -333,8 +333,8 @@ int64_t scgg_projector_counter(const scgg_projector* p);
  *
  * scgg_dropout replaces nn.Dropout at the reference's dropout sites (transformer_model.py:88-105 layers, :284-340 in /
  * out MLPs).  The reference draws from torch's global generator; here the mask of `site` is a pure function of
- * (seed, site, flat index): Philox4x32-10, counter (index low, index high, site, 0xD0), key = seed, kept iff
- * u >= (float)p, out = x / (float)(1 - p) (p is a double so that 1 - p rounds as the reference's Python float does).  The backward pass calls it again on the incoming gradient (same seed and site).
+ * (seed, site, flat index): Philox4x32-10, counter ((index >> 2) low, (index >> 2) high, site, 0xD0), key = seed, output
+ * word (index & 3), kept iff u >= (float)p, out = x / (float)(1 - p) (p is a double so that 1 - p rounds as the reference's Python float does).  The backward pass calls it again on the incoming gradient (same seed and site).
  * x == out is allowed.
  *
  * scgg_masked_cross_entropy replaces CrossEntropyMetric (src/ConStruct/metrics/abstract_metrics.py:77-93) inside
@@ -348,6 +348,44 @@ int scgg_dropout(const float* x, float* out, int64_t numel, double p, uint64_t s
 int64_t scgg_masked_cross_entropy_blocks(int64_t rows);
 int scgg_masked_cross_entropy(const float* logits, const int8_t* target, int64_t rows, int32_t C, float* partial,
                               float* grad, const float* grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Training step, edge path of one XEyTransformerLayer as fused kernels with a hand-written backward (row a11):
+ * replaces, for one layer, NodeEdgeBlock.forward's E part + attention (transformer_model.py:165-227) and the layer's E
+ * path with its three dropout sites (:94-98), together with what autograd does for them in training_step
+ * (diffusion_model_discrete_3d.py:215-239).  Nothing of size [B,n,n,dx] is kept between forward and backward: the
+ * backward recomputes the chain per 16-key unit from the layer's inputs and the saved (lse, wV).
+ *
+ * All tensors fp32, contiguous.  E [B,n,n,de] (the layer's input: symmetric, masked); Q / K / V [B,n,dx] (masked rows);
+ * yea / yem1 [B,dx] = y_e_add(y), y_e_mul(y) + 1; mask [B,n].  F_*: fragment images of the weights from
+ * scgg_train_edge_pack (transpose = 0), F_*T of their transposes (transpose = 1; backward only).  Dropout: p, seed =
+ * (k1 << 32 | k0), sites of newE / the FFN's hidden layer / its output (the stream of scgg_dropout); p = 0: none.
+ * forward:  E_out [B,n,n,de] (zero-filled by the caller; written on pairs of valid nodes, NOT yet symmetrised or masked),
+ *           part [B*n*nch, 3, dx] (scratch), wV_out / lse_out [B,n,dx] (attention output, log-sum-exp per channel).
+ * backward: dOut = dL/dE_out, dwV = dL/dwV, wV / lse from the forward -> dE [B,n,n,de] and, per DENSE pair slot
+ *           s = ((b n + i) nch + jc) 16 + (j & 15) (all slots written, zeros on non-pairs), the factors of the weight
+ *           gradients: G_e [S,de], G_da [S,2dx] (d e_mul out | d e_add out), G_z [S,dx] (input of e_out), G_dnewE [S,de],
+ *           G_h1 [S,de] (input of linE1), G_df [S,ffe], G_f [S,ffe] (input of linE2), G_do [S,de], G_dkv [S,2dx] (summands
+ *           of dK | dV over i), upart [B*n*nch, 2dx + 4de] = dQ row partial (before 1/sqrt(df)) | sum dz*Y (d yem1) |
+ *           d gamma2 | d beta2 | d gamma1 | d beta1.  The caller forms dW = G_g^T G_x (one GEMM each) and the sums.
+ * Built for (de, dim_ffE) = (32, 64) and (64, 128), dx a multiple of 16.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct scgg_train_edge_args {
+  const float *E, *Q, *K, *V, *yea, *yem1;
+  const uint8_t* mask;
+  const float *F_mul, *F_add, *F_out, *F_ff1, *F_ff2;
+  const float *F_mulT, *F_addT, *F_outT, *F_ff1T, *F_ff2T;
+  const float *b_mul, *b_add, *b_out, *g1, *b1, *b_ff1, *b_ff2, *g2, *b2;
+  float *E_out, *part, *wV_out, *lse_out;
+  const float *dOut, *dwV, *wV, *lse;
+  float *dE, *G_e, *G_da, *G_z, *G_dnewE, *G_h1, *G_df, *G_f, *G_do, *G_dkv, *upart;
+  int32_t B, n, nch, dx, de, ffe;
+  float inv_sqrt_df, p;
+  uint32_t k0, k1, site1, site2, site3;
+} scgg_train_edge_args;
+int scgg_train_edge_pack(const float* W, int32_t rows, int32_t cols, int32_t transpose, float* out, void* stream);
+int scgg_train_edge_forward(const scgg_train_edge_args* a, void* stream);
+int scgg_train_edge_backward(const scgg_train_edge_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Stress configuration (BASELINE.json configs[4]): NodeEdgeBlock.forward (transformer_model.py:165-248, without the y

@@ -11,7 +11,7 @@ Follows /root/reference/src/ConStruct
 
 Dropout.  The reference draws its masks from torch's global RNG; a bit-exact comparison needs an explicit stream, so the
 mask of dropout site ``s`` is a deterministic function of (seed, site, flat element index): Philox4x32-10 with counter
-(index low, index high, site, 0xD0) and key = seed, element kept iff u >= p, scaled by 1/(1-p) -- the same function the
+((index >> 2) low, (index >> 2) high, site, 0xD0), key = seed and output word (index & 3), element kept iff u >= p, scaled by 1/(1-p) -- the same function the
 HIP kernel evaluates (csrc/train_kernels.hip).  Sites are numbered in call order (``dropout_sites``).
 """
 from __future__ import annotations
@@ -55,16 +55,17 @@ def train_loss(pred_X, pred_E, true_X, true_E, node_mask, lambda_train=(1.0, 2.0
 
 # ---------------------------------------------------------------------------------------------- dropout stream
 def dropout_keep(seed: int, site: int, numel: int, p: float) -> np.ndarray:
-    """keep[numel] bool of dropout site ``site``: Philox4x32-10, counter (idx & 2^32-1, idx >> 32, site, 0xD0), key = seed,
-    word 0 -> u in [0,1) from the top 24 bits, kept iff u >= p."""
-    idx = np.arange(numel, dtype=np.uint64)
-    ctr = np.zeros((numel, 4), dtype=np.uint32)
+    """keep[numel] bool of dropout site ``site``: Philox4x32-10, counter ((idx >> 2) & 2^32-1, idx >> 34, site, 0xD0), key =
+    seed, word (idx & 3) -> u in [0,1) from the top 24 bits, kept iff u >= p (four consecutive elements share one call)."""
+    calls = (numel + 3) // 4
+    idx = np.arange(calls, dtype=np.uint64)
+    ctr = np.zeros((calls, 4), dtype=np.uint32)
     ctr[:, 0] = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     ctr[:, 1] = (idx >> np.uint64(32)).astype(np.uint32)
     ctr[:, 2] = np.uint32(site)
     ctr[:, 3] = np.uint32(0xD0)
     key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
-    u = N.u01(N.philox4x32_10(ctr, key)[:, 0])
+    u = N.u01(N.philox4x32_10(ctr, key)).reshape(-1)[:numel]
     return u >= np.float32(p)
 
 

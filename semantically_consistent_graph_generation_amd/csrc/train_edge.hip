@@ -1,0 +1,528 @@
+// Training step, edge path of one XEy layer as fused kernels with a hand-written backward (gfx950, fp32 on
+// v_mfma_f32_16x16x4_f32).  SURVEY.md row a11.
+//
+//   NodeEdgeBlock (E part + attention)  src/ConStruct/models/transformer_model.py:165-227
+//   XEyTransformerLayer E path          transformer_model.py:94-98 (dropout sites E1, E2-inner, E2-outer)
+//   the step they are part of           src/ConStruct/diffusion_model_discrete_3d.py:215-239
+//
+// What the reference's autograd keeps per layer -- about ten [B,n,n,dx] tensors -- is never materialised here: the forward
+// keeps the layer's INPUTS (E, Q, K, V, the two FiLM vectors) plus per (row, channel) the log-sum-exp of the attention
+// softmax and the attention output, and the backward kernel recomputes the chain per 16-key unit in registers.
+//
+// Layout ("C16", as the inference kernels): work unit = (query row (b,i), chunk of 16 keys); one wave per unit; key j on
+// lane & 15, channel group g = lane >> 4; a 16-channel block of activations is one f32x4 whose register r holds channel
+// 4g + r -- how v_mfma_f32_16x16x4_f32 leaves its result and takes its B operand.  A Linear is out^T = W . in^T with W as
+// the A operand; the data gradient of a Linear is the same product with W^T, so the backward needs fragment images of W
+// and of W^T (train_edge_pack_kernel: float4 ((rb CB + cb) 64 + l) = M[16 rb + (l & 15)][16 cb + 4 (l >> 4) + 0..3]).
+// Weight fragments are read from global memory (the images of a layer, 160-256 KB, stay in the L2s).
+//
+// Forward per valid pair (i, j), vectors over channels (e = E[b,i,j,:]):
+//   a1 = W_mul e + b_mul + 1      a2 = W_add e + b_add      y0 = (Q_i / sqrt(df)) (.) K_j      Y = y0 (.) a1 + a2
+//   z = yea + yem1 (.) Y          newE = W_out z + b_out     attention: p = exp(Y - lse_i), wV_i = sum_j p (.) V_j
+//   r1 = e + drop1(newE)   h1 = LN1(r1)   f = drop2(relu(W_1 h1 + b_1))   r2 = h1 + drop3(W_2 f + b_2)   out = LN2(r2)
+// Backward: see train_edge_bwd_kernel.  Weight gradients are sums over all pairs of outer products g (x) x, i.e. GEMMs
+// with the PAIR as the reduction index; in C16 layout the pair sits on the MFMA's free index, so the kernel writes the
+// factors ("G tensors", [pairs, width]) and the host forms G^T X with the GEMM library (training.py) -- stated plainly:
+// that part is a library GEMM on tensors this kernel emits, everything per pair is in the kernel.
+//
+// Dropout: the mask of site s is Philox4x32-10 of (flat element index >> 2, site) with the element's word (index & 3),
+// the definition of train_kernels.hip / oracle/training.py:dropout_keep; a lane's f32x4 is one Philox call.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/scgg.h"
+#include "c16.h"
+#include "kernels.h"
+#include "rng.h"
+
+namespace scgg {
+namespace {
+
+typedef scgg_train_edge_args TArgs;
+
+__device__ __forceinline__ void mfma4(f32x4& acc, const f32x4& w, const f32x4& x) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], x[r], acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 frag(const float* img, int idx, int lane) {
+  return reinterpret_cast<const f32x4*>(img)[(size_t)idx * 64 + lane];
+}
+
+// dropout of four consecutive elements starting at flat index idx (a multiple of 4): keep iff u >= p, scale 1 / (1 - p)
+__device__ __forceinline__ void drop4(f32x4& v, unsigned long long idx, uint32_t site, float p, float denom, uint32_t k0, uint32_t k1) {
+  const unsigned long long c = idx >> 2;
+  uint32_t r[4];
+  philox4x32_10((uint32_t)(c & 0xffffffffull), (uint32_t)(c >> 32), site, 0xD0u, k0, k1, r);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = u01(r[e]) >= p ? v[e] / denom : 0.f;
+}
+
+// LayerNorm forward over IBE*16 channels in C16 layout, keeping what the backward needs: xh = (x - mean) rstd, out = xh g + b
+template <int IBE>
+__device__ __forceinline__ float ln_fwd(const f32x4 (&x)[IBE], f32x4 (&xh)[IBE], f32x4 (&out)[IBE], const float* gamma,
+                                        const float* beta, int g) {
+  float s = 0.f;
+#pragma unroll
+  for (int b = 0; b < IBE; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s += x[b][r];
+  const float mean = groups_sum(s) * (1.0f / (16 * IBE));
+  float q = 0.f;
+#pragma unroll
+  for (int b = 0; b < IBE; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float d = x[b][r] - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(groups_sum(q) * (1.0f / (16 * IBE)) + 1e-5f);
+#pragma unroll
+  for (int b = 0; b < IBE; ++b) {
+    const f32x4 gm = ld4(gamma + 16 * b + 4 * g), bt = ld4(beta + 16 * b + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { xh[b][r] = (x[b][r] - mean) * rstd; out[b][r] = xh[b][r] * gm[r] + bt[r]; }
+  }
+  return rstd;
+}
+// LayerNorm backward: dy -> dx = rstd (dxh - mean(dxh) - xh mean(dxh xh)), dxh = dy g
+template <int IBE>
+__device__ __forceinline__ void ln_bwd(const f32x4 (&dy)[IBE], const f32x4 (&xh)[IBE], float rstd, const float* gamma, int g,
+                                       f32x4 (&dx)[IBE]) {
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int b = 0; b < IBE; ++b) {
+    const f32x4 gm = ld4(gamma + 16 * b + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { dx[b][r] = dy[b][r] * gm[r]; s1 += dx[b][r]; s2 += dx[b][r] * xh[b][r]; }
+  }
+  const float m1 = groups_sum(s1) * (1.0f / (16 * IBE)), m2 = groups_sum(s2) * (1.0f / (16 * IBE));
+#pragma unroll
+  for (int b = 0; b < IBE; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dx[b][r] = rstd * (dx[b][r] - m1 - xh[b][r] * m2);
+}
+
+struct UnitId {
+  long long unit;
+  int row, b, i, j, jj;
+  bool inb, vi, vj, any;
+};
+__device__ __forceinline__ UnitId unit_id(const TArgs& a, int lane) {
+  UnitId u;
+  u.unit = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  u.row = (int)(u.unit / a.nch);
+  const int jc = (int)(u.unit - (long long)u.row * a.nch);
+  u.b = u.row / a.n;
+  u.i = u.row - u.b * a.n;
+  u.j = jc * 16 + (lane & 15);
+  u.inb = u.j < a.n;
+  u.jj = u.inb ? u.j : 0;
+  u.vi = a.mask[u.row] != 0;
+  u.vj = u.vi && u.inb && a.mask[u.b * a.n + u.jj] != 0;
+  u.any = __any(u.vj);
+  return u;
+}
+
+// the first half of the chain: newE = W_out (yea + yem1 (.) Y) + b_out over all dx blocks (accO), optionally the softmax
+// partials of the unit (FWD) -- shared by the forward kernel and the backward's recomputation
+template <int IBE, bool FWD>
+__device__ __forceinline__ void attention_half(const TArgs& a, const UnitId& u, const f32x4 (&e)[IBE], f32x4 (&accO)[IBE], int lane) {
+  const int p = lane & 15, g = lane >> 4, DX = a.dx, XB = DX / 16;
+  const float* qrow = a.Q + (long long)u.row * DX;
+  const float* krow = a.K + ((long long)u.b * a.n + u.jj) * DX;
+  const float* vrow = a.V + ((long long)u.b * a.n + u.jj) * DX;
+  const float* yea = a.yea + (long long)u.b * DX;
+  const float* yem = a.yem1 + (long long)u.b * DX;
+  float* part = FWD ? a.part + u.unit * 3 * DX : nullptr;
+#pragma unroll
+  for (int ob = 0; ob < IBE; ++ob) accO[ob] = ld4(a.b_out + 16 * ob + 4 * g);
+#pragma unroll 1
+  for (int xb = 0; xb < XB; ++xb) {
+    const int co = 16 * xb + 4 * g;
+    f32x4 a1 = ld4(a.b_mul + co) + splat4(1.0f), a2 = ld4(a.b_add + co);
+#pragma unroll
+    for (int ib = 0; ib < IBE; ++ib) {
+      mfma4(a1, frag(a.F_mul, xb * IBE + ib, lane), e[ib]);
+      mfma4(a2, frag(a.F_add, xb * IBE + ib, lane), e[ib]);
+    }
+    const f32x4 q = ld4(qrow + co) * a.inv_sqrt_df;
+    const f32x4 k = u.vj ? ld4(krow + co) : splat4(0.f);
+    const f32x4 ya = ld4(yea + co), ym = ld4(yem + co);
+    f32x4 yy, z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { yy[r] = (q[r] * k[r]) * a1[r] + a2[r]; z[r] = ya[r] + ym[r] * yy[r]; }
+#pragma unroll
+    for (int ob = 0; ob < IBE; ++ob) mfma4(accO[ob], frag(a.F_out, ob * XB + xb, lane), z);
+    if (FWD) {
+      const f32x4 v = u.vj ? ld4(vrow + co) : splat4(0.f);
+      f32x4 cm, cs, ca;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float y = u.vj ? yy[r] : -INFINITY;
+        cm[r] = row_max16(y);
+        const float pe = u.vj ? __expf(y - cm[r]) : 0.f;
+        cs[r] = row_sum16(pe);
+        ca[r] = row_sum16(pe * v[r]);
+      }
+      if (p == 0) {
+        *reinterpret_cast<f32x4*>(part + co) = cm;
+        *reinterpret_cast<f32x4*>(part + DX + co) = cs;
+        *reinterpret_cast<f32x4*>(part + 2 * DX + co) = ca;
+      }
+    }
+  }
+}
+
+// the second half: r1 = e + drop1(newE), LN1, FFN with its two dropouts, r2, LN2.  Leaves everything the backward needs.
+template <int IBE, int IBF>
+struct Tail {
+  f32x4 xh1[IBE], h1[IBE], xh2[IBE], out[IBE], hid[IBF];
+  float rstd1, rstd2;
+};
+template <int IBE, int IBF>
+__device__ __forceinline__ void tail_fwd(const TArgs& a, const UnitId& u, const f32x4 (&e)[IBE], const f32x4 (&newE)[IBE],
+                                         Tail<IBE, IBF>& t, int lane) {
+  constexpr int DE = 16 * IBE, FFE = 16 * IBF;
+  const int g = lane >> 4;
+  const bool drop = a.p > 0.f;
+  const float denom = 1.0f - a.p;
+  const unsigned long long pair = (unsigned long long)u.row * a.n + u.jj;
+  f32x4 r1[IBE];
+#pragma unroll
+  for (int eb = 0; eb < IBE; ++eb) {
+    f32x4 d = newE[eb];
+    if (drop) drop4(d, pair * DE + 16 * eb + 4 * g, a.site1, a.p, denom, a.k0, a.k1);
+    r1[eb] = e[eb] + d;
+  }
+  t.rstd1 = ln_fwd<IBE>(r1, t.xh1, t.h1, a.g1, a.b1, g);
+  f32x4 o[IBE];
+#pragma unroll
+  for (int ob = 0; ob < IBE; ++ob) o[ob] = ld4(a.b_ff2 + 16 * ob + 4 * g);
+#pragma unroll
+  for (int fb = 0; fb < IBF; ++fb) {
+    f32x4 h = ld4(a.b_ff1 + 16 * fb + 4 * g);
+#pragma unroll
+    for (int ib = 0; ib < IBE; ++ib) mfma4(h, frag(a.F_ff1, fb * IBE + ib, lane), t.h1[ib]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = fmaxf(h[r], 0.f);
+    if (drop) drop4(h, pair * FFE + 16 * fb + 4 * g, a.site2, a.p, denom, a.k0, a.k1);
+    t.hid[fb] = h;
+#pragma unroll
+    for (int ob = 0; ob < IBE; ++ob) mfma4(o[ob], frag(a.F_ff2, ob * IBF + fb, lane), h);
+  }
+  f32x4 r2[IBE];
+#pragma unroll
+  for (int eb = 0; eb < IBE; ++eb) {
+    if (drop) drop4(o[eb], pair * DE + 16 * eb + 4 * g, a.site3, a.p, denom, a.k0, a.k1);
+    r2[eb] = t.h1[eb] + o[eb];
+  }
+  t.rstd2 = ln_fwd<IBE>(r2, t.xh2, t.out, a.g2, a.b2, g);
+}
+
+template <int IBE>
+__device__ __forceinline__ void load_tile(const TArgs& a, const UnitId& u, f32x4 (&e)[IBE], int lane) {
+  const float* ep = a.E + ((long long)u.row * a.n + u.jj) * (16 * IBE) + 4 * (lane >> 4);
+#pragma unroll
+  for (int eb = 0; eb < IBE; ++eb) e[eb] = u.vj ? ld4(ep + 16 * eb) : splat4(0.f);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Forward: E_out[b,i,j,:] = LN2(...) on the valid pairs (the caller zero-fills E_out; symmetrisation and the diagonal /
+// padding mask are the caller's, transformer_model.py:99,110-112) and the unit's softmax partials [max | sum p | sum p V].
+// ---------------------------------------------------------------------------------------------------------
+template <int IBE, int IBF>
+__global__ __launch_bounds__(256) void train_edge_fwd_kernel(TArgs a) {
+  const int lane = threadIdx.x & 63, g = lane >> 4;
+  const long long total = (long long)a.B * a.n * a.nch;
+  if ((long long)blockIdx.x * 4 + (threadIdx.x >> 6) >= total) return;
+  const UnitId u = unit_id(a, lane);
+  if (!u.any) {                                   // neutral partials: the merge walks every chunk of a valid row
+    float* part = a.part + u.unit * 3 * a.dx;
+    for (int c = lane; c < a.dx; c += 64) { part[c] = -INFINITY; part[a.dx + c] = 0.f; part[2 * a.dx + c] = 0.f; }
+    return;
+  }
+  f32x4 e[IBE], newE[IBE];
+  load_tile<IBE>(a, u, e, lane);
+  attention_half<IBE, true>(a, u, e, newE, lane);
+  Tail<IBE, IBF> t;
+  tail_fwd<IBE, IBF>(a, u, e, newE, t, lane);
+  if (u.vj) {
+    float* dst = a.E_out + ((long long)u.row * a.n + u.jj) * (16 * IBE) + 4 * g;
+#pragma unroll
+    for (int eb = 0; eb < IBE; ++eb) *reinterpret_cast<f32x4*>(dst + 16 * eb) = t.out[eb];
+  }
+}
+
+// merge of the units of a row: wV[row, c] = sum_j softmax_j(Y)[c] V_j[c], lse[row, c] = log sum_j exp(Y[c])
+__global__ __launch_bounds__(256) void train_edge_merge_kernel(TArgs a) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int DX = a.dx;
+  if (idx >= (long long)a.B * a.n * DX) return;
+  const int row = (int)(idx / DX), c = (int)(idx - (long long)row * DX);
+  float wv = 0.f, lse = 0.f;
+  if (a.mask[row] != 0) {
+    const float* part = a.part + (long long)row * a.nch * 3 * DX + c;
+    float M = -INFINITY;
+    for (int jc = 0; jc < a.nch; ++jc) M = fmaxf(M, part[(long long)jc * 3 * DX]);
+    float S = 0.f, A = 0.f;
+    for (int jc = 0; jc < a.nch; ++jc) {
+      const float* pj = part + (long long)jc * 3 * DX;
+      const float w = pj[0] == -INFINITY ? 0.f : __expf(pj[0] - M);
+      S += pj[DX] * w;
+      A += pj[2 * DX] * w;
+    }
+    wv = A / S;
+    lse = M + logf(S);
+  }
+  a.wV_out[idx] = wv;
+  a.lse_out[idx] = lse;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Backward.  Given dOut = dL/dE_out (read on the valid pairs only) and dwV = dL/dwV:
+//   LN2:  dr2 = LN2'(dOut)             do = drop3'(dr2)          df = (W_2^T do) (.) drop2' (.) [f > 0]
+//   dh1 = dr2 + W_1^T df               LN1: dr1 = LN1'(dh1)      dnewE = drop1'(dr1)        de = dr1
+//   per dx block: dz = W_out^T dnewE   dY = yem1 (.) dz + p (.) dwV_i (.) (V_j - wV_i)       (softmax backward in closed form:
+//                                      sum_j p dwV V_j = dwV wV, so no second pass over the row)
+//                 da1 = dY (.) y0      da2 = dY      de += W_mul^T da1 + W_add^T da2
+//                 dQ_i += sum_j dY a1 K_j / sqrt(df)      dK_j += sum_i dY a1 Q_i / sqrt(df)      dV_j += sum_i p dwV_i
+// Outputs, all indexed by the DENSE pair slot s = unit * 16 + (lane & 15) (every slot is written, zeros where the pair is
+// not valid, so the host needs no memset and its sums are deterministic):
+//   dE[b,i,j,:] (j < n)     G_e [s, de] = e      G_da [s, 2 dx] = da1 | da2      G_z [s, dx]      G_dnewE [s, de]
+//   G_h1 [s, de]   G_df [s, ffE]   G_f [s, ffE] (= f after ReLU and dropout)   G_do [s, de]   G_dkv [s, 2 dx] = dK | dV summands
+//   upart [unit, 2 dx + 4 de] = dQ row partial (unscaled) | sum dz (.) Y | dgamma2 | dbeta2 | dgamma1 | dbeta1
+// ---------------------------------------------------------------------------------------------------------
+template <int W16>
+__device__ __forceinline__ void zero_rows(float* base, long long slot, int g) {
+  float* dst = base + slot * (16 * W16) + 4 * g;
+#pragma unroll
+  for (int b = 0; b < W16; ++b) *reinterpret_cast<f32x4*>(dst + 16 * b) = splat4(0.f);
+}
+__device__ __forceinline__ void zero_rows_rt(float* base, long long slot, int width, int g) {
+  float* dst = base + slot * width + 4 * g;
+  for (int b = 0; b < width / 16; ++b) *reinterpret_cast<f32x4*>(dst + 16 * b) = splat4(0.f);
+}
+
+template <int IBE, int IBF>
+__global__ __launch_bounds__(256) void train_edge_bwd_kernel(TArgs a) {
+  constexpr int DE = 16 * IBE, FFE = 16 * IBF;
+  const int lane = threadIdx.x & 63, p = lane & 15, g = lane >> 4;
+  const long long total = (long long)a.B * a.n * a.nch;
+  if ((long long)blockIdx.x * 4 + (threadIdx.x >> 6) >= total) return;
+  const UnitId u = unit_id(a, lane);
+  const int DX = a.dx, XB = DX / 16;
+  const long long slot = u.unit * 16 + p;
+  float* up = a.upart + u.unit * (2 * DX + 4 * DE);
+  float* dEp = a.dE + ((long long)u.row * a.n + u.jj) * DE + 4 * g;
+  if (!u.any) {
+    if (u.inb)
+#pragma unroll
+      for (int eb = 0; eb < IBE; ++eb) *reinterpret_cast<f32x4*>(dEp + 16 * eb) = splat4(0.f);
+    zero_rows<IBE>(a.G_e, slot, g);
+    zero_rows_rt(a.G_da, slot, 2 * DX, g);
+    zero_rows_rt(a.G_z, slot, DX, g);
+    zero_rows<IBE>(a.G_dnewE, slot, g);
+    zero_rows<IBE>(a.G_h1, slot, g);
+    zero_rows<IBF>(a.G_df, slot, g);
+    zero_rows<IBF>(a.G_f, slot, g);
+    zero_rows<IBE>(a.G_do, slot, g);
+    zero_rows_rt(a.G_dkv, slot, 2 * DX, g);
+    for (int c = lane; c < 2 * DX + 4 * DE; c += 64) up[c] = 0.f;
+    return;
+  }
+  const bool drop = a.p > 0.f;
+  const float denom = 1.0f - a.p;
+  const unsigned long long pair = (unsigned long long)u.row * a.n + u.jj;
+
+  // ---- recompute the forward
+  f32x4 e[IBE], newE[IBE];
+  load_tile<IBE>(a, u, e, lane);
+  attention_half<IBE, false>(a, u, e, newE, lane);
+  Tail<IBE, IBF> t;
+  tail_fwd<IBE, IBF>(a, u, e, newE, t, lane);
+
+  // ---- LN2 backward
+  f32x4 gy[IBE], dr2[IBE];
+  {
+    const float* gp = a.dOut + ((long long)u.row * a.n + u.jj) * DE + 4 * g;
+#pragma unroll
+    for (int eb = 0; eb < IBE; ++eb) gy[eb] = u.vj ? ld4(gp + 16 * eb) : splat4(0.f);
+  }
+  ln_bwd<IBE>(gy, t.xh2, t.rstd2, a.g2, g, dr2);
+#pragma unroll
+  for (int eb = 0; eb < IBE; ++eb) {
+    f32x4 s1, s2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[r] = row_sum16(gy[eb][r] * t.xh2[eb][r]); s2[r] = row_sum16(gy[eb][r]); }
+    if (p == 0) {
+      *reinterpret_cast<f32x4*>(up + 2 * DX + 16 * eb + 4 * g) = s1;
+      *reinterpret_cast<f32x4*>(up + 2 * DX + DE + 16 * eb + 4 * g) = s2;
+    }
+  }
+  // ---- FFN backward
+  f32x4 dov[IBE], dh1[IBE];
+#pragma unroll
+  for (int eb = 0; eb < IBE; ++eb) {
+    dov[eb] = dr2[eb];
+    if (drop) drop4(dov[eb], pair * DE + 16 * eb + 4 * g, a.site3, a.p, denom, a.k0, a.k1);
+    dh1[eb] = dr2[eb];
+    *reinterpret_cast<f32x4*>(a.G_do + slot * DE + 16 * eb + 4 * g) = dov[eb];
+    *reinterpret_cast<f32x4*>(a.G_h1 + slot * DE + 16 * eb + 4 * g) = u.vj ? t.h1[eb] : splat4(0.f);
+  }
+#pragma unroll
+  for (int fb = 0; fb < IBF; ++fb) {
+    f32x4 df = splat4(0.f);
+#pragma unroll
+    for (int ob = 0; ob < IBE; ++ob) mfma4(df, frag(a.F_ff2T, fb * IBE + ob, lane), dov[ob]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) df[r] = t.hid[fb][r] > 0.f ? (drop ? df[r] / denom : df[r]) : 0.f;
+    *reinterpret_cast<f32x4*>(a.G_df + slot * FFE + 16 * fb + 4 * g) = df;
+    *reinterpret_cast<f32x4*>(a.G_f + slot * FFE + 16 * fb + 4 * g) = u.vj ? t.hid[fb] : splat4(0.f);
+#pragma unroll
+    for (int eb = 0; eb < IBE; ++eb) mfma4(dh1[eb], frag(a.F_ff1T, eb * IBF + fb, lane), df);
+  }
+  // ---- LN1 backward
+  f32x4 dr1[IBE], dnewE[IBE];
+  ln_bwd<IBE>(dh1, t.xh1, t.rstd1, a.g1, g, dr1);
+#pragma unroll
+  for (int eb = 0; eb < IBE; ++eb) {
+    f32x4 s1, s2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[r] = row_sum16(dh1[eb][r] * t.xh1[eb][r]); s2[r] = row_sum16(dh1[eb][r]); }
+    if (p == 0) {
+      *reinterpret_cast<f32x4*>(up + 2 * DX + 2 * DE + 16 * eb + 4 * g) = s1;
+      *reinterpret_cast<f32x4*>(up + 2 * DX + 3 * DE + 16 * eb + 4 * g) = s2;
+    }
+    dnewE[eb] = dr1[eb];
+    if (drop) drop4(dnewE[eb], pair * DE + 16 * eb + 4 * g, a.site1, a.p, denom, a.k0, a.k1);
+    *reinterpret_cast<f32x4*>(a.G_dnewE + slot * DE + 16 * eb + 4 * g) = dnewE[eb];
+    *reinterpret_cast<f32x4*>(a.G_e + slot * DE + 16 * eb + 4 * g) = e[eb];
+  }
+  // ---- the dx blocks again: attention and FiLM backward (dr1 accumulates dE)
+  const float* qrow = a.Q + (long long)u.row * DX;
+  const float* krow = a.K + ((long long)u.b * a.n + u.jj) * DX;
+  const float* vrow = a.V + ((long long)u.b * a.n + u.jj) * DX;
+  const float* yea = a.yea + (long long)u.b * DX;
+  const float* yem = a.yem1 + (long long)u.b * DX;
+  const float* lse = a.lse + (long long)u.row * DX;
+  const float* wV = a.wV + (long long)u.row * DX;
+  const float* dwV = a.dwV + (long long)u.row * DX;
+#pragma unroll 1
+  for (int xb = 0; xb < XB; ++xb) {
+    const int co = 16 * xb + 4 * g;
+    f32x4 a1 = ld4(a.b_mul + co) + splat4(1.0f), a2 = ld4(a.b_add + co);
+#pragma unroll
+    for (int ib = 0; ib < IBE; ++ib) {
+      mfma4(a1, frag(a.F_mul, xb * IBE + ib, lane), e[ib]);
+      mfma4(a2, frag(a.F_add, xb * IBE + ib, lane), e[ib]);
+    }
+    f32x4 dz = splat4(0.f);
+#pragma unroll
+    for (int ob = 0; ob < IBE; ++ob) mfma4(dz, frag(a.F_outT, xb * IBE + ob, lane), dnewE[ob]);
+    const f32x4 q = ld4(qrow + co) * a.inv_sqrt_df;
+    const f32x4 k = u.vj ? ld4(krow + co) : splat4(0.f);
+    const f32x4 v = u.vj ? ld4(vrow + co) : splat4(0.f);
+    const f32x4 ya = ld4(yea + co), ym = ld4(yem + co), ls = ld4(lse + co), wv = ld4(wV + co), dw = ld4(dwV + co);
+    f32x4 z, da1, da2, dk, dv, sq, sy;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float y0 = q[r] * k[r];
+      const float yy = y0 * a1[r] + a2[r];
+      z[r] = u.vj ? ya[r] + ym[r] * yy : 0.f;
+      const float pe = u.vj ? __expf(yy - ls[r]) : 0.f;
+      const float dY = u.vj ? ym[r] * dz[r] + pe * dw[r] * (v[r] - wv[r]) : 0.f;
+      da1[r] = dY * y0;
+      da2[r] = dY;
+      dk[r] = dY * a1[r] * q[r];
+      dv[r] = pe * dw[r];
+      sq[r] = row_sum16(dY * a1[r] * k[r]);
+      sy[r] = row_sum16(u.vj ? dz[r] * yy : 0.f);
+    }
+    *reinterpret_cast<f32x4*>(a.G_z + slot * DX + co) = z;
+    *reinterpret_cast<f32x4*>(a.G_da + slot * (2 * DX) + co) = da1;
+    *reinterpret_cast<f32x4*>(a.G_da + slot * (2 * DX) + DX + co) = da2;
+    *reinterpret_cast<f32x4*>(a.G_dkv + slot * (2 * DX) + co) = dk;
+    *reinterpret_cast<f32x4*>(a.G_dkv + slot * (2 * DX) + DX + co) = dv;
+    if (p == 0) {
+      *reinterpret_cast<f32x4*>(up + co) = sq;
+      *reinterpret_cast<f32x4*>(up + DX + co) = sy;
+    }
+#pragma unroll
+    for (int eb = 0; eb < IBE; ++eb) {
+      mfma4(dr1[eb], frag(a.F_mulT, eb * XB + xb, lane), da1);
+      mfma4(dr1[eb], frag(a.F_addT, eb * XB + xb, lane), da2);
+    }
+  }
+  if (u.inb)
+#pragma unroll
+    for (int eb = 0; eb < IBE; ++eb) *reinterpret_cast<f32x4*>(dEp + 16 * eb) = u.vj ? dr1[eb] : splat4(0.f);
+}
+
+// fragment image of M = W (transpose = 0) or W^T (1), W [rows, cols] row-major; M is [R, Cc], both multiples of 16
+__global__ __launch_bounds__(256) void train_edge_pack_kernel(const float* W, int rows, int cols, int transpose, float* out) {
+  const int R = transpose ? cols : rows, Cc = transpose ? rows : cols;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;          // float4 index
+  if (idx >= (long long)R * Cc / 4) return;
+  const int l = (int)(idx & 63);
+  const long long blk = idx >> 6;
+  const int CB = Cc / 16, rb = (int)(blk / CB), cb = (int)(blk - (long long)rb * CB);
+  const int r = 16 * rb + (l & 15), c0 = 16 * cb + 4 * (l >> 4);
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = transpose ? W[(size_t)(c0 + e) * cols + r] : W[(size_t)r * cols + c0 + e];
+  reinterpret_cast<f32x4*>(out)[idx] = v;
+}
+
+int check_args(const TArgs* a, bool bwd) {
+  if (!a) return fail("train_edge: null arguments");
+  if (a->B <= 0 || a->n <= 0 || a->nch != (a->n + 15) / 16) return fail("train_edge: bad B / n / nch");
+  if (a->dx < 16 || a->dx % 16 != 0) return fail("train_edge: dx = %d must be a multiple of 16", a->dx);
+  if (!((a->de == 32 && a->ffe == 64) || (a->de == 64 && a->ffe == 128)))
+    return fail("train_edge: (de, dim_ffE) = (%d, %d) not built (32/64 and 64/128 are)", a->de, a->ffe);
+  if (!(a->p >= 0.f) || !(a->p < 1.f)) return fail("train_edge: bad dropout p");
+  if (!a->E || !a->Q || !a->K || !a->V || !a->yea || !a->yem1 || !a->mask || !a->F_mul || !a->F_add || !a->F_out || !a->F_ff1 ||
+      !a->F_ff2 || !a->b_mul || !a->b_add || !a->b_out || !a->g1 || !a->b1 || !a->b_ff1 || !a->b_ff2 || !a->g2 || !a->b2)
+    return fail("train_edge: null input");
+  if (!bwd && (!a->E_out || !a->part || !a->wV_out || !a->lse_out)) return fail("train_edge forward: null output");
+  if (bwd && (!a->F_mulT || !a->F_addT || !a->F_outT || !a->F_ff1T || !a->F_ff2T || !a->dOut || !a->dwV || !a->wV || !a->lse || !a->dE ||
+              !a->G_e || !a->G_da || !a->G_z || !a->G_dnewE || !a->G_h1 || !a->G_df || !a->G_f || !a->G_do || !a->G_dkv || !a->upart))
+    return fail("train_edge backward: null argument");
+  if ((long long)a->B * a->n * a->nch / 4 + 1 > 0x7fffffffLL) return fail("train_edge: too many units for one launch");
+  return 0;
+}
+
+}  // namespace
+}  // namespace scgg
+
+using namespace scgg;
+
+extern "C" int scgg_train_edge_pack(const float* W, int32_t rows, int32_t cols, int32_t transpose, float* out, void* stream) {
+  if (!W || !out || rows <= 0 || cols <= 0 || rows % 16 != 0 || cols % 16 != 0) return fail("train_edge_pack: bad arguments");
+  const long long f4 = (long long)rows * cols / 4;
+  hipLaunchKernelGGL(train_edge_pack_kernel, dim3((unsigned)((f4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), W, rows,
+                     cols, transpose, out);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail("train_edge_pack: %s", hipGetErrorString(e));
+}
+
+extern "C" int scgg_train_edge_forward(const scgg_train_edge_args* a, void* stream) {
+  if (check_args(a, false)) return -1;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long units = (long long)a->B * a->n * a->nch;
+  const dim3 grid((unsigned)((units + 3) / 4)), blk(256);
+  if (a->de == 32) hipLaunchKernelGGL((train_edge_fwd_kernel<2, 4>), grid, blk, 0, st, *a);
+  else hipLaunchKernelGGL((train_edge_fwd_kernel<4, 8>), grid, blk, 0, st, *a);
+  const long long el = (long long)a->B * a->n * a->dx;
+  hipLaunchKernelGGL(train_edge_merge_kernel, dim3((unsigned)((el + 255) / 256)), dim3(256), 0, st, *a);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail("train_edge_forward: %s", hipGetErrorString(e));
+}
+
+extern "C" int scgg_train_edge_backward(const scgg_train_edge_args* a, void* stream) {
+  if (check_args(a, true)) return -1;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long units = (long long)a->B * a->n * a->nch;
+  const dim3 grid((unsigned)((units + 3) / 4)), blk(256);
+  if (a->de == 32) hipLaunchKernelGGL((train_edge_bwd_kernel<2, 4>), grid, blk, 0, st, *a);
+  else hipLaunchKernelGGL((train_edge_bwd_kernel<4, 8>), grid, blk, 0, st, *a);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail("train_edge_backward: %s", hipGetErrorString(e));
+}

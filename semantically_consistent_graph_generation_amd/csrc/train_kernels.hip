@@ -5,8 +5,8 @@
 //   TrainLoss      src/ConStruct/metrics/train_metrics.py:25-85, CrossEntropyMetric src/ConStruct/metrics/abstract_metrics.py:77-93
 //                  (sum of cross entropies over the rows that take part / number of those rows)
 // The reference draws dropout masks from torch's global generator; here the mask of site s is a pure function of
-// (seed, s, flat element index): Philox4x32-10, counter (index low, index high, s, 0xD0), key = seed, word 0 -> u in [0,1)
-// from the top 24 bits, kept iff u >= p, scaled by 1 / (1 - p).  The same function is oracle/training.py:dropout_keep, so
+// (seed, s, flat element index): Philox4x32-10, counter ((index >> 2) low, (index >> 2) high, s, 0xD0), key = seed, word
+// (index & 3) -> u in [0,1) from the top 24 bits, kept iff u >= p, scaled by 1 / (1 - p).  The same function is oracle/training.py:dropout_keep, so
 // a train-mode forward can be compared bit for bit, and the backward pass re-derives the mask instead of storing it.
 // Both kernels are HBM-bound streaming passes: dropout 8 B per element, the loss (4 C + 1) B per row read and 4 C written.
 #include <hip/hip_runtime.h>
@@ -24,8 +24,9 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= numel) return;
   uint32_t r[4];
-  philox4x32_10((uint32_t)(idx & 0xffffffffll), (uint32_t)(idx >> 32), site, 0xD0u, k0, k1, r);
-  out[idx] = u01(r[0]) >= p ? x[idx] / denom : 0.f;   // a division, as the oracle's x * keep / (1 - p)
+  const long long c = idx >> 2;                        // four consecutive elements share one Philox call (train_edge.hip: a lane's f32x4)
+  philox4x32_10((uint32_t)(c & 0xffffffffll), (uint32_t)(c >> 32), site, 0xD0u, k0, k1, r);
+  out[idx] = u01(r[idx & 3]) >= p ? x[idx] / denom : 0.f;   // a division, as the oracle's x * keep / (1 - p)
 }
 
 // rows of C logits, int8 target per row (< 0: the row does not take part).  partial[blockIdx.x] = sum of the cross

@@ -18,6 +18,7 @@ in / out MLPs, and only with ``dropout_in_and_out``.
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 
 import torch
@@ -170,6 +171,149 @@ def _block(a, X, E, y, m, node_mask):
     return newX, newE, new_y
 
 
+# ------------------------------------------------------------------------------------------------- fused edge layer
+_EDGE_W = ("e_mul.weight", "e_add.weight", "e_out.weight", "linE1.weight", "linE2.weight")
+
+
+def fused_edge_supported(dx, de, ffe):
+    """Shapes csrc/train_edge.hip is built for; SCGG_TRAIN_MODE=eager keeps the unfused tensor-op path (the checker)."""
+    import os
+    return os.environ.get("SCGG_TRAIN_MODE", "fused") != "eager" and dx % 16 == 0 and (de, ffe) in ((32, 64), (64, 128))
+
+
+def _pack(W, transpose):
+    W = W.detach().float().contiguous()
+    out = torch.empty(W.numel(), device=W.device)
+    _lib.check(_lib.lib().scgg_train_edge_pack(_lib.ptr(W), W.shape[0], W.shape[1], int(transpose), _lib.ptr(out), _lib.stream_ptr()),
+               "train_edge_pack")
+    return out
+
+
+class _FusedEdgeLayer(torch.autograd.Function):
+    """The [B,n,n,.] part of one XEyTransformerLayer in training mode as two HIP kernels (csrc/train_edge.hip):
+    (E, Q, K, V, yea, yem1) -> (E_out before symmetrisation / masking, wV).  Saves its inputs and (wV, lse) only; the
+    backward kernel recomputes the chain per 16-key unit, returns dE and the factors of the weight gradients, and the
+    gradients of the five weight matrices are one library GEMM each over those factors."""
+
+    @staticmethod
+    def forward(ctx, E, Q, K, V, yea, yem1, mask_u8, inv_sqrt_df, p, seed, sites,
+                W_mul, b_mul, W_add, b_add, W_out, b_out, g1, b1, W_ff1, b_ff1, W_ff2, b_ff2, g2, b2):
+        B, n, _, de = E.shape
+        dx, ffe = Q.shape[-1], W_ff1.shape[0]
+        nch = (n + 15) // 16
+        E, Q, K, V, yea, yem1 = (t.detach().float().contiguous() for t in (E, Q, K, V, yea, yem1))
+        vecs = [t.detach().float().contiguous() for t in (b_mul, b_add, b_out, g1, b1, b_ff1, b_ff2, g2, b2)]
+        Ws = (W_mul, W_add, W_out, W_ff1, W_ff2)
+        F_fwd = [_pack(W, False) for W in Ws]
+        a = _lib.TrainEdgeArgs()
+        keep = [E, Q, K, V, yea, yem1, mask_u8] + vecs + F_fwd
+        for k, t in zip(("E", "Q", "K", "V", "yea", "yem1", "mask"), (E, Q, K, V, yea, yem1, mask_u8)):
+            setattr(a, k, t.data_ptr())
+        for k, t in zip(("F_mul", "F_add", "F_out", "F_ff1", "F_ff2"), F_fwd):
+            setattr(a, k, t.data_ptr())
+        for k, t in zip(("b_mul", "b_add", "b_out", "g1", "b1", "b_ff1", "b_ff2", "g2", "b2"), vecs):
+            setattr(a, k, t.data_ptr())
+        E_out = torch.zeros_like(E)
+        part = torch.empty(B * n * nch, 3, dx, device=E.device)
+        wV = torch.empty(B, n, dx, device=E.device)
+        lse = torch.empty(B, n, dx, device=E.device)
+        a.E_out, a.part, a.wV_out, a.lse_out = E_out.data_ptr(), part.data_ptr(), wV.data_ptr(), lse.data_ptr()
+        a.B, a.n, a.nch, a.dx, a.de, a.ffe = B, n, nch, dx, de, ffe
+        a.inv_sqrt_df, a.p = float(inv_sqrt_df), float(p) if seed is not None else 0.0
+        sd = int(seed) if seed is not None else 0
+        a.k0, a.k1 = sd & 0xFFFFFFFF, (sd >> 32) & 0xFFFFFFFF
+        a.site1, a.site2, a.site3 = (int(v) for v in sites)
+        _lib.check(_lib.lib().scgg_train_edge_forward(C.byref(a), _lib.stream_ptr()), "train_edge_forward")
+        del keep
+        ctx.save_for_backward(E, Q, K, V, yea, yem1, mask_u8, wV, lse, *vecs, *[W.detach() for W in Ws])
+        ctx.cfg = (float(inv_sqrt_df), a.p, sd, tuple(int(v) for v in sites))
+        ctx.mark_non_differentiable(lse)
+        return E_out, wV, lse
+
+    @staticmethod
+    def backward(ctx, dOut, dwV, _dlse):
+        E, Q, K, V, yea, yem1, mask_u8, wV, lse = ctx.saved_tensors[:9]
+        vecs = list(ctx.saved_tensors[9:18])
+        Ws = list(ctx.saved_tensors[18:23])
+        inv_sqrt_df, p, sd, sites = ctx.cfg
+        B, n, _, de = E.shape
+        dx, ffe = Q.shape[-1], Ws[3].shape[0]
+        nch = (n + 15) // 16
+        dev = E.device
+        S = B * n * nch * 16
+        dOut = torch.zeros_like(E) if dOut is None else dOut.float().contiguous()
+        dwV = torch.zeros_like(wV) if dwV is None else dwV.float().contiguous()
+        F_fwd = [_pack(W, False) for W in Ws]
+        F_bwd = [_pack(W, True) for W in Ws]
+        a = _lib.TrainEdgeArgs()
+        for k, t in zip(("E", "Q", "K", "V", "yea", "yem1", "mask"), (E, Q, K, V, yea, yem1, mask_u8)):
+            setattr(a, k, t.data_ptr())
+        for k, t in zip(("F_mul", "F_add", "F_out", "F_ff1", "F_ff2"), F_fwd):
+            setattr(a, k, t.data_ptr())
+        for k, t in zip(("F_mulT", "F_addT", "F_outT", "F_ff1T", "F_ff2T"), F_bwd):
+            setattr(a, k, t.data_ptr())
+        for k, t in zip(("b_mul", "b_add", "b_out", "g1", "b1", "b_ff1", "b_ff2", "g2", "b2"), vecs):
+            setattr(a, k, t.data_ptr())
+        dE = torch.empty_like(E)
+        G = {k: torch.empty(S, w, device=dev) for k, w in (("G_e", de), ("G_da", 2 * dx), ("G_z", dx), ("G_dnewE", de), ("G_h1", de),
+                                                          ("G_df", ffe), ("G_f", ffe), ("G_do", de), ("G_dkv", 2 * dx))}
+        upart = torch.empty(B * n * nch, 2 * dx + 4 * de, device=dev)
+        a.dOut, a.dwV, a.wV, a.lse, a.dE, a.upart = dOut.data_ptr(), dwV.data_ptr(), wV.data_ptr(), lse.data_ptr(), dE.data_ptr(), upart.data_ptr()
+        for k, t in G.items():
+            setattr(a, k, t.data_ptr())
+        a.B, a.n, a.nch, a.dx, a.de, a.ffe = B, n, nch, dx, de, ffe
+        a.inv_sqrt_df, a.p = inv_sqrt_df, p
+        a.k0, a.k1 = sd & 0xFFFFFFFF, (sd >> 32) & 0xFFFFFFFF
+        a.site1, a.site2, a.site3 = sites
+        _lib.check(_lib.lib().scgg_train_edge_backward(C.byref(a), _lib.stream_ptr()), "train_edge_backward")
+        # weight gradients: dW = G_g^T G_x, the pair slot as the reduction index (library GEMMs on the kernel's factors)
+        dW_ma = G["G_da"].t() @ G["G_e"]                        # [2dx, de] = d e_mul.weight | d e_add.weight
+        db_ma = G["G_da"].sum(0)
+        dW_out, db_out = G["G_dnewE"].t() @ G["G_z"], G["G_dnewE"].sum(0)
+        dW_ff1, db_ff1 = G["G_df"].t() @ G["G_h1"], G["G_df"].sum(0)
+        dW_ff2, db_ff2 = G["G_do"].t() @ G["G_f"], G["G_do"].sum(0)
+        up = upart.view(B, n, nch, -1)
+        dQ = up[..., :dx].sum(2) * inv_sqrt_df
+        dyem1 = up[..., dx:2 * dx].sum((1, 2))
+        ln = up[..., 2 * dx:].sum((0, 1, 2))
+        dg2, db2, dg1, db1 = ln[:de], ln[de:2 * de], ln[2 * de:3 * de], ln[3 * de:]
+        dkv = G["G_dkv"].view(B, n, nch * 16, 2 * dx).sum(1)[:, :n]
+        dK, dV = dkv[..., :dx].contiguous(), dkv[..., dx:].contiguous()
+        dyea = G["G_dnewE"].view(B, n * nch * 16, de).sum(1) @ Ws[2]          # sum of dz = W_out^T sum of dnewE, per graph
+        return (dE, dQ, dK, dV, dyea, dyem1, None, None, None, None, None,
+                dW_ma[:dx], db_ma[:dx], dW_ma[dx:], db_ma[dx:], dW_out, db_out, dg1, db1, dW_ff1, db_ff1, dW_ff2, db_ff2, dg2, db2)
+
+
+def _layer_fused(layer, hX, hE, hy, m, node_mask, mask_u8, offdiag, dl, base):
+    """One XEyTransformerLayer in training mode with the [B,n,n,.] part in the fused kernels; the X / y paths and the pooled
+    statistics stay tensor ops (O(n dx^2) and O(n^2 de) work).  Dropout sites as in train_forward."""
+    a = layer.self_attn
+    xm = m[:, :, None]
+    Q, K, V = _lin(a.q, hX) * xm, _lin(a.k, hX) * xm, _lin(a.v, hX) * xm
+    E_raw, wV, _ = _FusedEdgeLayer.apply(
+        hE, Q, K, V, _lin(a.y_e_add, hy), _lin(a.y_e_mul, hy) + 1.0, mask_u8, 1.0 / math.sqrt(a.df), dl.p, dl.seed,
+        (base + 3, base + 4, base + 5), a.e_mul.weight, a.e_mul.bias, a.e_add.weight, a.e_add.bias, a.e_out.weight, a.e_out.bias,
+        layer.normE1.weight, layer.normE1.bias, layer.linE1.weight, layer.linE1.bias, layer.linE2.weight, layer.linE2.bias,
+        layer.normE2.weight, layer.normE2.bias)
+    newX = _lin(a.x_out, _lin(a.y_x_add, hy)[:, None, :] + (_lin(a.y_x_mul, hy)[:, None, :] + 1.0) * wV) * xm
+    new_y = None
+    if a.predicts_y:
+        z = _lin(a.y_y, hy) + _lin(a.x_y.lin, _node_stats(hX, m)) + _lin(a.e_y.lin, _edge_stats(hE, m))
+        new_y = _lin(a.y_out[2], torch.relu(_lin(a.y_out[0], z)))
+    dl.site = base
+    hX = _ln(layer.normX1, hX + dl(newX))
+    hX = _ln(layer.normX2, hX + dl(_lin(layer.linX2, dl(torch.relu(_lin(layer.linX1, hX))))))
+    hE = 0.5 * (E_raw + E_raw.transpose(1, 2))
+    if layer.predicts_y:
+        dl.site = base + 6
+        hy = _ln(layer.norm_y1, hy + dl(new_y))
+        hy = _ln(layer.norm_y2, hy + dl(_lin(layer.lin_y2, dl(torch.relu(_lin(layer.lin_y1, hy))))))
+    else:
+        hy = None
+    hX, hE = _mask_xe(hX, hE, m, offdiag)
+    return hX, hE, hy
+
+
 def train_forward(model, X, E, y, node_mask, seed=None, p_layer=None):
     """GraphTransformer.forward in training mode (transformer_model.py:344-389 with the dropout sites of :88-105 and
     :284-340), differentiable.  ``seed`` None: no dropout (the fixtures' setting); ``p_layer`` defaults to the reference's
@@ -196,8 +340,12 @@ def train_forward(model, X, E, y, node_mask, seed=None, p_layer=None):
     hX = mlp_in(model.mlp_in_X, X)
     hy = mlp_in(model.mlp_in_y, y)
     hX, hE = _mask_xe(hX, hE, m, offdiag)
+    mask_u8 = node_mask.contiguous().view(torch.uint8)
     for l, layer in enumerate(model.tf_layers):
         dl.site = 100 + 16 * l
+        if fused_edge_supported(hX.shape[-1], hE.shape[-1], layer.linE1.weight.shape[0]):
+            hX, hE, hy = _layer_fused(layer, hX, hE, hy, m, node_mask, mask_u8, offdiag, dl, 100 + 16 * l)
+            continue
         newX, newE, new_y = _block(layer.self_attn, hX, hE, hy, m, node_mask)
         hX = _ln(layer.normX1, hX + dl(newX))
         hX = _ln(layer.normX2, hX + dl(_lin(layer.linX2, dl(torch.relu(_lin(layer.linX1, hX))))))

@@ -326,3 +326,54 @@ def test_training_step_at_config3_shape():
     live = (m[sl][:, :, None] & m[sl][:, None, :]) & ~torch.eye(n, dtype=torch.bool)[None]
     want = 5.0 * torch.nn.functional.cross_entropy(oE[live], lab[sl][live], reduction="sum") / int(live.sum())
     close(l2, want, 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("dims_name,n_nodes,seed", [("tiny", [9, 4, 11, 17], None), ("tiny", [9, 4, 11, 17], 99),
+                                                    ("vessel", [40, 23, 33], 7), ("construct", [20, 32], 5)])
+def test_fused_edge_layer_matches_the_unfused_forward_and_backward(dims_name, n_nodes, seed, monkeypatch):
+    """Row a11: the train-mode forward through the fused edge kernels and their hand-written backward (csrc/train_edge.hip)
+    against the unfused tensor-op path (SCGG_TRAIN_MODE=eager, itself pinned by the reference fixture F10): logits 1e-5 of
+    the scale, loss 1e-6, every parameter gradient 2e-4 of its scale -- with and without dropout (same Philox masks)."""
+    from semantically_consistent_graph_generation_amd.training import train_forward, masked_cross_entropy
+    from semantically_consistent_graph_generation_amd.transformer_model import GraphTransformer
+    C, L = 5, 3
+    dims = {"tiny": fx.TINY_DIMS,
+            "vessel": dict(hidden_mlp_dims={"X": 128, "E": 128, "y": 128},
+                           hidden_dims={"dx": 128, "de": 64, "dy": 64, "n_head": 4, "dim_ffX": 128, "dim_ffE": 128, "dim_ffy": 128}),
+            "construct": dict(hidden_mlp_dims={"X": 256, "E": 128, "y": 128},
+                              hidden_dims={"dx": 256, "de": 64, "dy": 64, "n_head": 8, "dim_ffX": 256, "dim_ffE": 128, "dim_ffy": 128})}[dims_name]
+    model = GraphTransformer(L, fx.dims_ns(3, C + 2, 4), dims["hidden_mlp_dims"], dims["hidden_dims"], fx.dims_ns(1, C, 0))
+    model.load_state_dict(fx.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 77))
+    model = model.cuda().train()
+    m = fx.ragged_mask(n_nodes)
+    B, n = m.shape
+    gen = torch.Generator().manual_seed(13)
+    lab = fx.random_labels(m, C, 0.3, 4)
+    E = torch.cat([fx.one_hot_edges(lab, m, C), torch.randn(B, n, n, 2, generator=gen)], dim=-1)
+    E = 0.5 * (E + E.transpose(1, 2))
+    X = torch.randn(B, n, 3, generator=gen) * m[..., None]
+    y = torch.rand(B, 4, generator=gen)
+    live = (m[:, :, None] & m[:, None, :]) & ~torch.eye(n, dtype=torch.bool)[None]
+    tgt = torch.where(live, lab, torch.full_like(lab, -1)).cuda()
+    out = {}
+    for mode in ("eager", "fused"):
+        monkeypatch.setenv("SCGG_TRAIN_MODE", mode)
+        model.zero_grad(set_to_none=True)
+        pred = train_forward(model, X.cuda(), E.cuda(), y.cuda(), m.cuda(), seed=seed)
+        loss = masked_cross_entropy(pred.E, tgt) + 0.3 * (pred.X ** 2).mean()      # the X term reaches wV / newX in every layer
+        loss.backward()
+        torch.cuda.synchronize()
+        out[mode] = (pred.E.detach().clone(), float(loss), {k: (None if p.grad is None else p.grad.clone()) for k, p in model.named_parameters()})
+    sc = float(out["eager"][0].abs().max())
+    assert float((out["fused"][0] - out["eager"][0]).abs().max()) / sc < 1e-5
+    assert abs(out["fused"][1] - out["eager"][1]) < 1e-6 * max(1.0, abs(out["eager"][1]))
+    worst = ("", 0.0)
+    for k, ge in out["eager"][2].items():
+        gf = out["fused"][2][k]
+        assert (ge is None) == (gf is None), k
+        if ge is None:
+            continue
+        err = float((gf - ge).abs().max()) / max(float(ge.abs().max()), 1e-12)
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] < 2e-4, worst
