@@ -386,6 +386,11 @@ typedef struct scgg_train_edge_args {
 int scgg_train_edge_pack(const float* W, int32_t rows, int32_t cols, int32_t transpose, float* out, void* stream);
 int scgg_train_edge_forward(const scgg_train_edge_args* a, void* stream);
 int scgg_train_edge_backward(const scgg_train_edge_args* a, void* stream);
+/* the weight gradient of one Linear from the backward's factors (what autograd's `grad_out.T @ input` and
+ * `grad_out.sum(0)` do for nn.Linear): G [S,M], X [S,N] -> partial [scgg_train_wgrad_slabs(S, slab)][M*N + M]; slab w holds
+ * G^T X and the column sums of G over the slots [w slab, (w+1) slab); the caller adds the slabs.  M, N, slab multiples of 16. */
+int64_t scgg_train_wgrad_slabs(int64_t S, int32_t slab);
+int scgg_train_wgrad(const float* G, int32_t M, const float* X, int32_t N, int64_t S, int32_t slab, float* partial, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Stress configuration (BASELINE.json configs[4]): NodeEdgeBlock.forward (transformer_model.py:165-248, without the y

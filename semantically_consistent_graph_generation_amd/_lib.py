@@ -48,6 +48,8 @@ SIGNATURES = {
     "scgg_train_edge_pack": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "scgg_train_edge_forward": (C.c_int, [C.POINTER(TrainEdgeArgs), _vp]),
     "scgg_train_edge_backward": (C.c_int, [C.POINTER(TrainEdgeArgs), _vp]),
+    "scgg_train_wgrad_slabs": (_i64, [_i64, _i32]),
+    "scgg_train_wgrad": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp]),
     "scgg_version": (C.c_int, []),
     "scgg_last_error": (C.c_char_p, []),
     "scgg_denoiser_create": (_vp, [C.POINTER(DenoiserConfig)]),

@@ -21,9 +21,9 @@
 //   z = yea + yem1 (.) Y          newE = W_out z + b_out     attention: p = exp(Y - lse_i), wV_i = sum_j p (.) V_j
 //   r1 = e + drop1(newE)   h1 = LN1(r1)   f = drop2(relu(W_1 h1 + b_1))   r2 = h1 + drop3(W_2 f + b_2)   out = LN2(r2)
 // Backward: see train_edge_bwd_kernel.  Weight gradients are sums over all pairs of outer products g (x) x, i.e. GEMMs
-// with the PAIR as the reduction index; in C16 layout the pair sits on the MFMA's free index, so the kernel writes the
-// factors ("G tensors", [pairs, width]) and the host forms G^T X with the GEMM library (training.py) -- stated plainly:
-// that part is a library GEMM on tensors this kernel emits, everything per pair is in the kernel.
+// with the PAIR as the reduction index; in C16 layout the pair sits on the MFMA's free index, so the backward kernel writes
+// the factors ("G tensors", [pair slots, width]) and train_wgrad_kernel forms G^T X and the bias sums from them with the
+// slot as the MFMA's K index (split over slabs of slots; HBM-bound).
 //
 // Dropout: the mask of site s is Philox4x32-10 of (flat element index >> 2, site) with the element's word (index & 3),
 // the definition of train_kernels.hip / oracle/training.py:dropout_keep; a lane's f32x4 is one Philox call.
@@ -471,6 +471,67 @@ __global__ __launch_bounds__(256) void train_edge_pack_kernel(const float* W, in
   reinterpret_cast<f32x4*>(out)[idx] = v;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient: C[M,N] = G^T X and c[M] = column sums of G, G [S,M] and X [S,N] row-major factors written by the
+// backward kernel, S = pair slots (the reduction index, ~2.6e5 at B = 4, n = 256).  Split over S: workgroup w reduces
+// the slab [w slab, (w+1) slab) into partial[w] ([M, N] then [M] bias sums); the host adds the slabs in a fixed order
+// (deterministic, no atomics).  Wave v of the 4 owns the 16-row blocks v, v+4, ... of C; a K step takes 16 slots: lane
+// (m = l & 15, k = l >> 4) supplies G[s0 + 4k + r][16 mb + m] as A and X[s0 + 4k + r][16 nb + m] as B of
+// v_mfma_f32_16x16x4_f32 (64-byte runs per row: the factors are read once from HBM, the reuse across waves is cache).
+// The bias sums ride along as one more B block whose column 0 is all ones.  Bound: HBM (reads (M + N) 4 bytes per slot).
+// ---------------------------------------------------------------------------------------------------------
+template <int MW, int NB>
+__global__ __launch_bounds__(256) void train_wgrad_kernel(const float* __restrict__ G, int M, const float* __restrict__ X, long long S,
+                                                          int slab, float* __restrict__ partial) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, k = lane >> 4;
+  constexpr int N = 16 * NB;
+  const int Mb = M / 16;
+  const long long s_begin = (long long)blockIdx.x * slab;
+  const long long s_end = s_begin + slab < S ? s_begin + slab : S;
+  f32x4 acc[MW][NB], accb[MW];
+#pragma unroll
+  for (int i = 0; i < MW; ++i) {
+    accb[i] = splat4(0.f);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[i][j] = splat4(0.f);
+  }
+  const float one = m == 0 ? 1.0f : 0.f;
+  for (long long s0 = s_begin; s0 < s_end; s0 += 16) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long slot = s0 + 4 * k + r;
+      const bool ok = slot < s_end;
+      float av[MW], bv[NB];
+#pragma unroll
+      for (int i = 0; i < MW; ++i) {
+        const int mb = wave + 4 * i;
+        av[i] = (ok && mb < Mb) ? G[slot * M + 16 * mb + m] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) bv[j] = ok ? X[slot * N + 16 * j + m] : 0.f;
+#pragma unroll
+      for (int i = 0; i < MW; ++i) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        accb[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], ok ? one : 0.f, accb[i], 0, 0, 0);
+      }
+    }
+  }
+  float* out = partial + (size_t)blockIdx.x * ((size_t)M * N + M);
+#pragma unroll
+  for (int i = 0; i < MW; ++i) {
+    const int mb = wave + 4 * i;
+    if (mb >= Mb) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = 16 * mb + 4 * k + e;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) out[(size_t)row * N + 16 * j + m] = acc[i][j][e];
+      if (m == 0) out[(size_t)M * N + row] = accb[i][e];
+    }
+  }
+}
+
 int check_args(const TArgs* a, bool bwd) {
   if (!a) return fail("train_edge: null arguments");
   if (a->B <= 0 || a->n <= 0 || a->nch != (a->n + 15) / 16) return fail("train_edge: bad B / n / nch");
@@ -525,4 +586,30 @@ extern "C" int scgg_train_edge_backward(const scgg_train_edge_args* a, void* str
   else hipLaunchKernelGGL((train_edge_bwd_kernel<4, 8>), grid, blk, 0, st, *a);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail("train_edge_backward: %s", hipGetErrorString(e));
+}
+
+extern "C" int64_t scgg_train_wgrad_slabs(int64_t S, int32_t slab) { return (S <= 0 || slab <= 0) ? 0 : (S + slab - 1) / slab; }
+
+extern "C" int scgg_train_wgrad(const float* G, int32_t M, const float* X, int32_t N, int64_t S, int32_t slab, float* partial,
+                                void* stream) {
+  if (!G || !X || !partial || S <= 0) return fail("train_wgrad: bad arguments");
+  if (M < 16 || M % 16 != 0 || N < 16 || N % 16 != 0 || slab < 16 || slab % 16 != 0) return fail("train_wgrad: M, N, slab must be multiples of 16");
+  const int Mb = M / 16, NB = N / 16, MW = (Mb + 3) / 4;
+  const long long nsl = (S + slab - 1) / slab;
+  if (nsl > 0x7fffffffLL) return fail("train_wgrad: too many slabs");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)nsl), blk(256);
+#define SCGG_WG(mw, nb) hipLaunchKernelGGL((train_wgrad_kernel<mw, nb>), grid, blk, 0, st, G, (int)M, X, (long long)S, (int)slab, partial)
+  if (MW <= 1 && NB == 2) SCGG_WG(1, 2);
+  else if (MW <= 1 && NB == 4) SCGG_WG(1, 4);
+  else if (MW <= 1 && NB == 8) SCGG_WG(1, 8);
+  else if (MW <= 1 && NB == 16) SCGG_WG(1, 16);
+  else if (MW == 2 && NB == 2) SCGG_WG(2, 2);
+  else if (MW == 2 && NB == 4) SCGG_WG(2, 4);
+  else if (MW <= 4 && NB == 4) SCGG_WG(4, 4);
+  else if (MW <= 8 && NB == 4) SCGG_WG(8, 4);
+  else return fail("train_wgrad: shape M = %d, N = %d not built", (int)M, (int)N);
+#undef SCGG_WG
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail("train_wgrad: %s", hipGetErrorString(e));
 }

@@ -189,11 +189,24 @@ def _pack(W, transpose):
     return out
 
 
+def _wgrad(G, X, slab=1024):
+    """(G^T X, G.sum(0)) for the factor tensors of the backward kernel: split over the pair slots in the library's own
+    MFMA kernel (HBM-bound; the generic GEMM took 0.6 ms per call at K = 2.6e5), slabs added in a fixed order."""
+    S, M = G.shape
+    N = X.shape[1]
+    L = _lib.lib()
+    nsl = int(L.scgg_train_wgrad_slabs(S, slab))
+    partial = torch.empty(nsl, M * N + M, device=G.device)
+    _lib.check(L.scgg_train_wgrad(_lib.ptr(G), M, _lib.ptr(X), N, S, slab, _lib.ptr(partial), _lib.stream_ptr()), "train_wgrad")
+    tot = partial.sum(0)
+    return tot[: M * N].view(M, N), tot[M * N:]
+
+
 class _FusedEdgeLayer(torch.autograd.Function):
     """The [B,n,n,.] part of one XEyTransformerLayer in training mode as two HIP kernels (csrc/train_edge.hip):
     (E, Q, K, V, yea, yem1) -> (E_out before symmetrisation / masking, wV).  Saves its inputs and (wV, lse) only; the
-    backward kernel recomputes the chain per 16-key unit, returns dE and the factors of the weight gradients, and the
-    gradients of the five weight matrices are one library GEMM each over those factors."""
+    backward kernel recomputes the chain per 16-key unit, returns dE and the factors of the weight gradients, and
+    ``scgg_train_wgrad`` reduces those factors over the pair slots into the gradients of the five weight matrices."""
 
     @staticmethod
     def forward(ctx, E, Q, K, V, yea, yem1, mask_u8, inv_sqrt_df, p, seed, sites,
@@ -267,11 +280,10 @@ class _FusedEdgeLayer(torch.autograd.Function):
         a.site1, a.site2, a.site3 = sites
         _lib.check(_lib.lib().scgg_train_edge_backward(C.byref(a), _lib.stream_ptr()), "train_edge_backward")
         # weight gradients: dW = G_g^T G_x, the pair slot as the reduction index (library GEMMs on the kernel's factors)
-        dW_ma = G["G_da"].t() @ G["G_e"]                        # [2dx, de] = d e_mul.weight | d e_add.weight
-        db_ma = G["G_da"].sum(0)
-        dW_out, db_out = G["G_dnewE"].t() @ G["G_z"], G["G_dnewE"].sum(0)
-        dW_ff1, db_ff1 = G["G_df"].t() @ G["G_h1"], G["G_df"].sum(0)
-        dW_ff2, db_ff2 = G["G_do"].t() @ G["G_f"], G["G_do"].sum(0)
+        dW_ma, db_ma = _wgrad(G["G_da"], G["G_e"])             # [2dx, de] = d e_mul.weight | d e_add.weight
+        dW_out, db_out = _wgrad(G["G_dnewE"], G["G_z"])
+        dW_ff1, db_ff1 = _wgrad(G["G_df"], G["G_h1"])
+        dW_ff2, db_ff2 = _wgrad(G["G_do"], G["G_f"])
         up = upart.view(B, n, nch, -1)
         dQ = up[..., :dx].sum(2) * inv_sqrt_df
         dyem1 = up[..., dx:2 * dx].sum((1, 2))
