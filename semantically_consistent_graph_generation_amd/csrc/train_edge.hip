@@ -600,7 +600,9 @@ extern "C" int scgg_train_wgrad(const float* G, int32_t M, const float* X, int32
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid((unsigned)nsl), blk(256);
 #define SCGG_WG(mw, nb) hipLaunchKernelGGL((train_wgrad_kernel<mw, nb>), grid, blk, 0, st, G, (int)M, X, (long long)S, (int)slab, partial)
-  if (MW <= 1 && NB == 2) SCGG_WG(1, 2);
+  if (MW <= 1 && NB == 1) SCGG_WG(1, 1);
+  else if (MW == 2 && NB == 1) SCGG_WG(2, 1);
+  else if (MW <= 1 && NB == 2) SCGG_WG(1, 2);
   else if (MW <= 1 && NB == 4) SCGG_WG(1, 4);
   else if (MW <= 1 && NB == 8) SCGG_WG(1, 8);
   else if (MW <= 1 && NB == 16) SCGG_WG(1, 16);

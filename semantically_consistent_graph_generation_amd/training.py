@@ -202,6 +202,73 @@ def _wgrad(G, X, slab=1024):
     return tot[: M * N].view(M, N), tot[M * N:]
 
 
+_WGRAD_SHAPES = {(1, 1), (2, 1), (1, 2), (1, 4), (1, 8), (1, 16), (2, 2), (2, 4), (4, 4), (8, 4)}     # (ceil(M/64), N/16) built
+
+
+class _PairLinear(torch.autograd.Function):
+    """nn.Linear over the [B,n,n,.] tensors of the in / out MLPs of E in training mode: forward and data gradient are the
+    library GEMM (rows = pairs: its good case); the weight gradient, a reduction over ~2.6e5 pairs into a small matrix, is
+    ``scgg_train_wgrad`` (operands zero-padded to multiples of 16 columns when the widths are not)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        return F.linear(x, W, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
+        M, N = g2.shape[1], x2.shape[1]
+        Mp, Np = (M + 15) // 16 * 16, (N + 15) // 16 * 16
+        if ((Mp // 16 + 3) // 4, Np // 16) in _WGRAD_SHAPES and g2.shape[0] >= 4096:
+            gp = g2.contiguous() if Mp == M else F.pad(g2, (0, Mp - M))
+            xp = x2.contiguous() if Np == N else F.pad(x2, (0, Np - N))
+            dW, db = _wgrad(gp, xp)
+            dW, db = dW[:M, :N], db[:M]
+        else:
+            dW, db = g2.t() @ x2, g2.sum(0)
+        return g @ W, dW, db
+
+
+def _plin(m, x):
+    return _PairLinear.apply(x, m.weight, m.bias)
+
+
+class _EdgeStats(torch.autograd.Function):
+    """Etoy's pooled statistics (layers.py:34-41: mean | min | max | biased variance over all pairs of a graph, the masked
+    pairs pushed out of min / max by +-1e5) with a closed-form backward: saves E (which the fused layer keeps anyway), the
+    mean and the two arg-extrema instead of the five [B,n,n,de] temporaries autograd would keep per layer.  The gradient
+    of min / max goes to one element (the reference's ``.min(dim)[0]`` picks one index as well)."""
+
+    @staticmethod
+    def forward(ctx, E, m):
+        B, n, _, d = E.shape
+        pmf = (m[:, :, None] * m[:, None, :]).reshape(B, n * n, 1)
+        cnt = pmf.sum(1)                                            # [B,1]
+        Ef = E.reshape(B, n * n, d)
+        mean = Ef.sum(1) / cnt
+        big = 1e5 * (1.0 - pmf)
+        mn, imn = (Ef + big).min(dim=1)
+        mx, imx = (Ef - big).max(dim=1)
+        var = (((Ef - mean[:, None, :]) ** 2) * pmf).sum(1) / cnt
+        ctx.save_for_backward(E, m, mean, imn, imx)
+        return torch.cat([mean, mn, mx, var], dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        E, m, mean, imn, imx = ctx.saved_tensors
+        B, n, _, d = E.shape
+        pmf = (m[:, :, None] * m[:, None, :]).reshape(B, n * n, 1)
+        cnt = pmf.sum(1)
+        gm, gmi, gma, gv = g.split(d, dim=1)
+        Ef = E.reshape(B, n * n, d)
+        dE = (Ef - mean[:, None, :]) * pmf * (2.0 * gv / cnt)[:, None, :] + (gm / cnt)[:, None, :]
+        dE.scatter_add_(1, imn[:, None, :], gmi[:, None, :].contiguous())
+        dE.scatter_add_(1, imx[:, None, :], gma[:, None, :].contiguous())
+        return dE.view_as(E), None
+
+
 class _FusedEdgeLayer(torch.autograd.Function):
     """The [B,n,n,.] part of one XEyTransformerLayer in training mode as two HIP kernels (csrc/train_edge.hip):
     (E, Q, K, V, yea, yem1) -> (E_out before symmetrisation / masking, wV).  Saves its inputs and (wV, lse) only; the
@@ -310,7 +377,7 @@ def _layer_fused(layer, hX, hE, hy, m, node_mask, mask_u8, offdiag, dl, base):
     newX = _lin(a.x_out, _lin(a.y_x_add, hy)[:, None, :] + (_lin(a.y_x_mul, hy)[:, None, :] + 1.0) * wV) * xm
     new_y = None
     if a.predicts_y:
-        z = _lin(a.y_y, hy) + _lin(a.x_y.lin, _node_stats(hX, m)) + _lin(a.e_y.lin, _edge_stats(hE, m))
+        z = _lin(a.y_y, hy) + _lin(a.x_y.lin, _node_stats(hX, m)) + _lin(a.e_y.lin, _EdgeStats.apply(hE, m))
         new_y = _lin(a.y_out[2], torch.relu(_lin(a.y_out[0], z)))
     dl.site = base
     hX = _ln(layer.normX1, hX + dl(newX))
@@ -342,12 +409,15 @@ def train_forward(model, X, E, y, node_mask, seed=None, p_layer=None):
     offdiag = (1.0 - torch.eye(n, dtype=X.dtype, device=X.device))[None]
     oXc = model.out_dim_X + model.out_dim_charges
 
-    def mlp_in(seq, x):
-        return dio(torch.relu(_lin(seq[3], dio(torch.relu(_lin(seq[0], x))))))
+    import os
+    plin = _plin if os.environ.get("SCGG_TRAIN_MODE", "fused") != "eager" else _lin
 
-    def mlp_out(seq, x):
-        return _lin(seq[3], dio(torch.relu(_lin(seq[0], x))))
-    hE = mlp_in(model.mlp_in_E, E)
+    def mlp_in(seq, x, lin=_lin):
+        return dio(torch.relu(lin(seq[3], dio(torch.relu(lin(seq[0], x))))))
+
+    def mlp_out(seq, x, lin=_lin):
+        return lin(seq[3], dio(torch.relu(lin(seq[0], x))))
+    hE = mlp_in(model.mlp_in_E, E, plin)
     hE = (hE + hE.transpose(1, 2)) / 2
     hX = mlp_in(model.mlp_in_X, X)
     hy = mlp_in(model.mlp_in_y, y)
@@ -372,7 +442,7 @@ def train_forward(model, X, E, y, node_mask, seed=None, p_layer=None):
         hX, hE = _mask_xe(hX, hE, m, offdiag)
     dio.site = 50
     oX = mlp_out(model.mlp_out_X, hX) + X[..., :oXc]
-    oE = (mlp_out(model.mlp_out_E, hE) + E[..., : model.out_dim_E]) * offdiag[..., None]
+    oE = (mlp_out(model.mlp_out_E, hE, plin) + E[..., : model.out_dim_E]) * offdiag[..., None]
     oE = 0.5 * (oE + oE.transpose(1, 2))
     oy = mlp_out(model.mlp_out_y, hy) + y[..., : model.out_dim_y] if model.predicts_final_y else None
     oX, oE = _mask_xe(oX, oE, m, offdiag)
