@@ -379,6 +379,11 @@ typedef struct scgg_train_edge_args {
   float *E_out, *part, *wV_out, *lse_out;
   const float *dOut, *dwV, *wV, *lse;
   float *dE, *G_e, *G_da, *G_z, *G_dnewE, *G_h1, *G_df, *G_f, *G_do, *G_dkv, *upart;
+  /* backward, optional (all NULL: none): the gradient of Etoy's pooled statistics of E (scgg_train_edge_stats) is added to
+   * dE: st_mean [B,de]; st_cm = g_mean / count; st_cv = 2 g_var / count; st_gmi / st_gma = g_min / g_max; st_imn / st_imx =
+   * pair index i n + j of the extrema */
+  const float *st_mean, *st_cm, *st_cv, *st_gmi, *st_gma;
+  const int32_t *st_imn, *st_imx;
   int32_t B, n, nch, dx, de, ffe;
   float inv_sqrt_df, p;
   uint32_t k0, k1, site1, site2, site3;
@@ -389,6 +394,11 @@ int scgg_train_edge_backward(const scgg_train_edge_args* a, void* stream);
 /* the weight gradient of one Linear from the backward's factors (what autograd's `grad_out.T @ input` and
  * `grad_out.sum(0)` do for nn.Linear): G [S,M], X [S,N] -> partial [scgg_train_wgrad_slabs(S, slab)][M*N + M]; slab w holds
  * G^T X and the column sums of G over the slots [w slab, (w+1) slab); the caller adds the slabs.  M, N, slab multiples of 16. */
+/* Etoy's pooling of the layer input for the y update (layers.py:34-41), one read of E: per graph b and slice s (rows i = s,
+ * s + slices, ...) out[b][s] = [count | mean | M2 | min | max] x de and idx[b][s] = [argmin | argmax] x de (pair index i n + j);
+ * the caller merges the slices (pairwise variance update). */
+int scgg_train_edge_stats(const float* E, const uint8_t* mask, int32_t B, int32_t n, int32_t de, int32_t slices, float* out,
+                          int32_t* idx, void* stream);
 int64_t scgg_train_wgrad_slabs(int64_t S, int32_t slab);
 int scgg_train_wgrad(const float* G, int32_t M, const float* X, int32_t N, int64_t S, int32_t slab, float* partial, void* stream);
 

@@ -39,7 +39,7 @@ class TrainEdgeArgs(C.Structure):       # scgg_train_edge_args (include/scgg.h)
     _PTRS = ("E", "Q", "K", "V", "yea", "yem1", "mask", "F_mul", "F_add", "F_out", "F_ff1", "F_ff2", "F_mulT", "F_addT", "F_outT",
              "F_ff1T", "F_ff2T", "b_mul", "b_add", "b_out", "g1", "b1", "b_ff1", "b_ff2", "g2", "b2", "E_out", "part", "wV_out",
              "lse_out", "dOut", "dwV", "wV", "lse", "dE", "G_e", "G_da", "G_z", "G_dnewE", "G_h1", "G_df", "G_f", "G_do", "G_dkv",
-             "upart")
+             "upart", "st_mean", "st_cm", "st_cv", "st_gmi", "st_gma", "st_imn", "st_imx")
     _fields_ = [(k, C.c_void_p) for k in _PTRS] + [(k, C.c_int32) for k in ("B", "n", "nch", "dx", "de", "ffe")] + \
                [("inv_sqrt_df", C.c_float), ("p", C.c_float)] + [(k, C.c_uint32) for k in ("k0", "k1", "site1", "site2", "site3")]
 
@@ -48,6 +48,7 @@ SIGNATURES = {
     "scgg_train_edge_pack": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "scgg_train_edge_forward": (C.c_int, [C.POINTER(TrainEdgeArgs), _vp]),
     "scgg_train_edge_backward": (C.c_int, [C.POINTER(TrainEdgeArgs), _vp]),
+    "scgg_train_edge_stats": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "scgg_train_wgrad_slabs": (_i64, [_i64, _i32]),
     "scgg_train_wgrad": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp]),
     "scgg_version": (C.c_int, []),

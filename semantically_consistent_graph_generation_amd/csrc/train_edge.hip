@@ -451,6 +451,22 @@ __global__ __launch_bounds__(256) void train_edge_bwd_kernel(TArgs a) {
       mfma4(dr1[eb], frag(a.F_addT, eb * XB + xb, lane), da2);
     }
   }
+  // the pooled statistics of E feed the y update (Etoy): their gradient lands on the same element
+  if (a.st_mean != nullptr) {
+    const int pidx = u.i * a.n + u.jj;
+#pragma unroll
+    for (int eb = 0; eb < IBE; ++eb) {
+      const int c = u.b * DE + 16 * eb + 4 * g;
+      const f32x4 mean = ld4(a.st_mean + c), cm = ld4(a.st_cm + c), cv = ld4(a.st_cv + c), gmi = ld4(a.st_gmi + c), gma = ld4(a.st_gma + c);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float add = cm[r] + cv[r] * (e[eb][r] - mean[r]);
+        if (a.st_imn[c + r] == pidx) add += gmi[r];
+        if (a.st_imx[c + r] == pidx) add += gma[r];
+        dr1[eb][r] += add;
+      }
+    }
+  }
   if (u.inb)
 #pragma unroll
     for (int eb = 0; eb < IBE; ++eb) *reinterpret_cast<f32x4*>(dEp + 16 * eb) = u.vj ? dr1[eb] : splat4(0.f);
@@ -469,6 +485,82 @@ __global__ __launch_bounds__(256) void train_edge_pack_kernel(const float* W, in
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = transpose ? W[(size_t)(c0 + e) * cols + r] : W[(size_t)r * cols + c0 + e];
   reinterpret_cast<f32x4*>(out)[idx] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Etoy's pooled statistics of the layer input (layers.py:34-41) for the y update: per graph and channel, over the pairs of
+// valid nodes (zero diagonal included): count, mean, M2 = sum (v - mean)^2, min, max and the flat pair index (i n + j) of
+// the two extrema (the backward routes the gradient of min / max to that one element, as `.min(dim)[0]` does).  Grid
+// (slices, B): workgroup (s, b) takes the rows i = s, s + slices, ...; thread = (4 channels, one of 256 / (de/4) key
+// lanes); each thread keeps sum and sum of squares of (v - k), k = its first value (no cancellation), slices of a
+// workgroup are merged with the pairwise update (Chan et al.), the workgroups of a graph by the host (tiny tensors).
+// out [B, slices, 5, de] floats (cnt replicated | mean | M2 | min | max), idx [B, slices, 2, de] int32.  One read of E.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void train_edge_stats_kernel(const float* __restrict__ E, const uint8_t* __restrict__ mask, int n,
+                                                               int DE, float* __restrict__ out, int* __restrict__ idx) {
+  __shared__ f32x4 sh[5][256];
+  __shared__ int shi[2][256][4];
+  const int tid = threadIdx.x, G4 = DE / 4, KL = 256 / G4, c4 = tid % G4, kl = tid / G4;
+  const int b = blockIdx.y, slices = gridDim.x;
+  const uint8_t* mb = mask + (size_t)b * n;
+  f32x4 k = splat4(0.f), s1 = k, q = k, mn = splat4(INFINITY), mx = splat4(-INFINITY);
+  int imn[4] = {0, 0, 0, 0}, imx[4] = {0, 0, 0, 0};
+  int cnt = 0;
+  for (int i = blockIdx.x; i < n; i += slices) {
+    if (mb[i] == 0) continue;
+    const float* row = E + ((size_t)b * n + i) * n * DE + 4 * c4;
+    for (int j = kl; j < n; j += KL) {
+      if (mb[j] == 0) continue;
+      const f32x4 v = ld4(row + (size_t)j * DE);
+      if (cnt == 0) k = v;
+      ++cnt;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[e] - k[e];
+        s1[e] += d; q[e] += d * d;
+        if (v[e] < mn[e]) { mn[e] = v[e]; imn[e] = i * n + j; }
+        if (v[e] > mx[e]) { mx[e] = v[e]; imx[e] = i * n + j; }
+      }
+    }
+  }
+  // per-thread (cnt, mean, M2)
+  f32x4 mean = k, M2 = splat4(0.f);
+  if (cnt > 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { mean[e] = k[e] + s1[e] / (float)cnt; M2[e] = q[e] - s1[e] * s1[e] / (float)cnt; }
+  }
+  sh[0][tid] = splat4((float)cnt); sh[1][tid] = mean; sh[2][tid] = M2; sh[3][tid] = mn; sh[4][tid] = mx;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { shi[0][tid][e] = imn[e]; shi[1][tid][e] = imx[e]; }
+  __syncthreads();
+  if (kl == 0) {
+    float ca = (float)cnt;
+    for (int t = 1; t < KL; ++t) {
+      const int o = t * G4 + c4;
+      const float cb = sh[0][o][0];
+      if (cb == 0.f) continue;
+      const f32x4 mb2 = sh[1][o], Mb2 = sh[2][o], nb = sh[3][o], xb = sh[4][o];
+      const float tot = ca + cb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = mb2[e] - mean[e];
+        M2[e] = ca == 0.f ? Mb2[e] : M2[e] + Mb2[e] + d * d * (ca * cb / tot);
+        mean[e] = ca == 0.f ? mb2[e] : mean[e] + d * (cb / tot);
+        if (nb[e] < mn[e] || (nb[e] == mn[e] && shi[0][o][e] < imn[e])) { mn[e] = nb[e]; imn[e] = shi[0][o][e]; }
+        if (xb[e] > mx[e] || (xb[e] == mx[e] && shi[1][o][e] < imx[e])) { mx[e] = xb[e]; imx[e] = shi[1][o][e]; }
+      }
+      ca = tot;
+    }
+    float* o = out + ((size_t)b * slices + blockIdx.x) * 5 * DE + 4 * c4;
+    *reinterpret_cast<f32x4*>(o) = splat4(ca);
+    *reinterpret_cast<f32x4*>(o + DE) = mean;
+    *reinterpret_cast<f32x4*>(o + 2 * DE) = M2;
+    *reinterpret_cast<f32x4*>(o + 3 * DE) = mn;
+    *reinterpret_cast<f32x4*>(o + 4 * DE) = mx;
+    int* oi = idx + ((size_t)b * slices + blockIdx.x) * 2 * DE + 4 * c4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { oi[e] = imn[e]; oi[DE + e] = imx[e]; }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -614,4 +706,13 @@ extern "C" int scgg_train_wgrad(const float* G, int32_t M, const float* X, int32
 #undef SCGG_WG
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail("train_wgrad: %s", hipGetErrorString(e));
+}
+
+extern "C" int scgg_train_edge_stats(const float* E, const uint8_t* mask, int32_t B, int32_t n, int32_t de, int32_t slices, float* out,
+                                     int32_t* idx, void* stream) {
+  if (!E || !mask || !out || !idx || B <= 0 || n <= 0 || slices <= 0) return fail("train_edge_stats: bad arguments");
+  if (de % 4 != 0 || 256 % (de / 4) != 0) return fail("train_edge_stats: de = %d not supported", de);
+  hipLaunchKernelGGL(train_edge_stats_kernel, dim3(slices, B), dim3(256), 0, static_cast<hipStream_t>(stream), E, mask, n, de, out, idx);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail("train_edge_stats: %s", hipGetErrorString(e));
 }

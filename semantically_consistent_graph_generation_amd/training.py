@@ -235,40 +235,6 @@ def _plin(m, x):
     return _PairLinear.apply(x, m.weight, m.bias)
 
 
-class _EdgeStats(torch.autograd.Function):
-    """Etoy's pooled statistics (layers.py:34-41: mean | min | max | biased variance over all pairs of a graph, the masked
-    pairs pushed out of min / max by +-1e5) with a closed-form backward: saves E (which the fused layer keeps anyway), the
-    mean and the two arg-extrema instead of the five [B,n,n,de] temporaries autograd would keep per layer.  The gradient
-    of min / max goes to one element (the reference's ``.min(dim)[0]`` picks one index as well)."""
-
-    @staticmethod
-    def forward(ctx, E, m):
-        B, n, _, d = E.shape
-        pmf = (m[:, :, None] * m[:, None, :]).reshape(B, n * n, 1)
-        cnt = pmf.sum(1)                                            # [B,1]
-        Ef = E.reshape(B, n * n, d)
-        mean = Ef.sum(1) / cnt
-        big = 1e5 * (1.0 - pmf)
-        mn, imn = (Ef + big).min(dim=1)
-        mx, imx = (Ef - big).max(dim=1)
-        var = (((Ef - mean[:, None, :]) ** 2) * pmf).sum(1) / cnt
-        ctx.save_for_backward(E, m, mean, imn, imx)
-        return torch.cat([mean, mn, mx, var], dim=1)
-
-    @staticmethod
-    def backward(ctx, g):
-        E, m, mean, imn, imx = ctx.saved_tensors
-        B, n, _, d = E.shape
-        pmf = (m[:, :, None] * m[:, None, :]).reshape(B, n * n, 1)
-        cnt = pmf.sum(1)
-        gm, gmi, gma, gv = g.split(d, dim=1)
-        Ef = E.reshape(B, n * n, d)
-        dE = (Ef - mean[:, None, :]) * pmf * (2.0 * gv / cnt)[:, None, :] + (gm / cnt)[:, None, :]
-        dE.scatter_add_(1, imn[:, None, :], gmi[:, None, :].contiguous())
-        dE.scatter_add_(1, imx[:, None, :], gma[:, None, :].contiguous())
-        return dE.view_as(E), None
-
-
 class _FusedEdgeLayer(torch.autograd.Function):
     """The [B,n,n,.] part of one XEyTransformerLayer in training mode as two HIP kernels (csrc/train_edge.hip):
     (E, Q, K, V, yea, yem1) -> (E_out before symmetrisation / masking, wV).  Saves its inputs and (wV, lse) only; the
@@ -276,7 +242,7 @@ class _FusedEdgeLayer(torch.autograd.Function):
     ``scgg_train_wgrad`` reduces those factors over the pair slots into the gradients of the five weight matrices."""
 
     @staticmethod
-    def forward(ctx, E, Q, K, V, yea, yem1, mask_u8, inv_sqrt_df, p, seed, sites,
+    def forward(ctx, E, Q, K, V, yea, yem1, mask_u8, inv_sqrt_df, p, seed, sites, with_stats,
                 W_mul, b_mul, W_add, b_add, W_out, b_out, g1, b1, W_ff1, b_ff1, W_ff2, b_ff2, g2, b2):
         B, n, _, de = E.shape
         dx, ffe = Q.shape[-1], W_ff1.shape[0]
@@ -305,16 +271,37 @@ class _FusedEdgeLayer(torch.autograd.Function):
         a.site1, a.site2, a.site3 = (int(v) for v in sites)
         _lib.check(_lib.lib().scgg_train_edge_forward(C.byref(a), _lib.stream_ptr()), "train_edge_forward")
         del keep
-        ctx.save_for_backward(E, Q, K, V, yea, yem1, mask_u8, wV, lse, *vecs, *[W.detach() for W in Ws])
+        # Etoy's pooled statistics of the layer INPUT (they feed the y update): one more read of E, merged over the slices
+        stats = torch.zeros(B, 4 * de, device=E.device)
+        st_keep = [torch.zeros(0, device=E.device)] * 2 + [torch.zeros(0, dtype=torch.int32, device=E.device)] * 2
+        if with_stats:
+            slices = max(1, min(n, 256 // max(B, 1)))
+            so = torch.empty(B, slices, 5, de, device=E.device)
+            si = torch.empty(B, slices, 2, de, dtype=torch.int32, device=E.device)
+            _lib.check(_lib.lib().scgg_train_edge_stats(_lib.ptr(E), _lib.ptr(mask_u8), B, n, de, slices, _lib.ptr(so), _lib.ptr(si),
+                                                        _lib.stream_ptr()), "train_edge_stats")
+            cnt, mean_s, M2_s = so[:, :, 0], so[:, :, 1], so[:, :, 2]
+            tot = cnt.sum(1).clamp(min=1.0)
+            mean = (cnt * mean_s).sum(1) / tot
+            M2 = M2_s.sum(1) + (cnt * (mean_s - mean[:, None]) ** 2).sum(1)
+            mn, amn = so[:, :, 3].min(1)
+            mx, amx = so[:, :, 4].max(1)
+            imn = si[:, :, 0].gather(1, amn[:, None]).squeeze(1).contiguous()
+            imx = si[:, :, 1].gather(1, amx[:, None]).squeeze(1).contiguous()
+            stats = torch.cat([mean, mn, mx, M2 / tot], dim=1)
+            st_keep = [mean.contiguous(), tot.contiguous(), imn, imx]
+        ctx.with_stats = bool(with_stats)
+        ctx.save_for_backward(E, Q, K, V, yea, yem1, mask_u8, wV, lse, *vecs, *[W.detach() for W in Ws], *st_keep)
         ctx.cfg = (float(inv_sqrt_df), a.p, sd, tuple(int(v) for v in sites))
         ctx.mark_non_differentiable(lse)
-        return E_out, wV, lse
+        return E_out, wV, lse, stats
 
     @staticmethod
-    def backward(ctx, dOut, dwV, _dlse):
+    def backward(ctx, dOut, dwV, _dlse, dstats):
         E, Q, K, V, yea, yem1, mask_u8, wV, lse = ctx.saved_tensors[:9]
         vecs = list(ctx.saved_tensors[9:18])
         Ws = list(ctx.saved_tensors[18:23])
+        st_mean, st_tot, st_imn, st_imx = ctx.saved_tensors[23:27]
         inv_sqrt_df, p, sd, sites = ctx.cfg
         B, n, _, de = E.shape
         dx, ffe = Q.shape[-1], Ws[3].shape[0]
@@ -341,6 +328,11 @@ class _FusedEdgeLayer(torch.autograd.Function):
         a.dOut, a.dwV, a.wV, a.lse, a.dE, a.upart = dOut.data_ptr(), dwV.data_ptr(), wV.data_ptr(), lse.data_ptr(), dE.data_ptr(), upart.data_ptr()
         for k, t in G.items():
             setattr(a, k, t.data_ptr())
+        if ctx.with_stats and dstats is not None:
+            gm, gmi, gma, gv = (t.contiguous() for t in dstats.float().split(de, dim=1))
+            st = [st_mean, (gm / st_tot).contiguous(), (2.0 * gv / st_tot).contiguous(), gmi, gma]
+            a.st_mean, a.st_cm, a.st_cv, a.st_gmi, a.st_gma = (t.data_ptr() for t in st)
+            a.st_imn, a.st_imx = st_imn.data_ptr(), st_imx.data_ptr()
         a.B, a.n, a.nch, a.dx, a.de, a.ffe = B, n, nch, dx, de, ffe
         a.inv_sqrt_df, a.p = inv_sqrt_df, p
         a.k0, a.k1 = sd & 0xFFFFFFFF, (sd >> 32) & 0xFFFFFFFF
@@ -359,7 +351,7 @@ class _FusedEdgeLayer(torch.autograd.Function):
         dkv = G["G_dkv"].view(B, n, nch * 16, 2 * dx).sum(1)[:, :n]
         dK, dV = dkv[..., :dx].contiguous(), dkv[..., dx:].contiguous()
         dyea = G["G_dnewE"].view(B, n * nch * 16, de).sum(1) @ Ws[2]          # sum of dz = W_out^T sum of dnewE, per graph
-        return (dE, dQ, dK, dV, dyea, dyem1, None, None, None, None, None,
+        return (dE, dQ, dK, dV, dyea, dyem1, None, None, None, None, None, None,
                 dW_ma[:dx], db_ma[:dx], dW_ma[dx:], db_ma[dx:], dW_out, db_out, dg1, db1, dW_ff1, db_ff1, dW_ff2, db_ff2, dg2, db2)
 
 
@@ -369,15 +361,15 @@ def _layer_fused(layer, hX, hE, hy, m, node_mask, mask_u8, offdiag, dl, base):
     a = layer.self_attn
     xm = m[:, :, None]
     Q, K, V = _lin(a.q, hX) * xm, _lin(a.k, hX) * xm, _lin(a.v, hX) * xm
-    E_raw, wV, _ = _FusedEdgeLayer.apply(
+    E_raw, wV, _, e_stats = _FusedEdgeLayer.apply(
         hE, Q, K, V, _lin(a.y_e_add, hy), _lin(a.y_e_mul, hy) + 1.0, mask_u8, 1.0 / math.sqrt(a.df), dl.p, dl.seed,
-        (base + 3, base + 4, base + 5), a.e_mul.weight, a.e_mul.bias, a.e_add.weight, a.e_add.bias, a.e_out.weight, a.e_out.bias,
+        (base + 3, base + 4, base + 5), bool(a.predicts_y), a.e_mul.weight, a.e_mul.bias, a.e_add.weight, a.e_add.bias, a.e_out.weight, a.e_out.bias,
         layer.normE1.weight, layer.normE1.bias, layer.linE1.weight, layer.linE1.bias, layer.linE2.weight, layer.linE2.bias,
         layer.normE2.weight, layer.normE2.bias)
     newX = _lin(a.x_out, _lin(a.y_x_add, hy)[:, None, :] + (_lin(a.y_x_mul, hy)[:, None, :] + 1.0) * wV) * xm
     new_y = None
     if a.predicts_y:
-        z = _lin(a.y_y, hy) + _lin(a.x_y.lin, _node_stats(hX, m)) + _lin(a.e_y.lin, _EdgeStats.apply(hE, m))
+        z = _lin(a.y_y, hy) + _lin(a.x_y.lin, _node_stats(hX, m)) + _lin(a.e_y.lin, e_stats)
         new_y = _lin(a.y_out[2], torch.relu(_lin(a.y_out[0], z)))
     dl.site = base
     hX = _ln(layer.normX1, hX + dl(newX))
