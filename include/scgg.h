@@ -385,6 +385,7 @@ typedef struct scgg_train_edge_args {
   const float *st_mean, *st_cm, *st_cv, *st_gmi, *st_gma;
   const int32_t *st_imn, *st_imx;
   int32_t B, n, nch, dx, de, ffe;
+  int32_t b0;   /* the call covers graphs [b0, b0 + B) of a larger batch (all pointers already offset): only the dropout stream sees it */
   float inv_sqrt_df, p;
   uint32_t k0, k1, site1, site2, site3;
 } scgg_train_edge_args;

@@ -40,7 +40,7 @@ class TrainEdgeArgs(C.Structure):       # scgg_train_edge_args (include/scgg.h)
              "F_ff1T", "F_ff2T", "b_mul", "b_add", "b_out", "g1", "b1", "b_ff1", "b_ff2", "g2", "b2", "E_out", "part", "wV_out",
              "lse_out", "dOut", "dwV", "wV", "lse", "dE", "G_e", "G_da", "G_z", "G_dnewE", "G_h1", "G_df", "G_f", "G_do", "G_dkv",
              "upart", "st_mean", "st_cm", "st_cv", "st_gmi", "st_gma", "st_imn", "st_imx")
-    _fields_ = [(k, C.c_void_p) for k in _PTRS] + [(k, C.c_int32) for k in ("B", "n", "nch", "dx", "de", "ffe")] + \
+    _fields_ = [(k, C.c_void_p) for k in _PTRS] + [(k, C.c_int32) for k in ("B", "n", "nch", "dx", "de", "ffe", "b0")] + \
                [("inv_sqrt_df", C.c_float), ("p", C.c_float)] + [(k, C.c_uint32) for k in ("k0", "k1", "site1", "site2", "site3")]
 
 

@@ -184,7 +184,7 @@ __device__ __forceinline__ void tail_fwd(const TArgs& a, const UnitId& u, const 
   const int g = lane >> 4;
   const bool drop = a.p > 0.f;
   const float denom = 1.0f - a.p;
-  const unsigned long long pair = (unsigned long long)u.row * a.n + u.jj;
+  const unsigned long long pair = ((unsigned long long)a.b0 * a.n + u.row) * a.n + u.jj;   // GLOBAL pair index: the dropout stream
   f32x4 r1[IBE];
 #pragma unroll
   for (int eb = 0; eb < IBE; ++eb) {
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void train_edge_bwd_kernel(TArgs a) {
   }
   const bool drop = a.p > 0.f;
   const float denom = 1.0f - a.p;
-  const unsigned long long pair = (unsigned long long)u.row * a.n + u.jj;
+  const unsigned long long pair = ((unsigned long long)a.b0 * a.n + u.row) * a.n + u.jj;   // GLOBAL pair index: the dropout stream
 
   // ---- recompute the forward
   f32x4 e[IBE], newE[IBE];

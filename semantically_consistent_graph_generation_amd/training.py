@@ -189,12 +189,14 @@ def _pack(W, transpose):
     return out
 
 
-def _wgrad(G, X, slab=1024):
+def _wgrad(G, X, slab=None):
     """(G^T X, G.sum(0)) for the factor tensors of the backward kernel: split over the pair slots in the library's own
     MFMA kernel (HBM-bound; the generic GEMM took 0.6 ms per call at K = 2.6e5), slabs added in a fixed order."""
     S, M = G.shape
     N = X.shape[1]
     L = _lib.lib()
+    if slab is None:                       # at least ~2 workgroups per CU, slabs of 64 .. 1024 slots
+        slab = max(64, min(1024, (S // 512) // 16 * 16))
     nsl = int(L.scgg_train_wgrad_slabs(S, slab))
     partial = torch.empty(nsl, M * N + M, device=G.device)
     _lib.check(L.scgg_train_wgrad(_lib.ptr(G), M, _lib.ptr(X), N, S, slab, _lib.ptr(partial), _lib.stream_ptr()), "train_wgrad")
@@ -322,35 +324,52 @@ class _FusedEdgeLayer(torch.autograd.Function):
         for k, t in zip(("b_mul", "b_add", "b_out", "g1", "b1", "b_ff1", "b_ff2", "g2", "b2"), vecs):
             setattr(a, k, t.data_ptr())
         dE = torch.empty_like(E)
-        G = {k: torch.empty(S, w, device=dev) for k, w in (("G_e", de), ("G_da", 2 * dx), ("G_z", dx), ("G_dnewE", de), ("G_h1", de),
-                                                          ("G_df", ffe), ("G_f", ffe), ("G_do", de), ("G_dkv", 2 * dx))}
-        upart = torch.empty(B * n * nch, 2 * dx + 4 * de, device=dev)
-        a.dOut, a.dwV, a.wV, a.lse, a.dE, a.upart = dOut.data_ptr(), dwV.data_ptr(), wV.data_ptr(), lse.data_ptr(), dE.data_ptr(), upart.data_ptr()
-        for k, t in G.items():
-            setattr(a, k, t.data_ptr())
+        st = None
         if ctx.with_stats and dstats is not None:
             gm, gmi, gma, gv = (t.contiguous() for t in dstats.float().split(de, dim=1))
             st = [st_mean, (gm / st_tot).contiguous(), (2.0 * gv / st_tot).contiguous(), gmi, gma]
-            a.st_mean, a.st_cm, a.st_cv, a.st_gmi, a.st_gma = (t.data_ptr() for t in st)
-            a.st_imn, a.st_imx = st_imn.data_ptr(), st_imx.data_ptr()
-        a.B, a.n, a.nch, a.dx, a.de, a.ffe = B, n, nch, dx, de, ffe
+        # The factor tensors are the backward's transient memory (4.3 KB per pair slot): the batch is walked in chunks of
+        # graphs so that they stay below ~0.6 GB; gradients of shared parameters add up over the chunks.
+        per_graph = n * nch * 16 * (4 * de + 2 * ffe + 5 * dx) * 4
+        Bc = max(1, min(B, int(0.6 * 2 ** 30) // max(per_graph, 1)))
+        Sc = Bc * n * nch * 16
+        G = {k: torch.empty(Sc, w, device=dev) for k, w in (("G_e", de), ("G_da", 2 * dx), ("G_z", dx), ("G_dnewE", de), ("G_h1", de),
+                                                           ("G_df", ffe), ("G_f", ffe), ("G_do", de), ("G_dkv", 2 * dx))}
+        upart = torch.empty(Bc * n * nch, 2 * dx + 4 * de, device=dev)
+        for k, t in G.items():
+            setattr(a, k, t.data_ptr())
+        a.upart = upart.data_ptr()
+        a.n, a.nch, a.dx, a.de, a.ffe = n, nch, dx, de, ffe
         a.inv_sqrt_df, a.p = inv_sqrt_df, p
         a.k0, a.k1 = sd & 0xFFFFFFFF, (sd >> 32) & 0xFFFFFFFF
         a.site1, a.site2, a.site3 = sites
-        _lib.check(_lib.lib().scgg_train_edge_backward(C.byref(a), _lib.stream_ptr()), "train_edge_backward")
-        # weight gradients: dW = G_g^T G_x, the pair slot as the reduction index (library GEMMs on the kernel's factors)
-        dW_ma, db_ma = _wgrad(G["G_da"], G["G_e"])             # [2dx, de] = d e_mul.weight | d e_add.weight
-        dW_out, db_out = _wgrad(G["G_dnewE"], G["G_z"])
-        dW_ff1, db_ff1 = _wgrad(G["G_df"], G["G_h1"])
-        dW_ff2, db_ff2 = _wgrad(G["G_do"], G["G_f"])
-        up = upart.view(B, n, nch, -1)
-        dQ = up[..., :dx].sum(2) * inv_sqrt_df
-        dyem1 = up[..., dx:2 * dx].sum((1, 2))
-        ln = up[..., 2 * dx:].sum((0, 1, 2))
+        acc = None
+        dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+        dyea, dyem1 = torch.empty_like(yea), torch.empty_like(yem1)
+        for b0 in range(0, B, Bc):
+            nb = min(Bc, B - b0)
+            for k, t in (("E", E), ("Q", Q), ("K", K), ("V", V), ("yea", yea), ("yem1", yem1), ("mask", mask_u8), ("dOut", dOut),
+                         ("dwV", dwV), ("wV", wV), ("lse", lse), ("dE", dE)):
+                setattr(a, k, t[b0:].data_ptr())
+            if st is not None:
+                a.st_mean, a.st_cm, a.st_cv, a.st_gmi, a.st_gma = (t[b0:].data_ptr() for t in st)
+                a.st_imn, a.st_imx = st_imn[b0:].data_ptr(), st_imx[b0:].data_ptr()
+            a.B, a.b0 = nb, b0
+            _lib.check(_lib.lib().scgg_train_edge_backward(C.byref(a), _lib.stream_ptr()), "train_edge_backward")
+            Sn = nb * n * nch * 16
+            Gn = {k: t[:Sn] for k, t in G.items()}
+            parts = [_wgrad(Gn["G_da"], Gn["G_e"]),              # [2dx, de] = d e_mul.weight | d e_add.weight
+                     _wgrad(Gn["G_dnewE"], Gn["G_z"]), _wgrad(Gn["G_df"], Gn["G_h1"]), _wgrad(Gn["G_do"], Gn["G_f"])]
+            up = upart[: nb * n * nch].view(nb, n, nch, -1)
+            parts.append((up[..., 2 * dx:].sum((0, 1, 2)),))
+            acc = parts if acc is None else [tuple(x + y for x, y in zip(pa, pb)) for pa, pb in zip(acc, parts)]
+            dQ[b0:b0 + nb] = up[..., :dx].sum(2) * inv_sqrt_df
+            dyem1[b0:b0 + nb] = up[..., dx:2 * dx].sum((1, 2))
+            dkv = Gn["G_dkv"].view(nb, n, nch * 16, 2 * dx).sum(1)[:, :n]
+            dK[b0:b0 + nb], dV[b0:b0 + nb] = dkv[..., :dx], dkv[..., dx:]
+            dyea[b0:b0 + nb] = Gn["G_dnewE"].view(nb, n * nch * 16, de).sum(1) @ Ws[2]    # sum of dz = W_out^T sum of dnewE, per graph
+        (dW_ma, db_ma), (dW_out, db_out), (dW_ff1, db_ff1), (dW_ff2, db_ff2), (ln,) = acc
         dg2, db2, dg1, db1 = ln[:de], ln[de:2 * de], ln[2 * de:3 * de], ln[3 * de:]
-        dkv = G["G_dkv"].view(B, n, nch * 16, 2 * dx).sum(1)[:, :n]
-        dK, dV = dkv[..., :dx].contiguous(), dkv[..., dx:].contiguous()
-        dyea = G["G_dnewE"].view(B, n * nch * 16, de).sum(1) @ Ws[2]          # sum of dz = W_out^T sum of dnewE, per graph
         return (dE, dQ, dK, dV, dyea, dyem1, None, None, None, None, None, None,
                 dW_ma[:dx], db_ma[:dx], dW_ma[dx:], db_ma[dx:], dW_out, db_out, dg1, db1, dW_ff1, db_ff1, dW_ff2, db_ff2, dg2, db2)
 
