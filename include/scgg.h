@@ -393,8 +393,9 @@ int scgg_train_edge_pack(const float* W, int32_t rows, int32_t cols, int32_t tra
 int scgg_train_edge_forward(const scgg_train_edge_args* a, void* stream);
 int scgg_train_edge_backward(const scgg_train_edge_args* a, void* stream);
 /* the weight gradient of one Linear from the backward's factors (what autograd's `grad_out.T @ input` and
- * `grad_out.sum(0)` do for nn.Linear): G [S,M], X [S,N] -> partial [scgg_train_wgrad_slabs(S, slab)][M*N + M]; slab w holds
- * G^T X and the column sums of G over the slots [w slab, (w+1) slab); the caller adds the slabs.  M, N, slab multiples of 16. */
+ * `grad_out.sum(0)` do for nn.Linear): G [S,M], X [S,N] -> partial [scgg_train_wgrad_slabs(S, slab)][M*N + M]; every partial
+ * holds G^T X and the column sums of G over a quarter of a slab of `slab` slots; the caller adds the partials (every
+ * element of every partial is written).  M, N, slab multiples of 16. */
 /* Etoy's pooling of the layer input for the y update (layers.py:34-41), one read of E: per graph b and slice s (rows i = s,
  * s + slices, ...) out[b][s] = [count | mean | M2 | min | max] x de and idx[b][s] = [argmin | argmax] x de (pair index i n + j);
  * the caller merges the slices (pairwise variance update). */

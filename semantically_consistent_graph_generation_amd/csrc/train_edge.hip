@@ -565,63 +565,64 @@ __global__ __launch_bounds__(256) void train_edge_stats_kernel(const float* __re
 
 // ---------------------------------------------------------------------------------------------------------
 // Weight gradient: C[M,N] = G^T X and c[M] = column sums of G, G [S,M] and X [S,N] row-major factors written by the
-// backward kernel, S = pair slots (the reduction index, ~2.6e5 at B = 4, n = 256).  Split over S: workgroup w reduces
-// the slab [w slab, (w+1) slab) into partial[w] ([M, N] then [M] bias sums); the host adds the slabs in a fixed order
-// (deterministic, no atomics).  Wave v of the 4 owns the 16-row blocks v, v+4, ... of C; a K step takes 16 slots: lane
-// (m = l & 15, k = l >> 4) supplies G[s0 + 4k + r][16 mb + m] as A and X[s0 + 4k + r][16 nb + m] as B of
-// v_mfma_f32_16x16x4_f32 (64-byte runs per row: the factors are read once from HBM, the reuse across waves is cache).
-// The bias sums ride along as one more B block whose column 0 is all ones.  Bound: HBM (reads (M + N) 4 bytes per slot).
+// backward kernel, S = pair slots (the reduction index, ~2.6e5 at B = 4, n = 256).  Bound: HBM (reads (M + N) 4 bytes per
+// slot).  Grid (slabs, 64x64 output tiles); the 4 waves of a workgroup take the slots of their slab four at a time,
+// interleaved, and each wave writes its OWN partial tile (partial index 4 slab + wave): the host adds the partials in a
+// fixed order (deterministic, no atomics, no LDS).
+// Operand trick: lane (m = l & 15, k = l >> 4) loads ONE float4 = G[s0 + k][64 mt + 4m .. 4m+3] (a slot's 64 channels are 256
+// contiguous bytes over the 16 lanes) and register j of that float4 is the A operand of MFMA j: its row m then stands for
+// channel 4m + j.  X likewise as B.  The 16 MFMAs (j, j') of a step cover the 64 x 64 tile over 4 slots from two 1-KiB loads.
+// The bias sums ride along as a B operand of ones (column 0), for tile column 0 only.
 // ---------------------------------------------------------------------------------------------------------
-template <int MW, int NB>
-__global__ __launch_bounds__(256) void train_wgrad_kernel(const float* __restrict__ G, int M, const float* __restrict__ X, long long S,
-                                                          int slab, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void train_wgrad_kernel(const float* __restrict__ G, int M, const float* __restrict__ X, int N,
+                                                          long long S, int slab, float* __restrict__ partial) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, k = lane >> 4;
-  constexpr int N = 16 * NB;
-  const int Mb = M / 16;
+  const int ntn = (N + 63) / 64;
+  const int mt = blockIdx.y / ntn, nt = blockIdx.y - mt * ntn;
   const long long s_begin = (long long)blockIdx.x * slab;
   const long long s_end = s_begin + slab < S ? s_begin + slab : S;
-  f32x4 acc[MW][NB], accb[MW];
+  const int gc = 64 * mt + 4 * m, xc = 64 * nt + 4 * m;
+  const bool g_ok = gc < M, x_ok = xc < N;                   // widths are multiples of 16 >= 16: a float4 is in or out as a whole
+  f32x4 acc[4][4], accb[4];
 #pragma unroll
-  for (int i = 0; i < MW; ++i) {
-    accb[i] = splat4(0.f);
+  for (int j = 0; j < 4; ++j) {
+    accb[j] = splat4(0.f);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) acc[i][j] = splat4(0.f);
+    for (int i = 0; i < 4; ++i) acc[j][i] = splat4(0.f);
   }
   const float one = m == 0 ? 1.0f : 0.f;
-  for (long long s0 = s_begin; s0 < s_end; s0 += 16) {
+  const bool bias = nt == 0;
+  const float* Gp = G + gc;
+  const float* Xp = X + xc;
+#pragma unroll 2
+  for (long long s0 = s_begin + 4 * wave; s0 < s_end; s0 += 16) {
+    const long long slot = s0 + k;
+    const bool ok = slot < s_end;
+    const f32x4 gv = (ok && g_ok) ? ld4(Gp + slot * M) : splat4(0.f);
+    const f32x4 xv = (ok && x_ok) ? ld4(Xp + slot * N) : splat4(0.f);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long long slot = s0 + 4 * k + r;
-      const bool ok = slot < s_end;
-      float av[MW], bv[NB];
+    for (int j = 0; j < 4; ++j) {
 #pragma unroll
-      for (int i = 0; i < MW; ++i) {
-        const int mb = wave + 4 * i;
-        av[i] = (ok && mb < Mb) ? G[slot * M + 16 * mb + m] : 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < NB; ++j) bv[j] = ok ? X[slot * N + 16 * j + m] : 0.f;
-#pragma unroll
-      for (int i = 0; i < MW; ++i) {
-#pragma unroll
-        for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        accb[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], ok ? one : 0.f, accb[i], 0, 0, 0);
-      }
+      for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[j], xv[i], acc[j][i], 0, 0, 0);
+      if (bias) accb[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[j], ok ? one : 0.f, accb[j], 0, 0, 0);
     }
   }
-  float* out = partial + (size_t)blockIdx.x * ((size_t)M * N + M);
+  // acc[j][i][e]: row (4 k + e) of MFMA (j, i) = G channel 64 mt + 4 (4k + e) + j; column m = X channel 64 nt + 4 m + i
+  float* out = partial + ((size_t)blockIdx.x * 4 + wave) * ((size_t)M * N + M);
 #pragma unroll
-  for (int i = 0; i < MW; ++i) {
-    const int mb = wave + 4 * i;
-    if (mb >= Mb) continue;
+  for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int row = 16 * mb + 4 * k + e;
+      const int row = 64 * mt + 4 * (4 * k + e) + j;
+      if (row >= M) continue;
+      if (x_ok) {
+        f32x4 v;
 #pragma unroll
-      for (int j = 0; j < NB; ++j) out[(size_t)row * N + 16 * j + m] = acc[i][j][e];
-      if (m == 0) out[(size_t)M * N + row] = accb[i][e];
+        for (int i = 0; i < 4; ++i) v[i] = acc[j][i][e];
+        *reinterpret_cast<f32x4*>(out + (size_t)row * N + xc) = v;
+      }
+      if (bias && m == 0) out[(size_t)M * N + row] = accb[j][e];
     }
-  }
 }
 
 int check_args(const TArgs* a, bool bwd) {
@@ -680,30 +681,17 @@ extern "C" int scgg_train_edge_backward(const scgg_train_edge_args* a, void* str
   return e == hipSuccess ? 0 : fail("train_edge_backward: %s", hipGetErrorString(e));
 }
 
-extern "C" int64_t scgg_train_wgrad_slabs(int64_t S, int32_t slab) { return (S <= 0 || slab <= 0) ? 0 : (S + slab - 1) / slab; }
+extern "C" int64_t scgg_train_wgrad_slabs(int64_t S, int32_t slab) { return (S <= 0 || slab <= 0) ? 0 : 4 * ((S + slab - 1) / slab); }
 
 extern "C" int scgg_train_wgrad(const float* G, int32_t M, const float* X, int32_t N, int64_t S, int32_t slab, float* partial,
                                 void* stream) {
   if (!G || !X || !partial || S <= 0) return fail("train_wgrad: bad arguments");
   if (M < 16 || M % 16 != 0 || N < 16 || N % 16 != 0 || slab < 16 || slab % 16 != 0) return fail("train_wgrad: M, N, slab must be multiples of 16");
-  const int Mb = M / 16, NB = N / 16, MW = (Mb + 3) / 4;
   const long long nsl = (S + slab - 1) / slab;
-  if (nsl > 0x7fffffffLL) return fail("train_wgrad: too many slabs");
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid((unsigned)nsl), blk(256);
-#define SCGG_WG(mw, nb) hipLaunchKernelGGL((train_wgrad_kernel<mw, nb>), grid, blk, 0, st, G, (int)M, X, (long long)S, (int)slab, partial)
-  if (MW <= 1 && NB == 1) SCGG_WG(1, 1);
-  else if (MW == 2 && NB == 1) SCGG_WG(2, 1);
-  else if (MW <= 1 && NB == 2) SCGG_WG(1, 2);
-  else if (MW <= 1 && NB == 4) SCGG_WG(1, 4);
-  else if (MW <= 1 && NB == 8) SCGG_WG(1, 8);
-  else if (MW <= 1 && NB == 16) SCGG_WG(1, 16);
-  else if (MW == 2 && NB == 2) SCGG_WG(2, 2);
-  else if (MW == 2 && NB == 4) SCGG_WG(2, 4);
-  else if (MW <= 4 && NB == 4) SCGG_WG(4, 4);
-  else if (MW <= 8 && NB == 4) SCGG_WG(8, 4);
-  else return fail("train_wgrad: shape M = %d, N = %d not built", (int)M, (int)N);
-#undef SCGG_WG
+  const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  if (nsl > 0x7fffffffLL || tiles > 65535) return fail("train_wgrad: too many slabs / tiles");
+  hipLaunchKernelGGL(train_wgrad_kernel, dim3((unsigned)nsl, (unsigned)tiles), dim3(256), 0, static_cast<hipStream_t>(stream), G, (int)M, X,
+                     (int)N, (long long)S, (int)slab, partial);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail("train_wgrad: %s", hipGetErrorString(e));
 }

@@ -195,16 +195,14 @@ def _wgrad(G, X, slab=None):
     S, M = G.shape
     N = X.shape[1]
     L = _lib.lib()
-    if slab is None:                       # at least ~2 workgroups per CU, slabs of 64 .. 1024 slots
-        slab = max(64, min(1024, (S // 512) // 16 * 16))
+    if slab is None:                       # ~4 workgroups per CU over (slabs x 64x64 tiles), slabs of 256 .. 4096 slots
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        slab = max(256, min(4096, (S * tiles // 1024) // 16 * 16))
     nsl = int(L.scgg_train_wgrad_slabs(S, slab))
     partial = torch.empty(nsl, M * N + M, device=G.device)
     _lib.check(L.scgg_train_wgrad(_lib.ptr(G), M, _lib.ptr(X), N, S, slab, _lib.ptr(partial), _lib.stream_ptr()), "train_wgrad")
     tot = partial.sum(0)
     return tot[: M * N].view(M, N), tot[M * N:]
-
-
-_WGRAD_SHAPES = {(1, 1), (2, 1), (1, 2), (1, 4), (1, 8), (1, 16), (2, 2), (2, 4), (4, 4), (8, 4)}     # (ceil(M/64), N/16) built
 
 
 class _PairLinear(torch.autograd.Function):
@@ -223,7 +221,7 @@ class _PairLinear(torch.autograd.Function):
         g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
         M, N = g2.shape[1], x2.shape[1]
         Mp, Np = (M + 15) // 16 * 16, (N + 15) // 16 * 16
-        if ((Mp // 16 + 3) // 4, Np // 16) in _WGRAD_SHAPES and g2.shape[0] >= 4096:
+        if g2.shape[0] >= 4096:
             gp = g2.contiguous() if Mp == M else F.pad(g2, (0, Mp - M))
             xp = x2.contiguous() if Np == N else F.pad(x2, (0, Np - N))
             dW, db = _wgrad(gp, xp)
