@@ -156,7 +156,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(n_ranks, argv):
+def launch_ranks(n_ranks, argv, script=None):
     """``python bench.py --gpus N`` without torch.distributed.run: start N fresh children of this script, one per device
     (RANK = LOCAL_RANK = r, rendezvous on 127.0.0.1), and exit with the worst of their codes.  Runs before anything in
     this process has touched the GPU; rank 0's stdout (the JSON line) is this process's stdout."""
@@ -165,7 +165,7 @@ def launch_ranks(n_ranks, argv):
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script or __file__)] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     codes = [p.wait() for p in procs]
     return max(abs(c) for c in codes)
@@ -315,6 +315,8 @@ def main():
                 "algorithmic_f32_TFLOPs": algorithmic,
                 "algorithmic_over_x3_roof_417TF": algorithmic / (PEAK_BF16_MFMA_TFLOPS / X3_PRODUCTS),
                 "algorithmic_over_f32_mfma_peak": algorithmic / PEAK_F32_MFMA_TFLOPS,
+                "frac_algorithmic_f32_peak": algorithmic / PEAK_F32_MFMA_TFLOPS,     # SURVEY 8(d)'s recipe read literally: algorithmic
+                # fp32 flops / time / the dtype's own dense MFMA peak (157.3 TFLOP/s); `frac` above prices the executed bf16 products
                 "traffic": measured_traffic() if a.batch == 512 else None,
                 "algorithmic_bytes_per_launch": 3 * valid_pairs * hd["de"] * 4,
                 "kernel": "scgg::edge_unit_layer_x3_kernel<8,2,4,12> (fused XEy layer, edge path; fp32 results from 6 bf16 "

@@ -175,3 +175,19 @@ def test_gradient_buckets_average_equals_single_process_gradient():
                     for a, b in zip(got[:-2], full[:-2]):
                         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
                     assert got[-1] is None and got[-2] is None      # unused on every rank: grad stays None (as under DDP)
+
+
+def test_bench_train_gpus_flag_starts_its_own_ranks_and_keeps_replicas_identical():
+    """scripts/bench_train.py --gpus 2 --stub-gloo: the training launcher starts two ranks itself,
+    every rank trains on its own batch, GradientBuckets averages the gradients from the autograd hooks on persistent flat
+    buffers, the replicas end with identical parameters, and the line reports the job's graphs/s over the slowest rank."""
+    import json, subprocess, sys
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_train.py"), "--stub-gloo", "--gpus", "2", "--batch", "6",
+                        "--steps", "4", "--warmup", "1"], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["replicas_identical"] is True
+    assert line["ms_per_step"] >= 10.0                       # rank 1 sleeps 10 ms per step: MAX over ranks
+    assert abs(line["graphs_per_s"] - 2 * 6 / line["ms_per_step"] * 1e3) < 1e-6
+    assert line["loss_last"] < line["loss_first"]
