@@ -67,8 +67,9 @@ int scgg_denoiser_forward(scgg_denoiser* h, const float* X, const float* E, cons
                           int32_t B, int32_t n, float* out_X, float* out_E, float* out_y, void* workspace,
                           size_t workspace_bytes, void* stream);
 
-/* The same forward for callers that cannot allocate and have no workspace to pass (code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Scratch = a file-scope
+/* The same forward for callers that cannot allocate and have no workspace to pass (tight serving loops, harnesses that
+ * forbid hipMalloc, code that prepares a HIP graph -- the call itself is NOT capture-safe: it records an event on the
+ * engine's own second stream, which a stream under capture may not wait for; run it outside the capture).  No counterpart in the reference.  Scratch = a file-scope
  * `static __device__` array of scgg_denoiser_static_scratch_bytes() = 32 MiB per GPU (held until the process ends; its
  * per-device address is looked up with hipGetSymbolAddress in scgg_denoiser_finalize, else on the first call on a device);
  * shapes whose workspace_bytes(B, n) exceed it are rejected with an error, nothing is allocated or freed by the call.
@@ -81,13 +82,14 @@ int scgg_denoiser_forward_static(scgg_denoiser* h, const float* X, const float* 
                                  float* out_y, void* stream);
 size_t scgg_denoiser_static_scratch_bytes(void);
 
-/* The engine's second stream (a hipStream_t, owned by the handle; NULL + scgg_last_error on failure).  The forward
- * runs every consumer of its X and y arguments on this stream and only the edge path on the caller's, so work that
- * PRODUCES X or y may be enqueued on it before scgg_denoiser_forward is called (after making it wait for whatever that
- * work reads): it is then ordered before the node / global input MLPs but runs beside the edge input MLP, the long
- * pole of the prologue.  The sampling loop (diffusion_model_discrete.py:653-663) runs the eigen features, which feed
- * only X and y (extra_features.py:41-60), this way.  E and node_mask must be complete on the forward's own stream as
- * usual.  No counterpart in the reference (PyTorch serialises the whole step on one stream). */
+/* The engine's second stream (a hipStream_t, owned by the handle; NULL + scgg_last_error on failure).  The forward itself
+ * runs entirely on the caller's stream; this stream only carries what the CALLER enqueues on it.  The forward joins it
+ * (event wait, no host sync) in front of the first kernel that reads its X or y arguments -- behind the work lists, the
+ * zero fills and the edge input MLP, which need E and node_mask only -- so work that PRODUCES X or y may be enqueued here
+ * before scgg_denoiser_forward is called (after making this stream wait for whatever that work reads): it then runs beside
+ * the edge input MLP, the long pole of the prologue.  The sampling loop (diffusion_model_discrete.py:653-663) runs the
+ * eigen features, which feed only X and y (extra_features.py:41-60), this way.  E and node_mask must be complete on the
+ * forward's own stream as usual.  No counterpart in the reference (PyTorch serialises the whole step on one stream). */
 void* scgg_denoiser_side_stream(scgg_denoiser* h);
 
 /* Debug / test tap: runs the input MLPs and the first `n_run_layers` layers of the same network and returns the

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <map>
+#include <atomic>
 #include <stdlib.h>
 #include <string>
 #include <vector>
@@ -44,16 +45,16 @@ static int check_launch(const char* what) {
 // device address of this GPU's copy of scgg_static_scratch: looked up once per device, with that device current
 static void* static_scratch() {
   constexpr int MAX_DEV = 64;
-  static void* ptr[MAX_DEV] = {};
+  static std::atomic<void*> ptr[MAX_DEV] = {};              // threads may race to the first lookup: both find the same address
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) { fail("static scratch: no current device"); return nullptr; }
-  if (ptr[dev] == nullptr) {
-    void* p = nullptr;
+  void* p = ptr[dev].load(std::memory_order_acquire);
+  if (p == nullptr) {
     const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scgg_static_scratch));
     if (e != hipSuccess || p == nullptr) { fail("hipGetSymbolAddress(scgg_static_scratch): %s", hipGetErrorString(e)); return nullptr; }
-    ptr[dev] = p;
+    ptr[dev].store(p, std::memory_order_release);
   }
-  return ptr[dev];
+  return p;
 }
 
 static inline int pad32(int v) { return (v + 31) / 32 * 32; }
@@ -441,36 +442,20 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   const int dx = c.dx, de = c.de, dy = c.dy;
   const int kcat = dy + 4 * dx + 4 * de;
 
-  // ---- streams.  `st` (the caller's) carries the edge path and the fused node kernel; `ax` carries the node / global
-  //      input MLPs, the first q|k|v, the y path (pooled statistics, y update, FiLM vectors) and the X / y output MLPs.
-  //      Events per layer: FILM (film(l) -- and for l = 0 everything the aux prologue produced -- ready), EDGE (edge
-  //      kernel l done: Etoy partials ready), NS (Xtoy of X(l) taken: X may be overwritten), X (X(l+1) ready).
-  //      DEFAULT: ONE stream.  With the two-stream schedule below the forward is not reproducible on MI355X: a few per cent
-  //      of the forwards differ from the rest by up to 1e-2 in the logits (single wrong node rows, first seen where the edge
-  //      input MLP on `st` runs beside the node input MLP / q|k|v kernels on `ax`; scripts/probe/forward_repeat.py,
-  //      DESIGN.md "Two-stream schedule").  Every dependency below was checked, the same event pattern on synthetic kernels
-  //      is clean (scripts/probe/cross_wait_probe.hip), and with everything on one stream 2000 repeated forwards are
-  //      bit-identical -- so the schedule stays available (SCGG_TWO_STREAMS=1) but is not the default until the cause is
-  //      known.  In one-stream mode `ax` is `st`, the events are not needed, and the aux stream is only joined at the start
-  //      (the caller may have queued the producers of X / y there: scgg_denoiser_side_stream).
-  // SCGG_TWO_STREAMS: unset = one stream; "y" = only the y round of a layer on the second stream, beside that layer's edge
-  // kernel (it needs X(l), E(l) and y only); anything else = the round-1 schedule (not reproducible)
-  static const int stream_mode = [] { const char* e = getenv("SCGG_TWO_STREAMS"); return e == nullptr ? 0 : (e[0] == 'y' ? 2 : 1); }();
-  const bool two_streams = stream_mode == 1;
-  hipStream_t ax = two_streams ? h->aux : st;
-  // One stream: what the caller queued on the engine's second stream (the producers of X / y: scgg_denoiser_side_stream) is
-  // joined in front of the first kernel that reads X or y, i.e. BEHIND the work lists and the edge input MLP, which need E
-  // and the mask only.  SCGG_LATE_JOIN=0 joins at the start.
-  static const bool late_join_on = [] { const char* e = getenv("SCGG_LATE_JOIN"); return !(e != nullptr && e[0] == '0'); }();
-  const bool late_join = !two_streams && late_join_on;
-  if (!two_streams && hipEventRecord(h->sync_ev[0], h->aux) != hipSuccess) return fail("stream join failed");
-  if (!two_streams && !late_join && hipStreamWaitEvent(st, h->sync_ev[0], 0) != hipSuccess) return fail("stream join failed");
+  // ---- streams.  The forward runs on ONE stream, the caller's.  The engine's second stream (scgg_denoiser_side_stream) only
+  //      carries what the CALLER queues there -- the sampling loop's eigen features, which produce parts of X and y -- and is
+  //      joined in front of the first kernel that reads X or y, i.e. BEHIND the work lists and the edge input MLP, which
+  //      need E and the mask only (SCGG_LATE_JOIN=0 joins at the start).  SCGG_TWO_STREAMS=y is a development switch: the y
+  //      round of layer l on the second stream beside that layer's edge kernel (reproducible, slower).
+  //      The round-1 schedule that spread the whole node / global path over the second stream is gone: a few per cent of its
+  //      forwards computed single wrong node rows (up to 1e-2 in the logits) and the cause was never found.
+  static const int stream_mode = [] { const char* e = getenv("SCGG_TWO_STREAMS"); return (e != nullptr && e[0] == 'y') ? 2 : 0; }();
+  static const bool late_join = [] { const char* e = getenv("SCGG_LATE_JOIN"); return !(e != nullptr && e[0] == '0'); }();
+  if (hipEventRecord(h->sync_ev[0], h->aux) != hipSuccess) return fail("stream join failed");
+  if (!late_join && hipStreamWaitEvent(st, h->sync_ev[0], 0) != hipSuccess) return fail("stream join failed");
   enum { EV_FILM = 0, EV_EDGE = 1, EV_NS = 2, EV_X = 3, EV_PER_LAYER = 4 };
   auto ev = [&](int l, int k) { return h->sync_ev[(size_t)(l + 1) * EV_PER_LAYER + k]; };
-  auto signal = [&](hipEvent_t e, hipStream_t s) { return two_streams && hipEventRecord(e, s) != hipSuccess; };
-  auto await = [&](hipStream_t s, hipEvent_t e) { return two_streams && hipStreamWaitEvent(s, e, 0) != hipSuccess; };
-  hipEvent_t ev_join = h->sync_ev[0], ev_fork = h->sync_ev[1], ev_e0 = h->sync_ev[2], ev_pro = h->sync_ev[3];
-  hipEvent_t ev_y0 = h->sync_ev.back();
+  hipEvent_t ev_join = h->sync_ev[1];
 
   // ---- work lists (valid rows, 16-key units), then fork
   if (launch_build_lists(mask, B, n, w.goff, w.rows, w.row_count, w.units, w.unit_count, st, w.chunk_bits))
@@ -485,19 +470,11 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   float* Xcur = w.Xh;
   float* Xalt = w.t1;
   // valid rows only: the masked rows of the residual stream are zeroed once per forward, nothing writes them afterwards
-  // (on the caller's stream ahead of the fork: the second stream may still be busy with the caller's X / y producers)
   if (h->in_X2.W != nullptr && c.in_X <= 64 && c.hid_X % 4 == 0) {
     launch_zero_masked_rows(w.Xh, mask, M, dx, st);
     if (dbl_X) launch_zero_masked_rows(w.t1, mask, M, dx, st);
   }
-  // Every event is recorded directly behind the work it stands for, never directly behind a cross-stream wait: ev_pro =
-  // "the second stream has finished what the caller queued there" goes first, then the fork.
-  if (signal(ev_pro, ax)) return fail("event record failed");
-  if (signal(ev_fork, st) || await(ax, ev_fork)) return fail("stream fork failed");
-
-  // The y input MLP and the FiLM vectors of layer 0 (fused y path): on the caller's stream, which idles after the edge
-  // input MLP, beside the X chain on the second stream.  The caller's stream first waits until the second stream has
-  // caught up with whatever the caller queued there (the producers of y, scgg_denoiser_side_stream).
+  // the fused y path (y input MLP, FiLM vectors of layer 0 and the y rounds in y_layer_kernel)
   const bool y_on_main = y_layer_supported(dy, c.dim_ffy, dy + 4 * dx + 4 * de) && n_run_layers > 0;
   // One stream: the y round takes the pooled statistics of X(l) and E(l) itself (pool_stats.h) -- the separate statistics
   // kernels exist to run BESIDE other work, and here they would only add two launches per layer in front of it.
@@ -506,21 +483,19 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
   auto rec = [&](hipEvent_t e, hipStream_t s2) { return hipEventRecord(e, s2) != hipSuccess; };
   auto hold = [&](hipStream_t s2, hipEvent_t e) { return hipStreamWaitEvent(s2, e, 0) != hipSuccess; };
   static const bool y_pool_on = [] { const char* e = getenv("SCGG_Y_POOL"); return !(e != nullptr && e[0] == '0'); }();
-  const bool y_pools = !two_streams && y_pool_on && y_layer_supported(dy, c.dim_ffy, kcat) && dx % 4 == 0 && dx <= 512 &&
+  const bool y_pools = y_pool_on && y_layer_supported(dy, c.dim_ffy, kcat) && dx % 4 == 0 && dx <= 512 &&
                        256 % (dx / 4) == 0 && de % 4 == 0 && de <= 256 && 256 % (de / 4) == 0 && n <= 512;
   bool pooled_e0 = false;
   bool head_fused = false;   // the last node kernel also ran mlp_out_X.0
   {
     EdgeMlpUnitArgs a{E, nullptr, mask, h->in_E_img, w.E0, w.units, w.unit_count, B, n, c.in_E, c.out_E};
     if (launch_edge_mlp_in(a, c.in_E, c.hid_E, de, st)) return fail("edge_mlp_in: unsupported dims");
-    // Etoy of E(0) for the fused y path: on the caller's stream, which idles from here until the FiLM vectors of layer 0
-    // are ready (the second stream is still busy with the X / y prologue)
+    // Etoy of E(0) for the fused y path when the y round does not pool for itself (SCGG_Y_POOL=0)
     pooled_e0 = !y_pools && y_layer_supported(dy, c.dim_ffy, kcat) && n_run_layers > 0 && h->layers[0].predicts_y;
     if (pooled_e0) {
       EdgePoolArgs ep{w.E0, mask, w.epool, B, n, de, 4 * de, 0};
       if (launch_edge_pool_stats(ep, st)) return fail("edge_pool_stats: unsupported de=%d or n=%d", de, n);
     }
-    if (signal(ev_e0, st)) return fail("event record failed");
   }
   // the output tensors are zero outside the valid rows / live pairs (utils.py:154) and only their valid part is written
   // at the end: zero-filled now, while the caller's stream waits for the prologue of the second stream anyway
@@ -538,19 +513,18 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     if (!w0 || !b0 || !w3 || !b3) return -1;
     if (h->in_X2.W != nullptr && c.in_X <= 64 && c.hid_X % 4 == 0) {
       NarrowLinearArgs na{X, w0->p, b0->p, w.hidX, w.rows, w.row_count, c.hid_X, c.in_X, c.in_X, c.hid_X, 1};
-      if (launch_narrow_linear(na, M, ax)) return fail("narrow_linear rejected");
+      if (launch_narrow_linear(na, M, st)) return fail("narrow_linear rejected");
       NodeLinearArgs la{w.hidX, h->in_X2.W, h->in_X2.b, w.Xh, w.rows, w.row_count, dx, c.hid_X, (dx + 31) / 32, c.hid_X, dx,
                         (dx + 31) / 32 >= 4 ? 2 : 1, 1};
-      if (launch_node_linear_x3(la, h->in_X2.W3, M, ax) != 0 && launch_node_linear(la, M, ax))
+      if (launch_node_linear_x3(la, h->in_X2.W3, M, st) != 0 && launch_node_linear(la, M, st))
         return fail("node_linear(mlp_in_X.3) rejected");
     } else {
-      if (gemm(X, c.in_X, w0, b0, w.hidX, c.hid_X, M, c.hid_X, c.in_X, GEMM_RELU, nullptr, ax)) return -1;
-      if (gemm(w.hidX, c.hid_X, w3, b3, w.Xh, dx, M, dx, c.hid_X, GEMM_RELU | GEMM_ROWMASK, mask, ax)) return -1;
+      if (gemm(X, c.in_X, w0, b0, w.hidX, c.hid_X, M, c.hid_X, c.in_X, GEMM_RELU, nullptr, st)) return -1;
+      if (gemm(w.hidX, c.hid_X, w3, b3, w.Xh, dx, M, dx, c.hid_X, GEMM_RELU | GEMM_ROWMASK, mask, st)) return -1;
     }
   }
   {
-    hipStream_t ys = y_on_main ? st : ax;
-    if (y_on_main && await(st, ev_pro)) return fail("stream wait failed");
+    hipStream_t ys = st;
     if (gemm(y, c.in_y, P_(h, "mlp_in_y.0.weight", (int64_t)c.hid_y * c.in_y), P_(h, "mlp_in_y.0.bias", c.hid_y), w.hidy,
              c.hid_y, B, c.hid_y, c.in_y, GEMM_RELU, nullptr, ys)) return -1;
     if (gemm(w.hidy, c.hid_y, P_(h, "mlp_in_y.3.weight", (int64_t)dy * c.hid_y), P_(h, "mlp_in_y.3.bias", dy), w.y, dy, B,
@@ -570,7 +544,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     //      layer's fused node kernel; on the unfused path every layer computes them on the main stream
     const bool fused_node = node_layer_supported(dx, c.dim_ffX) && L.x_out.W && L.linX1.W && L.linX2.W && L.qkv.W;
     {
-      hipStream_t qs = l == 0 ? ax : st;
+      hipStream_t qs = st;
       if (fused_node && l > 0) {
       } else if (L.qkv.W != nullptr) {
         NodeLinearArgs qa{Xcur, L.qkv.W, L.qkv.b, w.qkv, w.rows, w.row_count, 3 * dx, dx, (3 * dx + 31) / 32, dx, 3 * dx,
@@ -588,33 +562,26 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
         ya.B = B; ya.dy = dy; ya.ffy = c.dim_ffy; ya.kcat = kcat; ya.dx = dx; ya.update = 0;
         // y on the caller's stream: what that stream needs from the second one before edge kernel 0 is X(0) and q|k|v(0);
         // the event goes directly behind those kernels, then the second stream waits for y(0)
-        if (y_on_main && signal(ev(l, EV_FILM), ax)) return fail("event record failed");
-        if (launch_y_layer(ya, y_on_main ? st : ax)) return fail("y_layer launch failed");
-        if (y_on_main && (signal(ev_y0, st) || await(ax, ev_y0))) return fail("stream sync failed");
-      } else if (gemm_raw(w.y, dy, L.Wfilm, L.bfilm, film, 4 * dx, B, 4 * dx, dy, GEMM_ADD_ONE_COLS, nullptr, ax, dx,
+        if (launch_y_layer(ya, st)) return fail("y_layer launch failed");
+      } else if (gemm_raw(w.y, dy, L.Wfilm, L.bfilm, film, 4 * dx, B, 4 * dx, dy, GEMM_ADD_ONE_COLS, nullptr, st, dx,
                           2 * dx, 3 * dx, 4 * dx)) return -1;
-      if (!(fused_y && y_on_main) && signal(ev(l, EV_FILM), ax)) return fail("event record failed");
     }
     if (L.predicts_y && !y_pools) {
-      if (!fused_y) launch_copy_cols(w.y, dy, w.ycat, kcat, B, dy, ax);
-      if (l > 0 && await(ax, ev(l - 1, EV_X))) return fail("stream wait failed");
+      if (!fused_y) launch_copy_cols(w.y, dy, w.ycat, kcat, B, dy, st);
       NodeStatsArgs ns{Xcur, mask, w.ycat, B, n, dx, kcat, dy};
-      if (launch_node_stats(ns, ax)) return fail("node_stats: unsupported dx=%d or n=%d", dx, n);
+      if (launch_node_stats(ns, st)) return fail("node_stats: unsupported dx=%d or n=%d", dx, n);
     }
-    if (signal(ev(l, EV_NS), ax)) return fail("event record failed");
     if (y_beside && rec(ev(l, EV_NS), st)) return fail("event record failed");      // X(l), E(l), y are final here
     // Etoy of the layer INPUT E(l) (:239-243).  Fused y path: E(0) here, E(l+1) at the end of round l (beside the node
     // kernel); unfused: every layer here, straight into the ycat row.
-    if (l == 0 && await(ax, ev_e0)) return fail("stream wait failed");
     if (L.predicts_y && !y_pools && (l == 0 || !fused_y) && !(l == 0 && pooled_e0)) {
       EdgePoolArgs ep{Ecur, mask, fused_y ? w.epool : w.ycat, B, n, de, fused_y ? 4 * de : kcat, fused_y ? 0 : dy + 4 * dx};
-      if (launch_edge_pool_stats(ep, ax)) return fail("edge_pool_stats: unsupported de=%d or n=%d", de, n);
+      if (launch_edge_pool_stats(ep, st)) return fail("edge_pool_stats: unsupported de=%d or n=%d", de, n);
     }
 
     // ---- main: fused edge kernel.  Its FiLM vectors: layer 0 (and the unfused y path) waits here; on the fused y path
     //      the wait for layer l + 1 sits in front of node kernel l (the y round of layer l runs beside edge kernel l),
     //      so node kernel l and edge kernel l + 1 go back to back (a cross-stream wait costs ~10 us of idle queue)
-    if ((l == 0 || !fused_y) && await(st, ev(l, EV_FILM))) return fail("stream wait failed");
     {
       EdgeLayerArgs a;
       a.E_in = Ecur; a.E_out = Enext; a.mask = mask;
@@ -630,7 +597,6 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       if (timed) (void)hipEventRecord(h->prof_ev[h->prof_used], st);
       if (launch_edge_layer(a, dx, de, c.dim_ffE, st)) return fail("edge_layer: unsupported dims dx=%d de=%d ffE=%d (or launch setup failed)", dx, de, c.dim_ffE);
       if (timed) { (void)hipEventRecord(h->prof_ev[h->prof_used + 1], st); h->prof_used += 2; }
-      if (signal(ev(l, EV_EDGE), st)) return fail("event record failed");
       if (!fused_node) {
         AttnFinishArgs af{w.attn, mask, film, w.newX, w.rows, w.row_count, n, dx};
         launch_attn_finish(af, M, st);
@@ -661,44 +627,39 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
         }
         if (next_layer) { ya.Wt_film = h->layers[l + 1].Wt_film; ya.b_film = h->layers[l + 1].bfilm; ya.film = film_next; }
         if (y_beside && hold(h->aux, ev(l, EV_NS))) return fail("stream wait failed");
-        if (launch_y_layer(ya, y_beside ? h->aux : ax)) return fail("y_layer launch failed");
-        if (next_layer && signal(ev(l + 1, EV_FILM), ax)) return fail("event record failed");
+        if (launch_y_layer(ya, y_beside ? h->aux : st)) return fail("y_layer launch failed");
         if (y_beside && next_layer && rec(ev(l + 1, EV_FILM), h->aux)) return fail("event record failed");
       }
       if (next_layer && h->layers[l + 1].predicts_y && !y_pools) {   // Etoy of E(l+1), the tensor edge kernel l has just written
-        if (await(ax, ev(l, EV_EDGE))) return fail("stream wait failed");
         EdgePoolArgs ep{Enext, mask, w.epool + (size_t)((l + 1) & 1) * B * 4 * de, B, n, de, 4 * de, 0};
-        if (launch_edge_pool_stats(ep, ax)) return fail("edge_pool_stats: unsupported de=%d or n=%d", de, n);
+        if (launch_edge_pool_stats(ep, st)) return fail("edge_pool_stats: unsupported de=%d or n=%d", de, n);
       }
     } else if (L.predicts_y) {
-      if (await(ax, ev(l, EV_EDGE))) return fail("stream wait failed");
-      if (gemm_raw(w.ycat, kcat, L.Wycat, L.bycat, w.yt1, dy, B, dy, kcat, 0, nullptr, ax)) return -1;
+      if (gemm_raw(w.ycat, kcat, L.Wycat, L.bycat, w.yt1, dy, B, dy, kcat, 0, nullptr, st)) return -1;
       if (gemm(w.yt1, dy, P_(h, sa + "y_out.0.weight", (int64_t)dy * dy), P_(h, sa + "y_out.0.bias", dy), w.yt2, dy, B, dy,
-               dy, GEMM_RELU, nullptr, ax)) return -1;
+               dy, GEMM_RELU, nullptr, st)) return -1;
       if (gemm(w.yt2, dy, P_(h, sa + "y_out.2.weight", (int64_t)dy * dy), P_(h, sa + "y_out.2.bias", dy), w.yt1, dy, B, dy,
-               dy, 0, nullptr, ax)) return -1;
+               dy, 0, nullptr, st)) return -1;
       const Param* g1 = P_(h, p + "norm_y1.weight", dy); const Param* b1 = P_(h, p + "norm_y1.bias", dy);
       const Param* g2 = P_(h, p + "norm_y2.weight", dy); const Param* b2 = P_(h, p + "norm_y2.bias", dy);
       if (!g1 || !b1 || !g2 || !b2) return -1;
       AddLnArgs ln1{w.y, w.yt1, g1->p, b1->p, nullptr, w.y, B, dy, nullptr, nullptr};
-      launch_add_layernorm(ln1, ax);
+      launch_add_layernorm(ln1, st);
       if (gemm(w.y, dy, P_(h, p + "lin_y1.weight", (int64_t)c.dim_ffy * dy), P_(h, p + "lin_y1.bias", c.dim_ffy), w.yt2,
-               c.dim_ffy, B, c.dim_ffy, dy, GEMM_RELU, nullptr, ax)) return -1;
+               c.dim_ffy, B, c.dim_ffy, dy, GEMM_RELU, nullptr, st)) return -1;
       if (gemm(w.yt2, c.dim_ffy, P_(h, p + "lin_y2.weight", (int64_t)dy * c.dim_ffy), P_(h, p + "lin_y2.bias", dy), w.yt1,
-               dy, B, dy, c.dim_ffy, 0, nullptr, ax)) return -1;
+               dy, B, dy, c.dim_ffy, 0, nullptr, st)) return -1;
       AddLnArgs ln2{w.y, w.yt1, g2->p, b2->p, nullptr, w.y, B, dy, nullptr, nullptr};
-      launch_add_layernorm(ln2, ax);
+      launch_add_layernorm(ln2, st);
     }
     // ---- main: X path (transformer_model.py:234-235, :88-92)
     {
       const Param* g1 = P_(h, p + "normX1.weight", dx); const Param* b1 = P_(h, p + "normX1.bias", dx);
       const Param* g2 = P_(h, p + "normX2.weight", dx); const Param* b2 = P_(h, p + "normX2.bias", dx);
       if (!g1 || !b1 || !g2 || !b2) return -1;
-      if (fused_y && l + 1 < n_run_layers && await(st, ev(l + 1, EV_FILM))) return fail("stream wait failed");
       if (y_beside && l + 1 < n_run_layers && hold(st, ev(l + 1, EV_FILM))) return fail("stream wait failed");
       // in place: X is overwritten from here on, its pooled statistics must have been taken; double-buffered: nothing
       // to wait for (the buffer written now was last read two layers ago)
-      if (!dbl_X && await(st, ev(l, EV_NS))) return fail("stream wait failed");
       if (fused_node) {
         const bool next = l + 1 < n_run_layers;
         NodeLayerArgs na{w.attn, mask, film, Xcur, w.rows, w.row_count, L.x_out.W, L.x_out.b, g1->p, b1->p,
@@ -729,17 +690,14 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
         AddLnArgs ln2{Xcur, w.t1, g2->p, b2->p, mask, Xcur, M, dx, w.rows, w.row_count};
         launch_add_layernorm(ln2, st);
       }
-      if (signal(ev(l, EV_X), st)) return fail("event record failed");
     }
     float* t = Ecur; Ecur = Enext; Enext = t;
     if (check_launch("layer")) return -1;
   }
   if (y_beside && (rec(ev_join, h->aux) || hold(st, ev_join))) return fail("stream join failed");   // the last y round
   // the aux stream needs the final X (the main stream's last node kernel) for the X output head
-  if (!tap && c.out_X > 0 && n_run_layers > 0 && await(ax, ev(n_run_layers - 1, EV_X))) return fail("stream wait failed");
 
   if (tap) {
-    if (signal(ev_join, ax) || await(st, ev_join)) return fail("stream join failed");
     if (o1) launch_copy_cols(Xcur, dx, o1, dx, M, dx, st);
     if (o2) {
       const long long total = (long long)M * n * de;
@@ -758,25 +716,25 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     NodeLinearArgs la{Xcur, h->out_X1.W, h->out_X1.b, w.hidX, w.rows, w.row_count, c.hid_X, dx, (c.hid_X + 31) / 32, dx, c.hid_X,
                       1, 1};
     bool rows_only = head_fused || (h->out_X1.W3 != nullptr && c.out_X <= 16 && c.hid_X % 4 == 0 &&
-                                    launch_node_linear_x3(la, h->out_X1.W3, M, ax) == 0);
+                                    launch_node_linear_x3(la, h->out_X1.W3, M, st) == 0);
     if (rows_only) {
-      if (!out_zeroed && hipMemsetAsync(o1, 0, (size_t)M * c.out_X * sizeof(float), ax) != hipSuccess) return fail("memset failed");
-      if (launch_row_head(w.hidX, c.hid_X, w3->p, b3->p, X, c.in_X, w.rows, w.row_count, o1, M, c.out_X, c.hid_X, ax))
+      if (!out_zeroed && hipMemsetAsync(o1, 0, (size_t)M * c.out_X * sizeof(float), st) != hipSuccess) return fail("memset failed");
+      if (launch_row_head(w.hidX, c.hid_X, w3->p, b3->p, X, c.in_X, w.rows, w.row_count, o1, M, c.out_X, c.hid_X, st))
         return fail("row_head rejected");
     } else {
       if (gemm(Xcur, dx, P_(h, "mlp_out_X.0.weight", (int64_t)c.hid_X * dx), P_(h, "mlp_out_X.0.bias", c.hid_X), w.hidX,
-               c.hid_X, M, c.hid_X, dx, GEMM_RELU, nullptr, ax)) return -1;
-      if (gemm(w.hidX, c.hid_X, w3, b3, w.xo, c.out_X, M, c.out_X, c.hid_X, 0, nullptr, ax)) return -1;
-      launch_x_out_residual(w.xo, X, c.in_X, mask, o1, M, c.out_X, ax);
+               c.hid_X, M, c.hid_X, dx, GEMM_RELU, nullptr, st)) return -1;
+      if (gemm(w.hidX, c.hid_X, w3, b3, w.xo, c.out_X, M, c.out_X, c.hid_X, 0, nullptr, st)) return -1;
+      launch_x_out_residual(w.xo, X, c.in_X, mask, o1, M, c.out_X, st);
     }
   }
   if (c.out_y > 0) {
     if (!o3) return fail("out_y requested by the config but out_y pointer is NULL");
     if (gemm(w.y, dy, P_(h, "mlp_out_y.0.weight", (int64_t)c.hid_y * dy), P_(h, "mlp_out_y.0.bias", c.hid_y), w.hidy,
-             c.hid_y, B, c.hid_y, dy, GEMM_RELU, nullptr, ax)) return -1;
+             c.hid_y, B, c.hid_y, dy, GEMM_RELU, nullptr, st)) return -1;
     if (gemm(w.hidy, c.hid_y, P_(h, "mlp_out_y.3.weight", (int64_t)c.out_y * c.hid_y), P_(h, "mlp_out_y.3.bias", c.out_y),
-             w.yt1, c.out_y, B, c.out_y, c.hid_y, 0, nullptr, ax)) return -1;
-    launch_x_out_residual(w.yt1, y, c.in_y, nullptr, o3, B, c.out_y, ax);
+             w.yt1, c.out_y, B, c.out_y, c.hid_y, 0, nullptr, st)) return -1;
+    launch_x_out_residual(w.yt1, y, c.in_y, nullptr, o3, B, c.out_y, st);
   }
   {
     // logits are zero outside the live pairs (utils.py:154); the unit kernel writes the chunks that hold valid keys
@@ -785,7 +743,6 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
     if (launch_edge_mlp_out(a, de, c.hid_E, c.out_E, st)) return fail("edge_mlp_out: unsupported dims");
   }
   // join: everything the aux stream did is ordered before what follows on the caller's stream
-  if (signal(ev_join, ax) || await(st, ev_join)) return fail("stream join failed");
   return check_launch("forward");
 }
 
