@@ -7,7 +7,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscgg.so")
+LIB_PATH = os.environ.get("SCGG_LIB_PATH") or os.path.join(_HERE, "libscgg.so")     # the override: timing builds (scripts/probe)
 
 c_f32p = C.c_void_p
 _i32, _i64, _vp, _sz = C.c_int32, C.c_int64, C.c_void_p, C.c_size_t

@@ -1622,7 +1622,7 @@ struct BlockGeomBF {
   static constexpr int B_CB = 4 * QE + IBE;                  // e_mul, e_add (q-major, two row blocks each), e_out slice
   static constexpr int BIAS_F4 = 64;
   static constexpr int PH_F4 = BIAS_F4 + B_CB * 64;          // one bf16 block = 64 lanes x 16 B
-  static constexpr size_t lds_bytes(int nw) { return (size_t)2 * PH_F4 * 16 + (size_t)nw * 3 * DX * 4; }
+  static constexpr size_t lds_bytes(int nw) { return (size_t)2 * PH_F4 * 16 + (size_t)nw * 6 * DX * 4; }   // images, row vectors, partials
 };
 
 __device__ __forceinline__ unsigned bf16_rn(float x) {       // round to nearest even, as torch's .to(bfloat16)
@@ -1691,6 +1691,10 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* vecw = fl + wave * (3 * DX);
+  // The unit's attention partials are collected in LDS and leave as three 1-KiB stores at the END of the unit.  Stored from
+  // inside a phase (16 bytes from 4 lanes) they were still in flight at the next phase barrier, whose vmcnt(0) -- stores
+  // count in vmcnt on gfx9 -- then waited out a full store latency in every phase.
+  float* statw = fl + NW * (3 * DX) + wave * (3 * DX);
   const int n = a.n, nch = (n + 15) >> 4;
   const int count = *a.unit_count;
   const int per_iter = NW * gridDim.x;
@@ -1734,6 +1738,18 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
     const cptr kbase = reinterpret_cast<cptr>(a.K + (long long)b * n * a.ldqkv);
     const cptr vbase = reinterpret_cast<cptr>(a.V + (long long)b * n * a.ldqkv);
     const unsigned kvoff = 4u * (jj * a.ldqkv + 4 * g);
+    // K / V rows of the lane's key, one phase AHEAD: a load that is consumed in the phase that issues it is younger than the
+    // phase's weight DMA, so waiting for it (vmcnt counts in order) waited for the DMA to land as well -- a full memory
+    // latency in the middle of every phase.  Requested a phase early they are covered by the vmcnt(0) in front of the
+    // barrier, which the DMA needs anyway.
+    f32x4 kc[2], vc[2];
+    if (active) {
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        kc[blk] = ldo(kbase, kvoff + 4u * (16 * blk));
+        vc[blk] = ldo(vbase, kvoff + 4u * (16 * blk));
+      }
+    }
 #pragma unroll 1
     for (int cb = 0; cb < NXB; ++cb) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the phase image (and the unit's loads) has landed
@@ -1742,11 +1758,15 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
       const float* bias = reinterpret_cast<const float*>(wbuf + cur * G::PH_F4);
       const u32x4* W = reinterpret_cast<const u32x4*>(wbuf + cur * G::PH_F4 + G::BIAS_F4);
       if (active) {
-        f32x4 k[2], vn[2], a1[2], a2[2];
+        f32x4 k[2], vn[2], a1[2], a2[2], kn[2], vnn[2];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
-          k[blk] = ldo(kbase, kvoff + 4u * (32 * cb + 16 * blk));
-          vn[blk] = ldo(vbase, kvoff + 4u * (32 * cb + 16 * blk));
+          k[blk] = kc[blk];
+          vn[blk] = vc[blk];
+          if (cb + 1 < NXB) {
+            kn[blk] = ldo(kbase, kvoff + 4u * (32 * (cb + 1) + 16 * blk));
+            vnn[blk] = ldo(vbase, kvoff + 4u * (32 * (cb + 1) + 16 * blk));
+          }
           a1[blk] = ld4(bias + 16 * blk + 4 * g);
           a2[blk] = ld4(bias + 32 + 16 * blk + 4 * g);
         }
@@ -1754,6 +1774,11 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
         for (int t = 0; t < 4 * QE; ++t) {                       // e_mul then e_add: blocks (q, ob), q-major
           const int rem = t % (2 * QE), q = rem >> 1, ob = rem & 1;
           const u32x4 w = W[t * 64 + lane];
+#ifdef SCGG_ABL_BF_NO_MFMA      // timing build: operands stay live, the matrix pipe idles
+          if (t < 2 * QE) a1[ob][0] += __uint_as_float((w[0] ^ eq[q][0]) & 0x3f800000u);
+          else a2[ob][0] += __uint_as_float((w[1] ^ eq[q][1]) & 0x3f800000u);
+          continue;
+#endif
           if (t < 2 * QE) a1[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(w), SCGG_BF(eq[q]), a1[ob], 0, 0, 0);
           else a2[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(w), SCGG_BF(eq[q]), a2[ob], 0, 0, 0);
         }
@@ -1783,9 +1808,17 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
 #pragma unroll
           for (int eb = 0; eb < IBE; ++eb) {
             const u32x4 w = W[(4 * QE + eb) * 64 + lane];
+#ifdef SCGG_ABL_BF_NO_MFMA
+            accO[eb][0] += __uint_as_float((w[0] ^ zb[0]) & 0x3f800000u);
+            continue;
+#endif
             accO[eb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SCGG_BF(w), SCGG_BF(zb), accO[eb], 0, 0, 0);
           }
         }
+#ifdef SCGG_ABL_BF_NO_SM        // timing build: no attention statistics
+        if (mloc == 12345.f)
+#endif
+        {
         const float M = row_max16_fused(mloc);
         const float nM = M == -INFINITY ? 0.f : -M * LOG2E;
         f32x4 cm[2], cs[2], ca[2];
@@ -1825,7 +1858,7 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
             }
         }
         if (p == 0) {
-          float* dst = a.attn_part + (long long)u * (3 * DX) + 32 * cb + 4 * g;
+          float* dst = statw + 32 * cb + 4 * g;
 #pragma unroll
           for (int blk = 0; blk < 2; ++blk) {
             *reinterpret_cast<f32x4*>(dst + 16 * blk) = cm[blk];
@@ -1833,8 +1866,17 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
             *reinterpret_cast<f32x4*>(dst + 2 * DX + 16 * blk) = ca[blk];
           }
         }
+        }
+        if (cb + 1 < NXB) {
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk) { kc[blk] = kn[blk]; vc[blk] = vnn[blk]; }
+        }
       }
       cur ^= 1;
+    }
+    if (active) {
+      float* dst = a.attn_part + (long long)u * (3 * DX);
+      for (int c = lane * 4; c < 3 * DX; c += 256) *reinterpret_cast<f32x4*>(dst + c) = *reinterpret_cast<const f32x4*>(statw + c);
     }
     if (active && inb) {
       unsigned short* dst = a.E_out + ((long long)row * n + jj) * DE + 4 * g;
