@@ -44,6 +44,46 @@ __device__ __forceinline__ void row_sum16_many(float (&v)[N]) {
 #pragma unroll
   for (int i = 0; i < N; ++i) v[i] += SCGG_DPP(v[i], 0x140);
 }
+// 16 independent 16-lane sums as a REDUCE-SCATTER: lane p of every row ends up with sum over the row's lanes of v[p].
+// Four halving stages (partners: row_mirror, row_half_mirror, quad xor 2, quad xor 1): a lane keeps the half of its
+// values that its lane bit selects and adds the partner's copy of them, so the work is 8 + 4 + 2 + 1 sums instead of the
+// 16 x 4 of sixteen butterflies.  The first two stages select by DPP bank mask (a bank = 4 lanes: bit 3 / bit 2 of the lane
+// pick whole banks), two v_add_f32_dpp per result; the last two select by v_cndmask.  33 VALU instead of 64-80.
+__device__ __forceinline__ float row_reduce_scatter16(const float (&v)[16], int p) {
+  float a[8], b[4];
+  // stage 1: lanes 0-7 (banks 0,1) keep v[0..7], lanes 8-15 keep v[8..15]; partner = 15 - p
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %8, %8 row_mirror row_mask:0xf bank_mask:0x3\n\tv_add_f32_dpp %0, %16, %16 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %1, %9, %9 row_mirror row_mask:0xf bank_mask:0x3\n\tv_add_f32_dpp %1, %17, %17 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %2, %10, %10 row_mirror row_mask:0xf bank_mask:0x3\n\tv_add_f32_dpp %2, %18, %18 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %3, %11, %11 row_mirror row_mask:0xf bank_mask:0x3\n\tv_add_f32_dpp %3, %19, %19 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %4, %12, %12 row_mirror row_mask:0xf bank_mask:0x3\n\tv_add_f32_dpp %4, %20, %20 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %5, %13, %13 row_mirror row_mask:0xf bank_mask:0x3\n\tv_add_f32_dpp %5, %21, %21 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %6, %14, %14 row_mirror row_mask:0xf bank_mask:0x3\n\tv_add_f32_dpp %6, %22, %22 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %7, %15, %15 row_mirror row_mask:0xf bank_mask:0x3\n\tv_add_f32_dpp %7, %23, %23 row_mirror row_mask:0xf bank_mask:0xc"
+      : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7])
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+        "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+  // stage 2: bit 2 of the lane = banks 1 and 3 keep the upper four; partner = 7 - (p & 7) within the half row
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %4, %4 row_half_mirror row_mask:0xf bank_mask:0x5\n\tv_add_f32_dpp %0, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %1, %5, %5 row_half_mirror row_mask:0xf bank_mask:0x5\n\tv_add_f32_dpp %1, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %2, %6, %6 row_half_mirror row_mask:0xf bank_mask:0x5\n\tv_add_f32_dpp %2, %10, %10 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %3, %7, %7 row_half_mirror row_mask:0xf bank_mask:0x5\n\tv_add_f32_dpp %3, %11, %11 row_half_mirror row_mask:0xf bank_mask:0xa"
+      : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
+  // stage 3: bit 1 (partner p ^ 2), stage 4: bit 0 (partner p ^ 1)
+  const bool h2 = (p & 2) != 0, h1 = (p & 1) != 0;
+  float c[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float lo = b[i] + SCGG_DPP(b[i], 0x4E), hi = b[i + 2] + SCGG_DPP(b[i + 2], 0x4E);   // quad_perm [2,3,0,1]
+    c[i] = h2 ? hi : lo;
+  }
+  const float lo = c[0] + SCGG_DPP(c[0], 0xB1), hi = c[1] + SCGG_DPP(c[1], 0xB1);             // quad_perm [1,0,3,2]
+  return h1 ? hi : lo;
+}
+
 // across the four channel groups (same key): lane ^ 16 then lane ^ 32
 __device__ __forceinline__ float groups_sum(float v) {
   v = swap_rows16_sum(v);

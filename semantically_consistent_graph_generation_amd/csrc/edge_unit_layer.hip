@@ -1631,6 +1631,13 @@ __device__ __forceinline__ unsigned bf16_rn(float x) {       // round to nearest
   return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
+// two fp32 -> packed bf16, round to nearest even (gfx950 has the instruction: v_cvt_pk_bf16_f32)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16_rn(float x0, float x1) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{x0, x1}, bf16x2_t));
+}
+
 struct EdgeBlockPackArgs { const float *W_mul, *b_mul, *W_add, *b_add, *W_out; u32x4* img; };
 
 template <int NXB, int NEB>
@@ -1788,13 +1795,15 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
         for (int blk = 0; blk < 2; ++blk) {
           const int co = 32 * cb + 16 * blk + 4 * g;
           const f32x4 q = ld4(vecw + co), yea = ld4(vecw + DX + co), yem = ld4(vecw + 2 * DX + co);
+          // No select on K / V: a lane without a valid key holds finite data of some other row (the caller zeroes masked
+          // rows; lanes beyond n read key 0), its logit is forced to -inf, so its weight is exactly 0, and an MFMA column
+          // depends on its own lane only -- nothing of such a lane is ever stored.
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float kk = vj ? k[blk][r] : 0.f;
-            const float yy = (q[r] * kk) * a1[blk][r] + a2[blk][r];
+            const float yy = (q[r] * k[blk][r]) * a1[blk][r] + a2[blk][r];
             z[blk][r] = yea[r] + yem[r] * yy;
             y[blk][r] = vj ? yy : -INFINITY;
-            v[blk][r] = vj ? vn[blk][r] : 0.f;
+            v[blk][r] = vn[blk][r];
             mloc = fmaxf(mloc, y[blk][r]);
           }
         }
@@ -1803,7 +1812,7 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
 #pragma unroll
           for (int d = 0; d < 4; ++d) {
             const float x0 = d < 2 ? z[0][2 * d] : z[1][2 * d - 4], x1 = d < 2 ? z[0][2 * d + 1] : z[1][2 * d - 3];
-            zb[d] = bf16_rn(x0) | (bf16_rn(x1) << 16);
+            zb[d] = pack_bf16_rn(x0, x1);
           }
 #pragma unroll
           for (int eb = 0; eb < IBE; ++eb) {
@@ -1824,7 +1833,7 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
         f32x4 cm[2], cs[2], ca[2];
         bool under = false;
         {
-          float red[16];
+          float red[16];                                                // 8 x exp(y - M) (0 on invalid keys), 8 x p V
 #pragma unroll
           for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -1833,18 +1842,14 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
               red[4 * blk + r] = pe;
               red[8 + 4 * blk + r] = pe * v[blk][r];
             }
-          row_sum16_many<16>(red);
-#pragma unroll
-          for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              cs[blk][r] = red[4 * blk + r];
-              ca[blk][r] = red[8 + 4 * blk + r];
-              cm[blk][r] = M;
-              under |= cs[blk][r] == 0.f;
-            }
+          // lane p of a row now gets the row's sum of red[p]: p < 8: sum p of channel (blk = p >> 2, r = p & 3), p >= 8: sum p V
+          const float mine = row_reduce_scatter16(red, p);
+          const int ch = 32 * cb + 16 * ((p >> 2) & 1) + 4 * g + (p & 3);
+          statw[(p < 8 ? DX : 2 * DX) + ch] = mine;
+          if (p < 8) statw[ch] = M;
+          under = p < 8 && mine == 0.f;
         }
-        if (__any(under && M > -INFINITY)) {
+        if (__any(under && M > -INFINITY)) {                         // a channel underflowed against the shared shift: exact maxima
 #pragma unroll
           for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -1854,16 +1859,16 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
               const float ex = yy == -INFINITY ? 0.f : __expf(yy - mx);
               cm[blk][r] = mx;
               cs[blk][r] = row_sum16(ex);
-              ca[blk][r] = row_sum16(ex * v[blk][r]);
+              ca[blk][r] = row_sum16(yy == -INFINITY ? 0.f : ex * v[blk][r]);
             }
-        }
-        if (p == 0) {
-          float* dst = statw + 32 * cb + 4 * g;
+          if (p == 0) {
+            float* dst = statw + 32 * cb + 4 * g;
 #pragma unroll
-          for (int blk = 0; blk < 2; ++blk) {
-            *reinterpret_cast<f32x4*>(dst + 16 * blk) = cm[blk];
-            *reinterpret_cast<f32x4*>(dst + DX + 16 * blk) = cs[blk];
-            *reinterpret_cast<f32x4*>(dst + 2 * DX + 16 * blk) = ca[blk];
+            for (int blk = 0; blk < 2; ++blk) {
+              *reinterpret_cast<f32x4*>(dst + 16 * blk) = cm[blk];
+              *reinterpret_cast<f32x4*>(dst + DX + 16 * blk) = cs[blk];
+              *reinterpret_cast<f32x4*>(dst + 2 * DX + 16 * blk) = ca[blk];
+            }
           }
         }
         }
@@ -1883,7 +1888,7 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
 #pragma unroll
       for (int eb = 0; eb < IBE; ++eb) {
         u32x2 o = {0u, 0u};
-        if (vj) o = u32x2{bf16_rn(accO[eb][0]) | (bf16_rn(accO[eb][1]) << 16), bf16_rn(accO[eb][2]) | (bf16_rn(accO[eb][3]) << 16)};
+        if (vj) o = u32x2{pack_bf16_rn(accO[eb][0], accO[eb][1]), pack_bf16_rn(accO[eb][2], accO[eb][3])};
         *reinterpret_cast<u32x2*>(dst + 16 * eb) = o;
       }
     }
