@@ -802,14 +802,16 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
           const f32x4 q = ld4(vecw + co);                               // Q_i / sqrt(df)
           const f32x4 yea = ld4(vecw + DX + co);
           const f32x4 yem = ld4(vecw + 2 * DX + co);
+          // No select on K / V: a lane without a valid key holds the finite data of some other row (q|k|v of masked rows are
+          // zero, lanes beyond n read key 0); its logit is masked below (once per lane), so its weight is exactly 0, and
+          // an MFMA column depends on its own lane only -- nothing of such a lane is ever stored.
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float kk = vj ? k[blk][r] : 0.f;
-            const float yy = (q[r] * kk) * a1[blk][r] + a2[blk][r];     // Y = QK/sqrt(df) * (E1+1) + E2
+            const float yy = (q[r] * k[blk][r]) * a1[blk][r] + a2[blk][r];   // Y = QK/sqrt(df) * (E1+1) + E2
             z[blk][r] = yea[r] + yem[r] * yy;                           // FiLM by y before e_out
-            y[blk][r] = vj ? yy : -INFINITY;
-            v[blk][r] = vj ? vn[blk][r] : 0.f;
-            mloc = fmaxf(mloc, y[blk][r]);
+            y[blk][r] = yy;
+            v[blk][r] = vn[blk][r];
+            mloc = fmaxf(mloc, yy);
           }
         }
         // newE += W_out[:, block cb] . z   (the (4 QE)-block pipeline above left the first e_out block in fa)
@@ -824,10 +826,9 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
         if (mloc == 12345.f)
 #endif
         {
-        const float M = row_max16_fused(mloc);
-        const float nM = M == -INFINITY ? 0.f : -M * LOG2E;
-        f32x4 cm[2], cs[2], ca[2];
-        bool under = false;
+        const float M = row_max16_fused(vj ? mloc : -INFINITY);
+        const float nM = !vj ? -INFINITY : (M == -INFINITY ? 0.f : -M * LOG2E);   // a lane without a key: exp2(-inf) = 0
+        float mine;
         {
           float red[16];                                                // 8 x exp(y - M) (0 on invalid keys), 8 x p V
 #pragma unroll
@@ -838,37 +839,36 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
               red[4 * blk + r] = pe;
               red[8 + 4 * blk + r] = pe * v[blk][r];
             }
-          row_sum16_many<16>(red);
-#pragma unroll
-          for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              cs[blk][r] = red[4 * blk + r];
-              ca[blk][r] = red[8 + 4 * blk + r];
-              cm[blk][r] = M;
-              under |= cs[blk][r] == 0.f;
-            }
+          // reduce-scatter over the 16 keys: lane p gets the row's sum of red[p] (p < 8: sum p of channel (blk = p >> 2,
+          // r = p & 3); p >= 8: sum p V of channel p - 8): 33 VALU instead of the 64-80 of sixteen butterflies
+          mine = row_reduce_scatter16(red, p);
         }
-        if (__any(under && M > -INFINITY)) {
+        float* part = a.attn_part + (long long)un.u * (3 * DX);
+        if (!__any(p < 8 && mine == 0.f && M > -INFINITY)) {
+          const int ch = 32 * cb + 16 * ((p >> 2) & 1) + 4 * g + (p & 3);
+          part[(p < 8 ? DX : 2 * DX) + ch] = mine;
+          if (p < 8) part[ch] = M;
+        } else {                                                        // a channel underflowed against the shared shift: exact maxima
+          f32x4 cm[2], cs[2], ca[2];
 #pragma unroll
           for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float yy = y[blk][r];
+              const float yy = vj ? y[blk][r] : -INFINITY;
               const float mx = row_max16(yy);
               const float ex = yy == -INFINITY ? 0.f : __expf(yy - mx);
               cm[blk][r] = mx;
               cs[blk][r] = row_sum16(ex);
-              ca[blk][r] = row_sum16(ex * v[blk][r]);
+              ca[blk][r] = row_sum16(yy == -INFINITY ? 0.f : ex * v[blk][r]);
             }
-        }
-        if (p == 0) {
-          float* dst = a.attn_part + (long long)un.u * (3 * DX) + 32 * cb + 4 * g;
+          if (p == 0) {
+            float* dst = part + 32 * cb + 4 * g;
 #pragma unroll
-          for (int blk = 0; blk < 2; ++blk) {
-            *reinterpret_cast<f32x4*>(dst + 16 * blk) = cm[blk];
-            *reinterpret_cast<f32x4*>(dst + DX + 16 * blk) = cs[blk];
-            *reinterpret_cast<f32x4*>(dst + 2 * DX + 16 * blk) = ca[blk];
+            for (int blk = 0; blk < 2; ++blk) {
+              *reinterpret_cast<f32x4*>(dst + 16 * blk) = cm[blk];
+              *reinterpret_cast<f32x4*>(dst + DX + 16 * blk) = cs[blk];
+              *reinterpret_cast<f32x4*>(dst + 2 * DX + 16 * blk) = ca[blk];
+            }
           }
         }
         }
@@ -1802,9 +1802,9 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
           for (int r = 0; r < 4; ++r) {
             const float yy = (q[r] * k[blk][r]) * a1[blk][r] + a2[blk][r];
             z[blk][r] = yea[r] + yem[r] * yy;
-            y[blk][r] = vj ? yy : -INFINITY;
+            y[blk][r] = yy;                                        // masked below: once per lane, not once per value
             v[blk][r] = vn[blk][r];
-            mloc = fmaxf(mloc, y[blk][r]);
+            mloc = fmaxf(mloc, yy);
           }
         }
         {
@@ -1828,8 +1828,8 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
         if (mloc == 12345.f)
 #endif
         {
-        const float M = row_max16_fused(mloc);
-        const float nM = M == -INFINITY ? 0.f : -M * LOG2E;
+        const float M = row_max16_fused(vj ? mloc : -INFINITY);
+        const float nM = !vj ? -INFINITY : (M == -INFINITY ? 0.f : -M * LOG2E);   // a lane without a key: exp2(-inf) = 0
         f32x4 cm[2], cs[2], ca[2];
         bool under = false;
         {
@@ -1849,12 +1849,13 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
           if (p < 8) statw[ch] = M;
           under = p < 8 && mine == 0.f;
         }
+        (void)cm; (void)cs; (void)ca;
         if (__any(under && M > -INFINITY)) {                         // a channel underflowed against the shared shift: exact maxima
 #pragma unroll
           for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float yy = y[blk][r];
+              const float yy = vj ? y[blk][r] : -INFINITY;
               const float mx = row_max16(yy);
               const float ex = yy == -INFINITY ? 0.f : __expf(yy - mx);
               cm[blk][r] = mx;
