@@ -1938,6 +1938,7 @@ using namespace scgg;
 extern "C" size_t scgg_edge_block_bf16_image_bytes(int32_t dx, int32_t de) {
   if (dx == 256 && de == 128) return (size_t)8 * BlockGeomBF<8, 4>::PH_F4 * 16;
   if (dx == 256 && de == 64) return (size_t)8 * BlockGeomBF<8, 2>::PH_F4 * 16;
+  if (dx == 128 && de == 64) return (size_t)4 * BlockGeomBF<4, 2>::PH_F4 * 16;      // vessel dims (discrete_vessels.yaml)
   return 0;
 }
 
@@ -1948,7 +1949,8 @@ extern "C" int scgg_edge_block_bf16_pack(const float* W_mul, const float* b_mul,
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dx == 256 && de == 128) hipLaunchKernelGGL((edge_block_pack_bf16_kernel<8, 4>), dim3(8), dim3(512), 0, st, a);
   else if (dx == 256 && de == 64) hipLaunchKernelGGL((edge_block_pack_bf16_kernel<8, 2>), dim3(8), dim3(512), 0, st, a);
-  else return fail("edge_block_bf16_pack: unsupported dims dx=%d de=%d (built: 256/128, 256/64)", dx, de);
+  else if (dx == 128 && de == 64) hipLaunchKernelGGL((edge_block_pack_bf16_kernel<4, 2>), dim3(4), dim3(512), 0, st, a);
+  else return fail("edge_block_bf16_pack: unsupported dims dx=%d de=%d (built: 256/128, 256/64, 128/64)", dx, de);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail("edge_block_bf16_pack: %s", hipGetErrorString(e));
 }
@@ -1980,7 +1982,8 @@ extern "C" int scgg_edge_block_bf16(const uint16_t* E_in, uint16_t* newE, const 
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dx == 256 && de == 128) return launch_edge_block_bf16<8, 4>(a, st);
   if (dx == 256 && de == 64) return launch_edge_block_bf16<8, 2>(a, st);
-  return fail("edge_block_bf16: unsupported dims dx=%d de=%d (built: 256/128, 256/64)", dx, de);
+  if (dx == 128 && de == 64) return launch_edge_block_bf16<4, 2>(a, st);
+  return fail("edge_block_bf16: unsupported dims dx=%d de=%d (built: 256/128, 256/64, 128/64)", dx, de);
 }
 
 extern "C" int scgg_attn_merge(const float* attn_part, const uint8_t* node_mask, const float* film, float* newX_pre,

@@ -26,7 +26,7 @@ class NodeEdgeBlockBF16:
             raise _lib.ScggError("the bf16 NodeEdgeBlock runs on the MI355X only; move the module to the GPU")
         nbytes = int(_lib.lib().scgg_edge_block_bf16_image_bytes(self.dx, self.de))
         if nbytes == 0:
-            raise _lib.ScggError(f"edge_block_bf16: dims dx={self.dx} de={self.de} are not built (256/128 and 256/64 are)")
+            raise _lib.ScggError(f"edge_block_bf16: dims dx={self.dx} de={self.de} are not built (256/128, 256/64 and 128/64 are)")
         self.image = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self.refresh()
 
@@ -74,10 +74,15 @@ class NodeEdgeBlockBF16:
         attn = attn if attn is not None else torch.empty(B * n * nch, 3, self.dx, device=X.device)
         b_out = b.e_out.bias.detach().float().contiguous()
         dx = self.dx
+        ev = getattr(self, "kernel_events", None)          # (start, end) torch events: the bench times the pair kernel alone
+        if ev is not None:
+            ev[0].record()
         _lib.check(_lib.lib().scgg_edge_block_bf16(
             _lib.ptr(E_bf16), _lib.ptr(newE), _lib.ptr(m.view(torch.uint8)), _lib.ptr(qkv), C.c_void_p(qkv.data_ptr() + 4 * dx),
             C.c_void_p(qkv.data_ptr() + 8 * dx), 3 * dx, _lib.ptr(film), _lib.ptr(self.image), _lib.ptr(b_out), _lib.ptr(attn), _lib.ptr(units),
             _lib.ptr(unit_count), B, n, dx, self.de, self.n_head, _lib.stream_ptr()), "edge_block_bf16")
+        if ev is not None:
+            ev[1].record()
         pre = torch.zeros(B, n, dx, device=X.device)
         _lib.check(_lib.lib().scgg_attn_merge(_lib.ptr(attn), _lib.ptr(m.view(torch.uint8)), _lib.ptr(film), _lib.ptr(pre), _lib.ptr(rows),
                                               _lib.ptr(row_count), max(int(rows.numel()), 1), n, dx, _lib.stream_ptr()), "attn_merge")

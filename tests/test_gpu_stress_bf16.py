@@ -22,10 +22,11 @@ def make_block(dx, de, dy, n_head, seed):
     return blk, sd
 
 
-@pytest.mark.parametrize("de,n_nodes", [(128, [40, 23, 1, 36]), (64, [33, 48]), (128, [130])])
-def test_bf16_block_matches_fp32_oracle(de, n_nodes):
+@pytest.mark.parametrize("dx,de,n_nodes", [(256, 128, [40, 23, 1, 36]), (256, 64, [33, 48]), (256, 128, [130]),
+                                           (128, 64, [50, 17, 64])])        # last: the vessel dims (discrete_vessels.yaml)
+def test_bf16_block_matches_fp32_oracle(dx, de, n_nodes):
     from semantically_consistent_graph_generation_amd.stress import NodeEdgeBlockBF16
-    dx, dy, n_head = 256, 64, 8
+    dy, n_head = 64, 8 if dx == 256 else 4
     blk, sd = make_block(dx, de, dy, n_head, 3)
     m = fx.ragged_mask(n_nodes)
     B, n = m.shape
