@@ -282,6 +282,17 @@ int scgg_eigen_features(const float* laplacian, const uint8_t* node_mask, int32_
                         int32_t off_ev, float* evec_feat, int32_t ld_vec, int32_t off_vec, float* w_out, float* v_out,
                         void* stream);
 
+/* The same features for graphs of up to 256 nodes (vessel graphs), where the reference's torch.linalg.eigh (:96) is the
+ * slowest call of a step: Householder tridiagonalisation in LDS, all eigenvalues by Sturm-count multisection, and ONLY
+ * the eigenvector columns the features read (column 0 and columns ncc .. ncc + num_eigenvectors - 1, :159-195) by inverse
+ * iteration.  One 1024-thread workgroup per graph.  eval_feat / evec_feat as above; w_out[B,n] ascending eigenvalues;
+ * vsel_out[B,n,1+num_eigenvectors] the selected eigenvector columns (rows of masked nodes zero) before the reference's
+ * column mask (both optional).  n <= 256, num_eigenvectors <= 7. */
+int scgg_eigen_features_tridiag(const float* laplacian, const uint8_t* node_mask, int32_t B, int32_t n,
+                                int32_t num_eigenvalues, int32_t num_eigenvectors, float* eval_feat, int32_t ld_ev,
+                                int32_t off_ev, float* evec_feat, int32_t ld_vec, int32_t off_vec, float* w_out,
+                                float* vsel_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Validity projector of the reverse loop (src/ConStruct/projector/projector_3d_utils.py; created at
  * diffusion_model_discrete_3d.py:636-650 and called once per reverse step at :661).

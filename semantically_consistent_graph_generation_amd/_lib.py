@@ -109,6 +109,7 @@ SIGNATURES = {
     "scgg_masked_cross_entropy": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "scgg_laplacian": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "scgg_eigen_features": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "scgg_eigen_features_tridiag": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
 }
 
 _lib = None

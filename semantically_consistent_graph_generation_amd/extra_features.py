@@ -48,6 +48,7 @@ class ExtraFeatures:
         self.num_eigenvectors = _get(cfg, "num_eigenvectors")
         self.num_eigenvalues = _get(cfg, "num_eigenvalues")
         self.lds_limit = 32                        # largest n of the one-workgroup kernels (adjacency and Jacobi eigen)
+        self.tridiag_limit = 256                   # largest n of the tridiagonalisation kernel (packed matrix in LDS); beyond: rocSOLVER
         self._ws = {}                              # device -> workspace tensor of the tiled adjacency pass
 
     def _workspace(self, B, n, dev):
@@ -118,6 +119,16 @@ class ExtraFeatures:
             evl_dst = torch.empty(B, 1 + self.num_eigenvalues, device=dev)
         if evc_dst is None:
             evc_dst = torch.empty(B, n, 1 + self.num_eigenvectors, device=dev)
+        if n > self.lds_limit and n <= self.tridiag_limit and self.num_eigenvectors <= 7:
+            # 32 < n <= 256: tridiagonalisation in LDS, only the eigenvector columns the features read (eigen_tridiag.hip).
+            # want_raw -> (w [B,n], the selected columns [B,n,1+num_eigenvectors]: column 0, then ncc .. ncc+k-1)
+            w = torch.empty(B, n, device=dev) if want_raw else None
+            V = torch.empty(B, n, 1 + self.num_eigenvectors, device=dev) if want_raw else None
+            _lib.check(_lib.lib().scgg_eigen_features_tridiag(
+                _lib.ptr(lap), _lib.ptr(node_mask.view(torch.uint8)), B, n, self.num_eigenvalues, self.num_eigenvectors,
+                _lib.ptr(evl_dst), evl_dst.shape[-1], evl_off, _lib.ptr(evc_dst), evc_dst.shape[-1], evc_off, _lib.ptr(w),
+                _lib.ptr(V), _lib.stream_ptr()), "eigen_features_tridiag")
+            return (evl_dst, evc_dst, w, V) if want_raw else (evl_dst, evc_dst)
         if n > self.lds_limit:
             w, V = self._eigen_features_library(lap, node_mask, evl_dst, evl_off, evc_dst, evc_off)
             return (evl_dst, evc_dst, w, V) if want_raw else (evl_dst, evc_dst)
@@ -130,7 +141,7 @@ class ExtraFeatures:
         return (evl_dst, evc_dst, w, V) if want_raw else (evl_dst, evc_dst)
 
     def _eigen_features_library(self, lap, node_mask, evl_dst, evl_off, evc_dst, evc_off):
-        """n > 32: ``torch.linalg.eigh`` (rocSOLVER; the reference's own call, :96) and the reference's bookkeeping
+        """n > 256: ``torch.linalg.eigh`` (rocSOLVER; the reference's own call, :96) and the reference's bookkeeping
         (:138-195) as device tensor ops without its host syncs: the gather windows are padded by their full width (value 2 /
         0 beyond column n, as :149-152 / :178-181 pad), and the mode of the rounded first eigenvector (:169-175) is taken
         over the valid nodes (padded slots get distinct values above every valid one: the limit of the reference's randn

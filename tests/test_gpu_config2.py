@@ -91,7 +91,7 @@ def make_cow(n_layers=2, T=12, max_n=16, seed=5, C=14, dims=None):
 @pytest.mark.parametrize("C,T,n_nodes,dims,min_simple,min_degenerate", [
     (14, 12, [13, 6, 10, 1, 16], fx.TINY_DIMS, 20, 1),          # CoW-like, the one-workgroup feature kernels (n <= 32)
     (5, 10, [40, 23, 36], fx.VESSEL_DIMS, 10, 0),               # vessel dims (de = 64) beyond 32 nodes: tiled MFMA adjacency
-])                                                           # pass + library eigensolver
+])                                                           # pass + tridiagonalisation eigen kernel
 def test_chain_with_extra_features_matches_oracle_chain(C, T, n_nodes, dims, min_simple, min_degenerate):
     """T reverse steps, extra features ON (the benchmarked mode), ragged graphs."""
     top_k, seed, base, max_n = 4, 77, 9, max(n_nodes)

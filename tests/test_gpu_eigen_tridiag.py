@@ -1,0 +1,197 @@
+"""GPU parity of the 32 < n <= 256 spectral-feature kernel (scgg_eigen_features_tridiag: Householder tridiagonalisation in LDS,
+Sturm multisection, inverse iteration for the columns the features read) against float64 LAPACK on the host and against the
+oracle's bookkeeping (reference extra_features.py:96-112, :138-195).  Eigenvalues to fp32 round-off of the matrix norm;
+eigenvectors through basis-independent properties (residual, orthonormality) because the basis inside a degenerate eigenspace
+is the solver's choice in the reference as well (SURVEY.md "Hard parts")."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import extra_features as XF
+from oracle import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+KV, KE = 5, 9
+
+
+def make_ef(max_n):
+    from semantically_consistent_graph_generation_amd.extra_features import ExtraFeatures
+    c = SimpleNamespace(model=SimpleNamespace(num_degree=10, max_degree=10, cycle_features=True, num_eigenvectors=KV,
+                                              num_eigenvalues=KE, eigenfeatures=True))
+    return ExtraFeatures(c, SimpleNamespace(max_n_nodes=max_n))
+
+
+def full_from_selected(w, vsel, mask):
+    """[B,n,n] eigenvector matrix holding the selected columns where torch.linalg.eigh would have them (0 elsewhere)."""
+    B, n = mask.shape
+    nv = mask.sum(1).float()
+    ncc = ((w / nv[:, None]) < 1e-5).sum(1)
+    V = torch.zeros(B, n, n)
+    for b in range(B):
+        cols = [0] + [int(ncc[b]) + k for k in range(KV)]
+        for s, c in enumerate(cols):
+            if c < n and (s == 0 or c != 0):
+                V[b, :, c] = vsel[b, :, s]
+    return V, ncc
+
+
+def laplacians(adjs, masks):
+    n = masks.shape[1]
+    Ls = []
+    for A, m in zip(adjs, masks):
+        mf = m.float()
+        A = A * mf[:, None] * mf[None, :]
+        L = torch.diag(A.sum(1)) - A
+        L = L + torch.diag(2.0 * n * (1 - mf))
+        Ls.append(L)
+    return torch.stack(Ls)
+
+
+def tree_adj(n_nodes, n, gen, extra=0, star=False, path=False):
+    A = torch.zeros(n, n)
+    for i in range(1, n_nodes):
+        p = 0 if star else i - 1 if path else int(torch.randint(max(0, i - 6), i, (1,), generator=gen))
+        A[i, p] = A[p, i] = 1
+    for _ in range(extra):
+        i, j = (int(v) for v in torch.randint(0, n_nodes, (2,), generator=gen))
+        if i != j:
+            A[i, j] = A[j, i] = 1
+    return A
+
+
+def check_batch(L, mask, tol_w=3e-5):
+    """-> (w, vsel) after checking eigenvalues, residuals, orthonormality and the feature bookkeeping."""
+    B, n = mask.shape
+    ef = make_ef(n)
+    evl, evc, w, vsel = ef.eigen_features(L.cuda(), mask.cuda(), want_raw=True)
+    torch.cuda.synchronize()
+    w, vsel, evl, evc = w.cpu(), vsel.cpu(), evl.cpu(), evc.cpu()
+    wd = torch.linalg.eigvalsh(L.double())
+    scale = L.abs().sum(-1).amax(-1).clamp(min=1.0)
+    err = ((w.double() - wd).abs().amax(-1) / scale)
+    assert float(err.max()) < tol_w, f"eigenvalues off by {float(err.max()):.2e} of the matrix norm"
+    V, ncc = full_from_selected(w, vsel, mask)
+    ncc_ref = ((wd / mask.sum(1)[:, None]) < 1e-5).sum(1)
+    assert torch.equal(ncc, ncc_ref)
+    for b in range(B):
+        nv = int(mask[b].sum())
+        cols = [c for c in [0] + [int(ncc[b]) + k for k in range(KV)] if c < nv]
+        cols = sorted(set(cols))
+        X = V[b][:, cols].double()
+        assert float(X[~mask[b]].abs().max()) == 0.0 if nv < n else True
+        R = L[b].double() @ X - X * w[b, cols].double()[None]
+        assert float(R.abs().max()) / float(scale[b]) < 2e-5, (b, float(R.abs().max()))
+        G = X.T @ X - torch.eye(len(cols), dtype=torch.float64)
+        assert float(G.abs().max()) < 2e-4, (b, float(G.abs().max()))
+    # bookkeeping: the oracle fed with the device's own decomposition
+    pad = (1.0e6 + torch.arange(n, dtype=torch.float32))[None].expand(B, -1)
+    E = torch.zeros(B, n, n, 2)
+    A = (-(L - torch.diag_embed(torch.diagonal(L, dim1=1, dim2=2)))).clamp(min=0)
+    E[..., 1] = A
+    E[..., 0] = 1 - A
+    oevl, oevc = XF.eigen_features(E, mask, pad_noise=pad, eigh=lambda _: (w, V))
+    np.testing.assert_allclose(evl.numpy(), oevl.numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(evc.numpy(), oevc.numpy())
+    return w, vsel
+
+
+def test_random_vessel_like_graphs():
+    gen = torch.Generator().manual_seed(21)
+    n = 256
+    sizes = [256, 255, 200, 129, 64, 33, 3, 2, 1]
+    mask = fx.ragged_mask(torch.tensor(sizes), n)
+    adjs = [tree_adj(s, n, gen, extra=s // 20) for s in sizes]
+    check_batch(laplacians(adjs, mask), mask)
+
+
+@pytest.mark.parametrize("n", [40, 100, 192])
+def test_smaller_paddings_and_scattered_masks(n):
+    gen = torch.Generator().manual_seed(n)
+    B = 6
+    mask = torch.rand(B, n, generator=gen) < 0.8                               # not a prefix: masked nodes in between
+    mask[0] = True
+    mask[1, 0] = False                                                         # column 0 masked: the first-vector feature is 0
+    adjs = []
+    for b in range(B):
+        idx = torch.nonzero(mask[b]).flatten()
+        A = torch.zeros(n, n)
+        T = tree_adj(len(idx), len(idx), gen, extra=len(idx) // 10)
+        A[idx[:, None], idx[None, :]] = T
+        adjs.append(A)
+    check_batch(laplacians(adjs, mask), mask)
+
+
+def test_degenerate_spectra():
+    """Star (eigenvalue 1 with multiplicity n - 2), path (no degeneracy, tiny gaps), several components + isolated nodes,
+    no edges at all: eigenvalues, the component count and orthonormal vectors inside the degenerate spaces."""
+    gen = torch.Generator().manual_seed(5)
+    n = 128
+    mask = torch.ones(5, n, dtype=torch.bool)
+    mask[3, 100:] = False
+    A_multi = torch.zeros(n, n)
+    A_multi[:50, :50] = tree_adj(50, 50, gen)
+    A_multi[50:110, 50:110] = tree_adj(60, 60, gen, extra=4)
+    perm = torch.randperm(n, generator=gen)
+    A_multi = A_multi[perm][:, perm]
+    adjs = [tree_adj(n, n, gen, star=True), tree_adj(n, n, gen, path=True), A_multi, tree_adj(100, n, gen, star=True),
+            torch.zeros(n, n)]
+    check_batch(laplacians(adjs, mask), mask)
+
+
+def test_same_features_as_the_jacobi_kernel_below_32_nodes():
+    """n <= 32 through both kernels: same component counts and eigenvalue features.  The graphs are connected, so the first
+    eigenvector is constant and the not-LCC flag must be 0 everywhere (the Jacobi kernel is not held to that here: at
+    nv = 23, 1000 / sqrt(nv) = 208.514 sits 1.4e-5 from a rounding boundary of :169 and its vectors carry off-diagonal
+    threshold / gap = 3e-5 of error)."""
+    from semantically_consistent_graph_generation_amd import _lib
+    gen = torch.Generator().manual_seed(9)
+    n, B = 32, 16
+    sizes = torch.randint(2, n + 1, (B,), generator=gen)
+    sizes[0] = n
+    mask = fx.ragged_mask(sizes, n)
+    adjs = [tree_adj(int(s), n, gen, extra=2) for s in sizes]
+    L = laplacians(adjs, mask).cuda()
+    ef = make_ef(n)
+    evl_j, evc_j = ef.eigen_features(L, mask.cuda())
+    evl_t = torch.empty_like(evl_j)
+    evc_t = torch.empty_like(evc_j)
+    _lib.check(_lib.lib().scgg_eigen_features_tridiag(
+        _lib.ptr(L), _lib.ptr(mask.cuda().view(torch.uint8)), B, n, KE, KV, _lib.ptr(evl_t), evl_t.shape[-1], 0,
+        _lib.ptr(evc_t), evc_t.shape[-1], 0, None, None, _lib.stream_ptr()), "eigen_features_tridiag")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(evl_t.cpu().numpy(), evl_j.cpu().numpy(), rtol=1e-4, atol=2e-6)
+    assert float(evc_t[..., 0].abs().max()) == 0.0
+
+
+def test_rejects_what_it_cannot_hold():
+    from semantically_consistent_graph_generation_amd import _lib
+    L = torch.zeros(1, 300, 300, device="cuda")
+    m = torch.ones(1, 300, dtype=torch.uint8, device="cuda")
+    out = torch.empty(1, 10, device="cuda")
+    rc = _lib.lib().scgg_eigen_features_tridiag(_lib.ptr(L), _lib.ptr(m), 1, 300, KE, KV, _lib.ptr(out), 10, 0, None, 0, 0, None,
+                                                None, _lib.stream_ptr())
+    assert rc != 0 and b"256" in _lib.lib().scgg_last_error()
+
+
+def test_time_at_vessel_size(capsys):
+    gen = torch.Generator().manual_seed(2)
+    n, B = 256, 4
+    mask = torch.ones(B, n, dtype=torch.bool)
+    L = laplacians([tree_adj(n, n, gen, extra=12) for _ in range(B)], mask).cuda()
+    ef = make_ef(n)
+    mc = mask.cuda()
+    for _ in range(3):
+        ef.eigen_features(L, mc)
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(20):
+        ef.eigen_features(L, mc)
+    t1.record()
+    torch.cuda.synchronize()
+    ms = t0.elapsed_time(t1) / 20
+    with capsys.disabled():
+        print(f"\n[eigen_tridiag] B={B} n={n}: {ms:.3f} ms per call")
+    assert ms < 5.3                                                            # rocSOLVER's time for the same call
