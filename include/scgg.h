@@ -287,7 +287,8 @@ int scgg_eigen_features(const float* laplacian, const uint8_t* node_mask, int32_
  * the eigenvector columns the features read (column 0 and columns ncc .. ncc + num_eigenvectors - 1, :159-195) by inverse
  * iteration.  One 1024-thread workgroup per graph.  eval_feat / evec_feat as above; w_out[B,n] ascending eigenvalues;
  * vsel_out[B,n,1+num_eigenvectors] the selected eigenvector columns (rows of masked nodes zero) before the reference's
- * column mask (both optional).  n <= 256, num_eigenvectors <= 7. */
+ * column mask (both optional; the whole spectrum is only computed when w_out is given).  n <= 256, num_eigenvalues <= 15,
+ * num_eigenvectors <= 7. */
 int scgg_eigen_features_tridiag(const float* laplacian, const uint8_t* node_mask, int32_t B, int32_t n,
                                 int32_t num_eigenvalues, int32_t num_eigenvectors, float* eval_feat, int32_t ld_ev,
                                 int32_t off_ev, float* evec_feat, int32_t ld_vec, int32_t off_vec, float* w_out,

@@ -13,4 +13,7 @@ for (B, n) in [(4, 256), (4, 128), (4, 64)]:
         _lib.check(_lib.lib().scgg_eigen_features_tridiag(_lib.ptr(L), _lib.ptr(mc), B, n, KE, KV, _lib.ptr(evl), 10, 0, _lib.ptr(evc), 6, 0, _lib.ptr(w), None, _lib.stream_ptr()), "x")
     torch.cuda.synchronize()
     names = ["compact", "load", "tridiag", "bisect", "select", "invit", "gs", "backtr"]
+    names = ["setup", "tridiag", "bisect", "select", "invit", "gs", "backtr", "outputs"]
     print(f"n={n}: " + ", ".join(f"{k} {v / 100:.1f} us" for k, v in zip(names, w[0, :8].cpu().tolist())))
+    print("   step k=8, 10-ns ticks since its start: top done, after barrier A, symv done, after B, combine done, after C, update done:",
+          [int(v) for v in w[0, 9:16].cpu().tolist()])

@@ -6,13 +6,14 @@
 // The reference takes the FULL decomposition from its library (LAPACK / cuSOLVER syevd; rocSOLVER here: 5.3 ms for four
 // 256-node graphs) and then uses n eigenvalues and 1 + num_eigenvectors columns of the eigenvector matrix.  This kernel
 // computes exactly that much:
-//   1. Householder tridiagonalisation of the valid nv x nv block, packed lower triangle in LDS (nv (nv+1) / 2 floats =
-//      129 KiB at nv = 256; masked and padding nodes are decoupled 1 x 1 blocks with eigenvalue 2n and never enter),
+//   1. Householder tridiagonalisation of the valid nv x nv block, lower triangle in LDS with every row padded to whole
+//      quads (130 KiB at nv = 256; masked and padding nodes are decoupled 1 x 1 blocks with eigenvalue 2n and never enter),
 //      reflectors kept in place of the eliminated columns;
-//   2. all nv eigenvalues of the tridiagonal matrix by Sturm-count multisection (4 threads per eigenvalue, the interval
-//      shrinks 5x per round);
+//   2. the eigenvalues the features read (the component count is one Sturm count at the reference's threshold, then
+//      eigenvalue 0 and the next max(num_eigenvalues, num_eigenvectors) ones, one wave each: 64 Sturm counts per round
+//      cut the interval into 65 parts); the whole spectrum, 4 threads per eigenvalue, only when the caller asks for it;
 //   3. the selected eigenvectors (column 0 and columns ncc .. ncc + num_eigenvectors - 1) by inverse iteration on the
-//      tridiagonal matrix (LU with partial pivoting, one wave per vector, three iterations from a fixed start vector), made
+//      tridiagonal matrix (LU with partial pivoting, one wave per vector, two iterations from a fixed start vector), made
 //      orthonormal inside clusters of close eigenvalues, then multiplied by the reflectors;
 //   4. the reference's bookkeeping (:138-195) as in eigen_features.hip.
 // The basis inside a degenerate eigenspace is solver-specific in the reference too (SURVEY.md "Hard parts"); here it is the
@@ -23,7 +24,7 @@
 
 #include "../../include/scgg.h"
 #include "kernels.h"
-#include "mfma_chain.h"
+#include "c16.h"
 
 namespace scgg {
 
@@ -43,30 +44,33 @@ struct TriArgs {
   int B, n, num_ev, num_vec, ld_ev, off_ev, ld_vec, off_vec, lu_batch;
 };
 
-__host__ __device__ inline int tri(int i) { return (i * (i + 1)) >> 1; }
+// Row i of the lower triangle starts at rs(i) and holds 4 (i / 4 + 1) floats: columns 0 .. i, then zeros up to the end of its
+// last quad, so that every quad of four columns is one aligned ds_read_b128.
+__host__ __device__ inline int rs(int i) { const int a = i >> 2; return 4 * (a + 1) * (2 * a + (i & 3)); }
 
-struct TriLayout { int np, oV, oP, oD, oE, oT, oW, oRed, oAct, oSel, oZ, oLU, lu_words, total; };   // offsets in 4-byte words
+struct TriLayout { int np, oV, oP, oD, oE, oW, oRed, oAct, oSel, oZ, oLU, lu_words, total; };   // offsets in 4-byte words
 __host__ __device__ inline TriLayout tri_layout(int n, int nsel, int batch) {
   TriLayout L;
   L.np = (n + 63) & ~63;
-  int o = (tri(n) + 3) & ~3;
+  int o = rs((n + 3) & ~3);                            // whole row blocks of four
   L.oV = o; o += L.np;
   L.oP = o; o += L.np;
   L.oD = o; o += L.np;
   L.oE = o; o += L.np;
-  L.oT = o; o += L.np;
   L.oW = o; o += L.np;
   L.oRed = o; o += 64;
   L.oAct = o; o += L.np / 4;                           // node ids as bytes
-  L.oSel = o; o += 32;
+  L.oSel = o; o += 48;
   L.oZ = o; o += nsel * L.np;
   L.oLU = o;
   L.lu_words = 3 * L.np + 8;
   o += batch * L.lu_words;
+  if (o < L.oZ + 16 * L.np) o = L.oZ + 16 * L.np;      // the same region holds 16 partial p vectors during the tridiagonalisation
   L.total = o;
   return L;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float wave_sum(float v) { return other_half_sum(half_sum(v)); }
 
 // ---- LU with partial pivoting of (T - lam I), T = tridiag(e, d, e); one lane, branch-free steps.  dl: multipliers, rd:
@@ -76,36 +80,45 @@ __device__ __forceinline__ float tri_rcp(float x) {    // reciprocal to ~1 ulp: 
   const float r = __builtin_amdgcn_rcpf(x);
   return r * (2.0f - x * r);
 }
+// Both routines work in chunks of TRI_CH steps whose operands were loaded one chunk earlier: the recurrences are serial, an
+// LDS round trip per step would dominate them.
+constexpr int TRI_CH = 8;
 __device__ void tri_lu_factor(const float* d, const float* e, int nv, float lam, float eps_t, float* dl, float* rd, float* du,
                               unsigned* pv) {
   float dcur = d[0] - lam, ucur = nv > 1 ? e[0] : 0.f;
   unsigned word = 0;
-  for (int i0 = 0; i0 + 1 < nv; i0 += 4) {
-    float sb[4], dn[4], un[4];
+  float ce[TRI_CH + 1], cd[TRI_CH], ne[TRI_CH + 1], nd[TRI_CH];
+  auto load = [&](int i0, float (&le)[TRI_CH + 1], float (&ld)[TRI_CH]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {                 // the loads of four steps at once: one LDS round trip per chunk
-      const int i = min(i0 + u, nv - 2);
-      sb[u] = e[i];
-      dn[u] = d[i + 1] - lam;
-      un[u] = i + 2 < nv ? e[i + 1] : 0.f;
-    }
+    for (int u = 0; u <= TRI_CH; ++u) le[u] = i0 + u < nv - 1 ? e[i0 + u] : 0.f;      // e[nv-1] does not exist: 0
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < TRI_CH; ++u) ld[u] = d[min(i0 + u + 1, nv - 1)];
+  };
+  load(0, ce, cd);
+  for (int i0 = 0; i0 + 1 < nv; i0 += TRI_CH) {
+    if (i0 + TRI_CH + 1 < nv) load(i0 + TRI_CH, ne, nd);
+#pragma unroll
+    for (int u = 0; u < TRI_CH; ++u) {
       const int i = i0 + u;
       if (i + 1 < nv) {
-        const bool sw = fabsf(dcur) < fabsf(sb[u]);
-        float piv = sw ? sb[u] : dcur;
+        const float sb = ce[u], dn = cd[u] - lam, un = ce[u + 1];
+        const bool sw = fabsf(dcur) < fabsf(sb);
+        float piv = sw ? sb : dcur;
         piv = fabsf(piv) < eps_t ? eps_t : piv;
         const float r = tri_rcp(piv);
-        const float f = (sw ? dcur : sb[u]) * r;
-        const float keep = sw ? dn[u] : ucur;      // the super-diagonal entry of the pivot row
-        dcur = (sw ? ucur : dn[u]) - f * keep;
-        ucur = sw ? -f * un[u] : un[u];
+        const float f = (sw ? dcur : sb) * r;
+        const float keep = sw ? dn : ucur;         // the super-diagonal entry of the pivot row
+        dcur = (sw ? ucur : dn) - f * keep;
+        ucur = sw ? -f * un : un;
         word |= (sw ? 1u : 0u) << (i & 31);
         dl[i] = f; rd[i] = r; du[i] = keep;
         if ((i & 31) == 31) { pv[i >> 5] = word; word = 0; }
       }
     }
+#pragma unroll
+    for (int u = 0; u <= TRI_CH; ++u) ce[u] = ne[u];
+#pragma unroll
+    for (int u = 0; u < TRI_CH; ++u) cd[u] = nd[u];
   }
   const float piv = fabsf(dcur) < eps_t ? eps_t : dcur;
   dl[nv - 1] = 0.f; rd[nv - 1] = tri_rcp(piv); du[nv - 1] = 0.f;
@@ -115,45 +128,59 @@ __device__ void tri_lu_factor(const float* d, const float* e, int nv, float lam,
 // z <- (T - lam I)^-1 z with the factors above; one lane
 __device__ void tri_lu_solve(int nv, const float* e, const float* dl, const float* rd, const float* du, const unsigned* pv,
                              float* z) {
-  float bc = z[0];
-  for (int i0 = 0; i0 + 1 < nv; i0 += 4) {
-    float bn[4], f[4];
-    const unsigned word = pv[i0 >> 5];            // i0 is a multiple of 4: one word covers the chunk
+  {
+    float bc = z[0];
+    float cb[TRI_CH], cf[TRI_CH], nb[TRI_CH], nf[TRI_CH];
+    auto load = [&](int i0, float (&lb)[TRI_CH], float (&lf)[TRI_CH]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = min(i0 + u, nv - 2);
-      bn[u] = z[i + 1];
-      f[u] = dl[i];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u;
-      if (i + 1 < nv) {
-        const bool sw = (word >> (i & 31)) & 1u;
-        z[i] = sw ? bn[u] : bc;
-        bc = sw ? bc - f[u] * bn[u] : bn[u] - f[u] * bc;
+      for (int u = 0; u < TRI_CH; ++u) {
+        const int i = min(i0 + u, nv - 2);
+        lb[u] = z[i + 1];                           // not yet overwritten: the sweep writes z[i] behind itself
+        lf[u] = dl[i];
       }
+    };
+    if (nv > 1) load(0, cb, cf);
+    for (int i0 = 0; i0 + 1 < nv; i0 += TRI_CH) {
+      const unsigned word = pv[i0 >> 5];            // i0 is a multiple of 8: one word covers the chunk
+      if (i0 + TRI_CH + 1 < nv) load(i0 + TRI_CH, nb, nf);
+#pragma unroll
+      for (int u = 0; u < TRI_CH; ++u) {
+        const int i = i0 + u;
+        if (i + 1 < nv) {
+          const bool sw = (word >> (i & 31)) & 1u;
+          z[i] = sw ? cb[u] : bc;
+          bc = sw ? bc - cf[u] * cb[u] : cb[u] - cf[u] * bc;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < TRI_CH; ++u) { cb[u] = nb[u]; cf[u] = nf[u]; }
     }
+    z[nv - 1] = bc;
   }
-  z[nv - 1] = bc;
   float x1 = 0.f, x2 = 0.f;
-  for (int i0 = nv - 1; i0 >= 0; i0 -= 4) {
-    float zb[4], r[4], u1[4], u2[4];
+  float cz[TRI_CH], cr[TRI_CH], c1[TRI_CH], c2[TRI_CH], nz[TRI_CH], nr[TRI_CH], n1[TRI_CH], n2[TRI_CH];
+  auto load = [&](int i0, float (&lz)[TRI_CH], float (&lr)[TRI_CH], float (&l1)[TRI_CH], float (&l2)[TRI_CH]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < TRI_CH; ++u) {
       const int i = max(i0 - u, 0);
-      zb[u] = z[i]; r[u] = rd[i]; u1[u] = du[i];
-      u2[u] = (i + 2 < nv && ((pv[i >> 5] >> (i & 31)) & 1u)) ? e[i + 1] : 0.f;
+      lz[u] = z[i]; lr[u] = rd[i]; l1[u] = du[i];
+      l2[u] = (i + 2 < nv && ((pv[i >> 5] >> (i & 31)) & 1u)) ? e[i + 1] : 0.f;
     }
+  };
+  load(nv - 1, cz, cr, c1, c2);
+  for (int i0 = nv - 1; i0 >= 0; i0 -= TRI_CH) {
+    if (i0 - TRI_CH >= 0) load(i0 - TRI_CH, nz, nr, n1, n2);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < TRI_CH; ++u) {
       const int i = i0 - u;
       if (i >= 0) {
-        const float x = (zb[u] - u1[u] * x1 - u2[u] * x2) * r[u];
+        const float x = (cz[u] - c1[u] * x1 - c2[u] * x2) * cr[u];
         z[i] = x;
         x2 = x1; x1 = x;
       }
     }
+#pragma unroll
+    for (int u = 0; u < TRI_CH; ++u) { cz[u] = nz[u]; cr[u] = nr[u]; c1[u] = n1[u]; c2[u] = n2[u]; }
   }
 }
 
@@ -167,8 +194,12 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
   extern __shared__ float smem[];
 #ifdef SCGG_TRI_STAMP
   long long stamp[10];
+  long long st2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TRI_ST2(j) if (t == 0 && k == 8) st2[j] = wall_clock64()
+#else
+#define TRI_ST2(j)
 #endif
-  const int b = blockIdx.x, n = a.n, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int b = blockIdx.x, n = a.n, t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int nsel = 1 + a.num_vec;
   const TriLayout lo = tri_layout(n, nsel, a.lu_batch);
   const int np = lo.np;
@@ -177,7 +208,6 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
   float* pp = smem + lo.oP;
   float* dd = smem + lo.oD;
   float* ee = smem + lo.oE;
-  float* tt = smem + lo.oT;
   float* ww = smem + lo.oW;
   float* red = smem + lo.oRed;
   int* redi = reinterpret_cast<int*>(red);
@@ -185,6 +215,8 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
   int* seli = reinterpret_cast<int*>(smem + lo.oSel);        // [0,8): column, [8,16): -1 own vector / -2 zero / p copy of p
   float* self = smem + lo.oSel + 16;                         // [16,24): the shift used
   float* Z = smem + lo.oZ;
+  float* zq = smem + lo.oSel + 28;                           // four zeros: what a lane beyond the diagonal reads
+  if (t < 4) zq[t] = 0.f;
   const uint8_t* m = a.mask + (long long)b * n;
   const float* L = a.lap + (long long)b * n * n;
 
@@ -204,20 +236,26 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
   const int nv = redi[0] + redi[1] + redi[2] + redi[3];
   const float nvf = (float)nv;
   __syncthreads();
-  for (int idx = t; idx < nv * nv; idx += TRI_THREADS) {
-    const int r = idx / nv, c = idx - r * nv;
-    if (c <= r) Ap[tri(r) + c] = L[act[r] * n + act[c]];
+  {
+    const int nq = (nv + 3) & ~3;                      // rows nv .. nq-1 complete the last row block: zeros
+    for (int idx = t; idx < nq * nq; idx += TRI_THREADS) {
+      const int r = idx / nq, c = idx - r * nq;
+      if (c <= (r | 3)) Ap[rs(r) + c] = (c <= r && r < nv) ? L[act[r] * n + act[c]] : 0.f;   // a row's last quad is padded with 0
+    }
   }
   __syncthreads();
 
   TRI_STAMP(1);
   // ---- 1. Householder tridiagonalisation.  Step k: v from column k, p = tau A v, A -= v w^T + w v^T with w = p - K v.
-  // Three barriers per step: the update of step k also takes the norm of column k + 1 (red[32..48]).
-  const int r4 = t >> 2, q = t & 3;
+  // A wave takes row blocks of four rows, lane c the quad of columns 4c .. 4c+3: every stored element is read once per pass
+  // (one ds_read_b128 per row and lane) and serves its row sum (reduced over the lanes) and its column sum (kept per lane,
+  // the 16 waves' partial vectors are added up afterwards).  v and p sit in registers, one quad per lane.
+  float* scr = smem + lo.oZ;                           // [16][np] partial column sums; free until the inverse iteration
+  const int l4 = lane * 4;
   auto column_norm = [&](int kc) {                     // red[32 + wave] = partial sums of x_i^2, i > kc + 1; red[48] = x_{kc+1}
     const int mc = nv - kc - 1;
     float x = 0.f;
-    if (t < mc) x = Ap[tri(kc + 1 + t) + kc];
+    if (t < mc) x = Ap[rs(kc + 1 + t) + kc];
     const float sq = wave_sum(t > 0 ? x * x : 0.f);
     if (lane == 0) red[32 + wv] = sq;
     if (t == 0) red[48] = x;
@@ -225,13 +263,13 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
   if (nv > 2) column_norm(0);
   __syncthreads();
   for (int k = 0; k + 2 < nv; ++k) {
-    const int mk = nv - k - 1;                         // order of the trailing block (rows / columns k+1 .. nv-1)
+    TRI_ST2(0);
     float sig = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) sig += red[32 + w];
     const float x0 = red[48];
     if (sig == 0.f) {                                  // nothing to eliminate (uniform: sig comes from LDS)
-      if (t == 0) { ee[k] = x0; tt[k] = 0.f; dd[k] = Ap[tri(k) + k]; }
+      if (t == 0) { ee[k] = x0; dd[k] = Ap[rs(k) + k]; Ap[rs(k) + k] = 0.f; }
       __syncthreads();                                 // everybody has read red[32..48]
       if (k + 3 < nv) column_norm(k + 1);
       __syncthreads();
@@ -241,89 +279,132 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
     const float nrm = sqrtf(nrm2);
     const float alpha = x0 >= 0.f ? -nrm : nrm;
     const float tau = 1.0f / (nrm2 - alpha * x0);      // 2 / v.v
-    if (t < mk) {
-      const float v = t == 0 ? x0 - alpha : Ap[tri(k + 1 + t) + k];
-      vv[k + 1 + t] = v;
-      if (t == 0) Ap[tri(k + 1) + k] = v;              // the reflector stays in the eliminated column
+    if (t < np) {                                      // v, zero outside rows k+1 .. nv-1
+      float v = 0.f;
+      if (t == k + 1) v = x0 - alpha;
+      else if (t > k + 1 && t < nv) v = Ap[rs(t) + k];
+      vv[t] = v;
+      if (t == k + 1) Ap[rs(t) + k] = v;               // the reflector stays in the eliminated column,
     }
-    if (t == 0) { ee[k] = alpha; tt[k] = tau; dd[k] = Ap[tri(k) + k]; }
+    if (t == 0) { ee[k] = alpha; dd[k] = Ap[rs(k) + k]; Ap[rs(k) + k] = tau; }       // its tau in the diagonal slot
+    TRI_ST2(1);
     __syncthreads();
-    // p_i = tau sum_j A_ij v_j: thread (row r4, residue q) takes the columns j = k+1+jj, jj = q mod 4; row part from the
-    // packed row, the rest from the packed column.  Four elements per trip so that eight LDS reads are in flight.
-    const bool on = r4 < mk;
-    const int i = k + 1 + r4, base = tri(i);
-    float acc = 0.f;
-    if (on) {
-      const float* Ar = Ap + base + k + 1;
-      const float* vr = vv + k + 1;
-      float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-      int jj = q;
-      for (; jj + 12 <= r4; jj += 16) {
-        const float a0 = Ar[jj], a1 = Ar[jj + 4], a2 = Ar[jj + 8], a3 = Ar[jj + 12];
-        const float v0 = vr[jj], v1 = vr[jj + 4], v2 = vr[jj + 8], v3 = vr[jj + 12];
-        c0 += a0 * v0; c1 += a1 * v1; c2 += a2 * v2; c3 += a3 * v3;
-      }
-      for (; jj <= r4; jj += 4) c0 += Ar[jj] * vr[jj];
-      jj = r4 + 1 + ((q - r4 - 1) & 3);
-      int j = k + 1 + jj, ad = tri(j) + i;
-      for (; jj + 12 < mk; jj += 16) {                 // tri(j + 4 s) - tri(j) = 4 s j + 2 s (4 s + 1)
-        const float a0 = Ap[ad], a1 = Ap[ad + 4 * j + 10], a2 = Ap[ad + 8 * j + 36], a3 = Ap[ad + 12 * j + 78];
-        const float v0 = vv[j], v1 = vv[j + 4], v2 = vv[j + 8], v3 = vv[j + 12];
-        c0 += a0 * v0; c1 += a1 * v1; c2 += a2 * v2; c3 += a3 * v3;
-        ad += 16 * j + 136;
-        j += 16;
-      }
-      for (; jj < mk; jj += 4) {
-        c1 += Ap[ad] * vv[j];
-        ad += 4 * j + 10;
-        j += 4;
-      }
-      acc = (c0 + c1) + (c2 + c3);
-    }
-    acc += SCGG_DPP(acc, 0xB1);
-    acc += SCGG_DPP(acc, 0x4E);
-    const float p = tau * acc;
-    float kp = 0.f;
-    if (on && q == 0) { pp[i] = p; kp = p * vv[i]; }
-    kp = wave_sum(kp);
-    if (lane == 0) red[16 + wv] = kp;
-    __syncthreads();
-    float K2 = 0.f;
+    TRI_ST2(2);
+    const f32x4 vreg = l4 < np ? *reinterpret_cast<const f32x4*>(vv + l4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int A0 = (k + 1) >> 2, A1 = (nv - 1) >> 2;
+    {
+      // this wave's row blocks: A0 + wv + 16 s.  Rows <= k hold reflectors and rows >= nv zeros: v is 0 there, so they add
+      // nothing to the column sums, and their row sums are never read.  Lanes beyond the diagonal quad read the zero quad.
+      f32x2 cpl = {0.f, 0.f}, cph = {0.f, 0.f};
+      float rp[16];
 #pragma unroll
-    for (int w = 0; w < 16; ++w) K2 += red[16 + w];
-    K2 *= tau;                                         // 2 K = tau p.v
-    float nx = 0.f;                                    // this thread's element of column k + 1 after the update
-    if (on) {
-      const float av = vv[i], c = pp[i] - K2 * av;     // A_ij -= v_i p_j + (p_i - 2 K v_i) v_j
-      float* Ar = Ap + base + k + 1;
-      const float* pr = pp + k + 1;
-      const float* vr = vv + k + 1;
-      int jj = q;
-      if (q == 0) {                                    // jj = 0 is column k + 1: next step's column
-        nx = Ar[0] - (av * pr[0] + c * vr[0]);
-        Ar[0] = nx;
-        jj = 4;
+      for (int sb = 0; sb < 4; ++sb) {
+        const int A = A0 + wv + 16 * sb;               // uniform (wv comes from readfirstlane below)
+        if (A <= A1) {
+          const float* rowp = Ap + 8 * A * (A + 1) + l4;   // rs(4A) = 8 A (A + 1), a row of this block is 4 (A + 1) floats
+          f32x4 qd[4];
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) qd[bb] = *reinterpret_cast<const f32x4*>(lane <= A ? rowp + bb * 4 * (A + 1) : zq);
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) {
+            const float vi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vreg[bb]), A));
+            const f32x2 ql = {qd[bb][0], qd[bb][1]}, qh = {qd[bb][2], qd[bb][3]};
+            const f32x2 r2 = ql * f32x2{vreg[0], vreg[1]} + qh * f32x2{vreg[2], vreg[3]};
+            rp[4 * sb + bb] = r2[0] + r2[1];
+            const f32x2 vi2 = {vi, vi};
+            cpl += ql * vi2;
+            cph += qh * vi2;
+          }
+        } else {
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) rp[4 * sb + bb] = 0.f;
+        }
       }
-      for (; jj + 12 <= r4; jj += 16) {
-        const float a0 = Ar[jj], a1 = Ar[jj + 4], a2 = Ar[jj + 8], a3 = Ar[jj + 12];
-        const float p0 = pr[jj], p1 = pr[jj + 4], p2 = pr[jj + 8], p3 = pr[jj + 12];
-        const float v0 = vr[jj], v1 = vr[jj + 4], v2 = vr[jj + 8], v3 = vr[jj + 12];
-        Ar[jj] = a0 - (av * p0 + c * v0);
-        Ar[jj + 4] = a1 - (av * p1 + c * v1);
-        Ar[jj + 8] = a2 - (av * p2 + c * v2);
-        Ar[jj + 12] = a3 - (av * p3 + c * v3);
+      // sixteen wave sums: reduce-scatter inside the 16-lane rows (lane p keeps sum p), then across the four rows
+      float r = row_reduce_scatter16(rp, lane & 15);
+      r = other_half_sum(swap_rows16_sum(r));
+      {
+        const int A = A0 + wv + 16 * (lane >> 2);
+        if (lane < 16 && A <= A1) pp[4 * A + (lane & 3)] = r;
       }
-      for (; jj <= r4; jj += 4) Ar[jj] -= av * pr[jj] + c * vr[jj];
+      if (l4 < np) *reinterpret_cast<f32x4*>(scr + wv * np + l4) = f32x4{cpl[0], cpl[1], cph[0], cph[1]};
     }
-    // norm of column k + 1 below its sub-diagonal element (rows r4 >= 2), sub-diagonal element itself (r4 == 1)
-    const float sq = wave_sum((on && q == 0 && r4 >= 2) ? nx * nx : 0.f);
-    if (lane == 0) red[32 + wv] = sq;
-    if (t == 4) red[48] = nx;                          // r4 == 1, q == 0
+    TRI_ST2(3);
+    __syncthreads();
+    TRI_ST2(4);
+    if (t < 256) {                                     // p_j = tau (row sum + column sums - the diagonal term counted twice)
+      float kp = 0.f;
+      if (t < np) {
+        float p = 0.f;
+        if (t > k && t < nv) {
+          float sacc = pp[t];
+#pragma unroll
+          for (int w = 0; w < 16; ++w) sacc += scr[w * np + t];
+          sacc -= Ap[rs(t) + t] * vv[t];
+          p = tau * sacc;
+        }
+        pp[t] = p;
+        kp = p * vv[t];
+      }
+      kp = wave_sum(kp);
+      if (lane == 0) red[16 + wv] = kp;
+    }
+    TRI_ST2(5);
+    __syncthreads();
+    TRI_ST2(6);
+    {
+      const float K2 = tau * ((red[16] + red[17]) + (red[18] + red[19]));            // 2 K = tau p.v
+      const f32x4 preg = l4 < np ? *reinterpret_cast<const f32x4*>(pp + l4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 creg;                                      // A_ij -= v_i p_j + (p_i - 2 K v_i) v_j
+#pragma unroll
+      for (int e = 0; e < 4; ++e) creg[e] = preg[e] - K2 * vreg[e];
+      const f32x2 pl = {preg[0], preg[1]}, ph = {preg[2], preg[3]}, vl = {vreg[0], vreg[1]}, vh = {vreg[2], vreg[3]};
+#pragma unroll
+      for (int sb = 0; sb < 4; ++sb) {
+        const int A = A0 + wv + 16 * sb;
+        if (A <= A1) {
+          float* rowp = Ap + 8 * A * (A + 1) + l4;
+          f32x4 qd[4];
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) qd[bb] = *reinterpret_cast<const f32x4*>(lane <= A ? rowp + bb * 4 * (A + 1) : zq);
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) {             // rows <= k and >= nv: v_i = c_i = 0, they are written back unchanged
+            const float vi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vreg[bb]), A));
+            const float ci = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(creg[bb]), A));
+            const f32x2 vi2 = {vi, vi}, ci2 = {ci, ci};
+            f32x2 ql = {qd[bb][0], qd[bb][1]}, qh = {qd[bb][2], qd[bb][3]};
+            ql -= vi2 * pl + ci2 * vl;
+            qh -= vi2 * ph + ci2 * vh;
+            qd[bb] = f32x4{ql[0], ql[1], qh[0], qh[1]};
+#pragma unroll
+            for (int e = bb + 1; e < 4; ++e)
+              if (lane == A) qd[bb][e] = 0.f;          // beyond the diagonal: padding
+          }
+          if (lane <= A) {
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) *reinterpret_cast<f32x4*>(rowp + bb * 4 * (A + 1)) = qd[bb];
+          }
+        }
+      }
+      // column k + 1 of this wave's rows (read back behind the wave's own writes): its norm below the sub-diagonal element
+      float sq = 0.f;
+      {
+        const int i = 4 * (A0 + wv + 16 * (lane >> 2)) + (lane & 3);
+        if (lane < 16 && i >= k + 2 && i < nv) {
+          const float nx = Ap[rs(i) + k + 1];
+          if (i == k + 2) red[48] = nx;
+          else sq = nx * nx;
+        }
+      }
+      sq = wave_sum(sq);
+      if (lane == 0) red[32 + wv] = sq;
+    }
+    TRI_ST2(7);
     __syncthreads();
   }
   if (t == 0 && nv > 0) {
-    if (nv >= 2) { dd[nv - 2] = Ap[tri(nv - 2) + nv - 2]; ee[nv - 2] = Ap[tri(nv - 1) + nv - 2]; tt[nv - 2] = 0.f; }
-    dd[nv - 1] = Ap[tri(nv - 1) + nv - 1]; ee[nv - 1] = 0.f; tt[nv - 1] = 0.f;
+    if (nv >= 2) { dd[nv - 2] = Ap[rs(nv - 2) + nv - 2]; ee[nv - 2] = Ap[rs(nv - 1) + nv - 2]; }
+    dd[nv - 1] = Ap[rs(nv - 1) + nv - 1]; ee[nv - 1] = 0.f;
   }
   __syncthreads();
 
@@ -352,24 +433,55 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
   if (nv == 0) { gl = 0.f; gu = 0.f; }
   const float nrmT = fmaxf(fmaxf(fabsf(gl), fabsf(gu)), 1.0f);
   const float eps_t = nrmT * 6e-8f;
-  {
-    const float pivmin = 1e-30f;
-    const float margin = (gu - gl) * 1e-6f + 2.0f * eps_t;
+  const float pivmin = 1e-30f;
+  const float margin = (gu - gl) * 1e-6f + 2.0f * eps_t;
+  auto sturm = [&](float x) {                          // number of eigenvalues of T below x
+    float qv = dd[0] - x;
+    int c = qv < 0.f ? 1 : 0;
+#pragma unroll 4
+    for (int i = 1; i < nv; ++i) {
+      if (fabsf(qv) < pivmin) qv = -pivmin;
+      qv = (dd[i] - x) - pp[i - 1] * __builtin_amdgcn_rcpf(qv);
+      c += qv < 0.f ? 1 : 0;
+    }
+    return c;
+  };
+  // The features read eigenvalue 0 and eigenvalues ncc .. ncc + max(num_ev, num_vec) - 1 (:138-195): ncc is ONE Sturm count at
+  // the reference's threshold (ev = w / n_valid < 1e-5), and each of those eigenvalues is found by its own wave, the 64
+  // lanes cutting the interval into 65 parts per round (5 rounds: 65^5 > 2^30 subdivisions of the Gershgorin interval).
+  float* wsel = smem + lo.oSel + 32;                   // [16] the eigenvalues the features read
+  const int nneed = 1 + max(a.num_ev, a.num_vec);
+  if (wv < nneed && nv > 0) {
+    const int ncc_w = sturm(1e-5f * nvf);
+    const int idx = wv == 0 ? 0 : ncc_w + wv - 1;
+    float lam = 0.f;
+    if (idx < nv) {
+      float blo = gl - margin, bhi = gu + margin;
+      for (int it = 0; it < 5; ++it) {
+        const float h = (bhi - blo) * (1.0f / 65.0f);
+        const int c = sturm(blo + h * (float)(lane + 1));
+        const unsigned long long bal = __ballot(c > idx);          // lanes whose point lies above eigenvalue idx
+        const int pfirst = bal == 0ull ? 64 : __ffsll((long long)bal) - 1;
+        const float nlo = blo + h * (float)pfirst;
+        if (pfirst < 64) bhi = blo + h * (float)(pfirst + 1);
+        blo = nlo;
+      }
+      lam = 0.5f * (blo + bhi);
+    }
+    if (lane == 0) {
+      wsel[wv] = lam;
+      if (wv == 0) redi[36] = ncc_w;
+    }
+  }
+  if (nv == 0 && t == 0) redi[36] = 0;
+  if (a.w_out != nullptr) {                            // the whole spectrum only on request: 4 Sturm counts per eigenvalue and round
     float blo = gl - margin, bhi = gu + margin;
     const int j = t >> 2, s = t & 3;
     if (j < nv) {
       for (int it = 0; it < TRI_ROUNDS; ++it) {
         const float h = (bhi - blo) * 0.2f;
         const float x1 = blo + h, x2 = blo + 2.f * h, x3 = blo + 3.f * h, x4 = blo + 4.f * h;
-        const float x = s == 0 ? x1 : s == 1 ? x2 : s == 2 ? x3 : x4;
-        float qv = dd[0] - x;
-        int c = qv < 0.f ? 1 : 0;
-#pragma unroll 4
-        for (int i = 1; i < nv; ++i) {
-          if (fabsf(qv) < pivmin) qv = -pivmin;
-          qv = (dd[i] - x) - pp[i - 1] * __builtin_amdgcn_rcpf(qv);
-          c += qv < 0.f ? 1 : 0;
-        }
+        const int c = sturm(s == 0 ? x1 : s == 1 ? x2 : s == 2 ? x3 : x4);
         const int f = c > j ? 1 : 0;                  // eigenvalue j lies below x
         const int f0 = __builtin_amdgcn_mov_dpp(f, 0x00, 0xF, 0xF, true), f1 = __builtin_amdgcn_mov_dpp(f, 0x55, 0xF, 0xF, true);
         const int f2 = __builtin_amdgcn_mov_dpp(f, 0xAA, 0xF, 0xF, true), f3 = __builtin_amdgcn_mov_dpp(f, 0xFF, 0xF, 0xF, true);
@@ -386,13 +498,7 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
 
   TRI_STAMP(3);
   // ---- 3. which columns: 0 and ncc .. ncc + num_vec - 1 (:159-195), their shifts
-  {
-    const bool isz = t < nv && ww[t] / nvf < 1e-5f;
-    const unsigned long long bal = __ballot(isz);
-    if (t < 256 && lane == 0) redi[32 + wv] = __popcll(bal);
-  }
-  __syncthreads();
-  const int ncc = redi[32] + redi[33] + redi[34] + redi[35];
+  const int ncc = redi[36];
   if (t == 0) {
     for (int s = 0; s < nsel; ++s) {
       const int c = s == 0 ? 0 : ncc + s - 1;
@@ -402,7 +508,7 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
       else {
         for (int p = 0; p < s; ++p) if (seli[p] == c && seli[8 + p] == -1) src = p;
         if (src == -1) {
-          lam = ww[c];
+          lam = wsel[s];
           for (int p = 0; p < s; ++p)
             if (seli[8 + p] == -1 && fabsf(lam - self[p]) < 10.f * eps_t) lam = self[p] + 10.f * eps_t;
         }
@@ -429,7 +535,7 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
       }
       if (lane == 0) tri_lu_factor(dd, ee, nv, self[s], eps_t, dl, rd, du, pv);
       __builtin_amdgcn_wave_barrier();
-      for (int it = 0; it < 3; ++it) {
+      for (int it = 0; it < 2; ++it) {
         if (lane == 0) tri_lu_solve(nv, ee, dl, rd, du, pv, z);
         __builtin_amdgcn_wave_barrier();
         float ss = 0.f;
@@ -462,7 +568,7 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
         for (int rep = 0; rep < 2; ++rep)
 #pragma unroll
           for (int p = 0; p < s; ++p) {
-            if (seli[8 + p] == -1 && fabsf(ww[seli[s]] - ww[seli[p]]) < 1e-3f * nrmT) {
+            if (seli[8 + p] == -1 && fabsf(wsel[s] - wsel[p]) < 1e-3f * nrmT) {
               float dot = 0.f;
 #pragma unroll
               for (int e = 0; e < 4; ++e) dot += zr[s][e] * zr[p][e];
@@ -498,13 +604,13 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
       xr[e] = i < nv ? Z[wv * np + i] : 0.f;
     }
     for (int k = nv - 3; k >= 0; --k) {
-      const float tau = tt[k];
+      const float tau = Ap[rs(k) + k];
       if (tau == 0.f) continue;
       float ve[4], dot = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int i = lane + 64 * e;
-        ve[e] = (i > k && i < nv) ? Ap[tri(i) + k] : 0.f;
+        ve[e] = (i > k && i < nv) ? Ap[rs(i) + k] : 0.f;
         dot += ve[e] * xr[e];
       }
       dot = wave_sum(dot) * tau;
@@ -530,7 +636,7 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
     if (t == 0) ef[0] = (float)ncc;
     if (t < a.num_ev) {
       const int r = ncc + t;
-      ef[1 + t] = r < n ? (r < nv ? ww[r] : padv) / nvf : 2.0f;            // extension with 2's (:149-151)
+      ef[1 + t] = r < n ? (r < nv ? wsel[1 + t] : padv) / nvf : 2.0f;      // extension with 2's (:149-151)
     }
   }
   // first column, rounded to 3 decimals (:169), mode over the valid nodes (ties -> smallest value)
@@ -591,7 +697,10 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
   __syncthreads();
   TRI_STAMP(8);
   if (t == 0 && b == 0 && a.w_out != nullptr)
-    for (int k = 0; k < 8; ++k) a.w_out[k] = (float)(stamp[k + 1] - stamp[k]);      // 100 MHz ticks
+    for (int k = 0; k < 8; ++k) {
+      a.w_out[k] = (float)(stamp[k + 1] - stamp[k]);      // 100 MHz ticks
+      a.w_out[8 + k] = (float)(st2[k] - st2[0]);
+    }
 #endif
 }
 
@@ -606,13 +715,13 @@ extern "C" int scgg_eigen_features_tridiag(const float* laplacian, const uint8_t
   if (!laplacian || !node_mask) return fail("eigen_features_tridiag: null argument");
   if (B <= 0 || n <= 0) return fail("eigen_features_tridiag: bad shape");
   if (n > TRI_MAXN) return fail("eigen_features_tridiag: n=%d > %d (one workgroup holds the packed matrix in LDS)", n, TRI_MAXN);
-  if (num_eigenvalues < 0 || num_eigenvalues > 256 || num_eigenvectors < 0 || num_eigenvectors + 1 > TRI_MAXSEL)
-    return fail("eigen_features_tridiag: unsupported feature counts (num_eigenvectors <= %d)", TRI_MAXSEL - 1);
+  if (num_eigenvalues < 0 || num_eigenvalues > 15 || num_eigenvectors < 0 || num_eigenvectors + 1 > TRI_MAXSEL)
+    return fail("eigen_features_tridiag: unsupported feature counts (num_eigenvalues <= 15, num_eigenvectors <= %d)", TRI_MAXSEL - 1);
   if ((eval_feat && ld_ev < off_ev + 1 + num_eigenvalues) || (evec_feat && ld_vec < off_vec + 1 + num_eigenvectors))
     return fail("eigen_features_tridiag: bad destination stride");
   const int nsel = 1 + num_eigenvectors;
   const TriLayout l0 = tri_layout(n, nsel, 0);
-  int batch = (TRI_LDS_MAX / 4 - l0.total) / l0.lu_words;
+  int batch = (TRI_LDS_MAX / 4 - l0.oLU) / l0.lu_words;
   if (batch < 1) return fail("eigen_features_tridiag: no LDS left for the LU workspace at n=%d", n);
   if (batch > nsel) batch = nsel;
   const TriLayout lay = tri_layout(n, nsel, batch);

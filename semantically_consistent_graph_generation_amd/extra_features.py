@@ -119,7 +119,7 @@ class ExtraFeatures:
             evl_dst = torch.empty(B, 1 + self.num_eigenvalues, device=dev)
         if evc_dst is None:
             evc_dst = torch.empty(B, n, 1 + self.num_eigenvectors, device=dev)
-        if n > self.lds_limit and n <= self.tridiag_limit and self.num_eigenvectors <= 7:
+        if n > self.lds_limit and n <= self.tridiag_limit and self.num_eigenvectors <= 7 and self.num_eigenvalues <= 15:
             # 32 < n <= 256: tridiagonalisation in LDS, only the eigenvector columns the features read (eigen_tridiag.hip).
             # want_raw -> (w [B,n], the selected columns [B,n,1+num_eigenvectors]: column 0, then ncc .. ncc+k-1)
             w = torch.empty(B, n, device=dev) if want_raw else None
