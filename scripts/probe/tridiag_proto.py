@@ -16,11 +16,13 @@ def tridiag(A):
     d = np.zeros(n, F)
     e = np.zeros(max(n - 1, 0), F)
     H = []
+    amax = F(np.abs(A).max()) if n else F(0)
+    tiny2 = F(1e-20) * amax * amax                      # a column below 1e-10 of the matrix is taken as zero
     for k in range(n - 2):
         x = A[k + 1:, k].copy()
         d[k] = A[k, k]
         sig = F(np.dot(x[1:], x[1:]))
-        if sig == 0:
+        if sig <= tiny2:
             e[k] = x[0]
             H.append((F(0), None))
             continue
@@ -226,3 +228,16 @@ if __name__ == "__main__":
     for name in sys.argv[1:]:
         g = np.load(name)
         print(name, list(g.keys())[:12])
+
+
+def sparse_check():
+    rng = np.random.default_rng(4)
+    for trial in range(30):
+        s = int(rng.integers(10, 41))
+        A = np.zeros((s, s))
+        for _ in range(int(rng.integers(0, 2 * s))):
+            i, j = rng.integers(0, s, 2)
+            if i != j:
+                A[i, j] = A[j, i] = 1
+        L = np.diag(A.sum(1)) - A
+        check(L, f"sparse{trial}")

@@ -236,12 +236,28 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
   const int nv = redi[0] + redi[1] + redi[2] + redi[3];
   const float nvf = (float)nv;
   __syncthreads();
+  float tiny2;                                         // a column whose squared norm is below this is taken as zero
   {
     const int nq = (nv + 3) & ~3;                      // rows nv .. nq-1 complete the last row block: zeros
+    float amax = 0.f;
     for (int idx = t; idx < nq * nq; idx += TRI_THREADS) {
       const int r = idx / nq, c = idx - r * nq;
-      if (c <= (r | 3)) Ap[rs(r) + c] = (c <= r && r < nv) ? L[act[r] * n + act[c]] : 0.f;   // a row's last quad is padded with 0
+      if (c <= (r | 3)) {
+        const float val = (c <= r && r < nv) ? L[act[r] * n + act[c]] : 0.f;         // a row's last quad is padded with 0
+        Ap[rs(r) + c] = val;
+        amax = fmaxf(amax, fabsf(val));
+      }
     }
+#pragma unroll
+    for (int mm = 1; mm < 64; mm <<= 1) amax = fmaxf(amax, __shfl_xor(amax, mm));
+    if (lane == 0) red[wv] = amax;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 16; ++w) amax = fmaxf(amax, red[w]);
+    // Rounding leaves entries of ~1e-8 |A| where exact arithmetic has zeros (isolated nodes, small components), and their
+    // products leave ~1e-16: a reflector built on such a column has tau = 2 / v.v beyond the fp32 range.  Below 1e-10 |A| a
+    // column is dropped, which perturbs the matrix by less than fp32 round-off.
+    tiny2 = 1e-20f * amax * amax;
   }
   __syncthreads();
 
@@ -268,7 +284,7 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
 #pragma unroll
     for (int w = 0; w < 16; ++w) sig += red[32 + w];
     const float x0 = red[48];
-    if (sig == 0.f) {                                  // nothing to eliminate (uniform: sig comes from LDS)
+    if (sig <= tiny2) {                                // nothing to eliminate (uniform: sig comes from LDS)
       if (t == 0) { ee[k] = x0; dd[k] = Ap[rs(k) + k]; Ap[rs(k) + k] = 0.f; }
       __syncthreads();                                 // everybody has read red[32..48]
       if (k + 3 < nv) column_norm(k + 1);

@@ -140,6 +140,25 @@ def test_degenerate_spectra():
     check_batch(laplacians(adjs, mask), mask)
 
 
+def test_sparse_graphs_with_isolated_nodes_and_small_components():
+    """Few random edges (the states early in a reverse chain): many exact zeros in the matrix, which rounding turns into
+    1e-8 leftovers; a reflector built on such a column would have tau beyond the fp32 range."""
+    gen = torch.Generator().manual_seed(4)
+    n = 40
+    for trial in range(8):
+        sizes = torch.tensor([40, 23, 36, 33, 17, 40])
+        mask = fx.ragged_mask(sizes, n)
+        adjs = []
+        for s in sizes.tolist():
+            A = torch.zeros(n, n)
+            for _ in range(int(torch.randint(0, 2 * s, (1,), generator=gen))):
+                i, j = (int(v) for v in torch.randint(0, s, (2,), generator=gen))
+                if i != j:
+                    A[i, j] = A[j, i] = 1
+            adjs.append(A)
+        check_batch(laplacians(adjs, mask), mask)
+
+
 def test_same_features_as_the_jacobi_kernel_below_32_nodes():
     """n <= 32 through both kernels: same component counts and eigenvalue features.  The graphs are connected, so the first
     eigenvector is constant and the not-LCC flag must be 0 everywhere (the Jacobi kernel is not held to that here: at
