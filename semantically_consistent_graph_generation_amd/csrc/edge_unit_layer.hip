@@ -738,13 +738,17 @@ __global__ __launch_bounds__(NW * 64) void edge_unit_layer_x3_kernel(EdgeLayerAr
     const int j = un.j0 + p;
     const bool inb = j < n, vj = mk != 0, live = vj && j != un.i;
     const int jj = inb ? j : 0;
+    // K / V are read without a select per element (a lane without a key has logit -inf, weight 0): its rows must hold
+    // finite numbers.  The rows of masked / padding nodes are never written by the row-list Linears, so such a lane reads
+    // the query's own row instead (valid whenever the unit is).
+    const int jkv = vj ? j : (active ? un.i : 0);
     // the next unit: scalars now, the mask byte of the lane's key in flight until the FFN phases
     const Unit nx = unit_of(slot(it + 1));
     const int nmk = mask_byte(nx);
 
     const cptr kbase = reinterpret_cast<cptr>(a.K + (long long)un.b * n * a.ldqkv);
     const cptr vbase = reinterpret_cast<cptr>(a.V + (long long)un.b * n * a.ldqkv);
-    const unsigned kvoff = 4u * (jj * a.ldqkv + 4 * g);
+    const unsigned kvoff = 4u * (jkv * a.ldqkv + 4 * g);
 
     // per-layer vectors are re-read per unit (L1/L2 hits): hoisted out of the unit loop they would hold ~80 VGPRs
     const float *b_out = a.b_out, *ln1_g = a.ln1_g, *ln1_b = a.ln1_b, *ln2_g = a.ln2_g, *ln2_b = a.ln2_b;
@@ -1744,7 +1748,8 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
     }
     const cptr kbase = reinterpret_cast<cptr>(a.K + (long long)b * n * a.ldqkv);
     const cptr vbase = reinterpret_cast<cptr>(a.V + (long long)b * n * a.ldqkv);
-    const unsigned kvoff = 4u * (jj * a.ldqkv + 4 * g);
+    // no select per K / V element: a lane without a key (logit -inf, weight 0) reads the query's own row, which is written
+    const unsigned kvoff = 4u * ((vj ? j : (active ? row - b * n : 0)) * a.ldqkv + 4 * g);
     // K / V rows of the lane's key, one phase AHEAD: a load that is consumed in the phase that issues it is younger than the
     // phase's weight DMA, so waiting for it (vmcnt counts in order) waited for the DMA to land as well -- a full memory
     // latency in the middle of every phase.  Requested a phase early they are covered by the vmcnt(0) in front of the

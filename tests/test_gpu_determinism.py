@@ -44,6 +44,43 @@ def test_forward_is_bit_reproducible(dims_name, ind, C, n_nodes, L):
     assert bad == 0, f"{bad} of {150 + 30 * L} repeated forwards differ from the first"
 
 
+@pytest.mark.parametrize("dims_name,ind,C,n_nodes,L", [
+    ("tiny", (1, 6, 1), 6, [9, 4, 7, 1], 2),
+    ("construct", (10, 25, 43), 14, [32, 17, 25, 12, 30, 31, 8, 1], 5),
+    ("vessel", (10, 16, 34), 5, [40, 23, 36, 7], 2),
+])
+def test_outputs_do_not_depend_on_what_the_workspace_held(dims_name, ind, C, n_nodes, L):
+    """The caller's workspace is uninitialised memory: whatever it holds (zeros in a fresh process; -1 labels, NaNs or old
+    activations after other work on the device) must not reach the outputs.  Round 3: the fused edge kernel read the K / V
+    rows of masked nodes, which the row-list Linears never write, and relied on their being finite."""
+    from semantically_consistent_graph_generation_amd.transformer_model import GraphTransformer, model_input
+    dims = {"tiny": fx.TINY_DIMS, "construct": fx.CONSTRUCT_DIMS, "vessel": fx.VESSEL_DIMS}[dims_name]
+    m = fx.ragged_mask(n_nodes)
+    if dims_name == "construct":
+        m[2, 3] = m[2, 11] = False                                             # a scattered mask as well
+    B, n = m.shape
+    model = GraphTransformer(L, fx.dims_ns(*ind), dims["hidden_mlp_dims"], dims["hidden_dims"], fx.dims_ns(1, C, 0)).eval()
+    model.load_state_dict(fx.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 5))
+    model = model.cuda()
+    g = torch.Generator().manual_seed(2)
+    E = torch.randn(B, n, n, ind[1], generator=g)
+    inp = model_input(torch.randn(B, n, ind[0], generator=g).cuda(), (0.5 * (E + E.transpose(1, 2))).cuda(),
+                      torch.randn(B, ind[2], generator=g).cuda(), m.cuda())
+    dev = torch.device("cuda", torch.cuda.current_device())
+    model._ensure_engine(dev)
+    model._workspace(B, n, dev)
+    (ws,) = model._ws.values()
+    outs = []
+    for byte in (0, 0xFF, 0x7F, 0x3F):                                         # 0xFF..: NaN as float, -1 as a label
+        ws.fill_(byte)
+        out = model(inp)
+        torch.cuda.synchronize()
+        assert not bool(torch.isnan(out.E).any() or torch.isnan(out.X).any())
+        outs.append((out.E.clone(), out.X.clone()))
+    for e, x in outs[1:]:
+        assert torch.equal(e, outs[0][0]) and torch.equal(x, outs[0][1])
+
+
 def test_reverse_step_inputs_and_logits_are_bit_reproducible():
     """The state route of one reverse step at the benchmark's dims (structural + eigen features on the side stream, then
     the forward) on a fixed state, 100 times."""
