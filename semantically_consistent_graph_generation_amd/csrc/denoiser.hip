@@ -332,7 +332,7 @@ struct Workspace {
   float *Xh, *qkv, *newX, *t1, *t2, *E0, *E1, *y, *ycat, *yt1, *yt2, *film, *hidX, *hidy, *xo;
   int *rows, *row_count, *units, *unit_count, *goff;
   unsigned* chunk_bits;   // [B] valid-chunk bits per graph (launch_build_lists)
-  float *epool, *attn;
+  float *epool, *attn, *epart;
   size_t bytes;
 };
 
@@ -361,6 +361,7 @@ Workspace carve(const scgg_denoiser_config& c, int B, int n, char* base) {
   const size_t nch = (size_t)(n + 15) / 16;                 // 16-key chunks per row (edge_unit_layer.hip)
   w.epool = ar.take<float>((size_t)2 * B * 4 * c.de);       // Etoy stats of E(l), E(l+1)
   w.attn = ar.take<float>(M * nch * 3 * c.dx);
+  w.epart = ar.take<float>(n > POOL_SLICED_MIN_N ? (size_t)B * POOL_SLICED_W * 5 * c.de : 0);   // Etoy parts of large graphs
   w.rows = ar.take<int>(M);
   w.row_count = ar.take<int>(64);
   w.units = ar.take<int>(M * nch);
@@ -611,7 +612,14 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
         ya.y = w.y; ya.ycat = w.ycat; ya.etoy = w.epool + (size_t)(l & 1) * B * 4 * de;
         ya.B = B; ya.dy = dy; ya.ffy = c.dim_ffy; ya.kcat = kcat; ya.dx = dx;
         ya.update = L.predicts_y ? 1 : 0;
-        if (y_pools && L.predicts_y) { ya.pool_X = Xcur; ya.pool_E = Ecur; ya.mask = mask; ya.n = n; ya.de = de; }
+        if (y_pools && L.predicts_y) {
+          ya.pool_X = Xcur; ya.pool_E = Ecur; ya.mask = mask; ya.n = n; ya.de = de;
+          if (n > POOL_SLICED_MIN_N) {   // few large graphs: the pooled E statistics by W workgroups per graph, the y round reads them
+            EdgePoolArgs ep{Ecur, mask, w.epool + (size_t)(l & 1) * B * 4 * de, B, n, de, 4 * de, 0};
+            if (launch_edge_pool_stats_sliced(ep, w.epart, POOL_SLICED_W, st)) return fail("edge_pool_stats: unsupported de=%d or n=%d", de, n);
+            ya.pool_E = nullptr;
+          }
+        }
         // The y round needs nothing from edge kernel l and is not held back for it: one y workgroup (50 VGPRs, 36 KB of
         // LDS at ConStruct dims) fits on a CU beside one edge workgroup (2 x 200 VGPRs per SIMD lane, 122 KB).
         if (L.predicts_y) {

@@ -1514,6 +1514,31 @@ __global__ __launch_bounds__(POOL_T) void edge_pool_stats_kernel(EdgePoolArgs a)
   pool_etoy_graph(ps, a.E + (long long)b * a.n * a.n * a.de, a.n, nv, a.de, a.z + (long long)b * a.z_stride + a.z_offset, tid);
 }
 
+// several workgroups per graph (pool_stats.h): grid (W, B) parts, then one workgroup per graph merges them
+__global__ __launch_bounds__(POOL_T) void edge_pool_part_kernel(EdgePoolArgs a, float* __restrict__ parts, int W) {
+  __shared__ PoolScratch ps;
+  const int w = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int nv = pool_compact_mask(ps, a.mask + (long long)b * a.n, a.n, tid);
+  pool_etoy_part(ps, a.E + (long long)b * a.n * a.n * a.de, a.n, nv, a.de, w, W, parts + ((size_t)b * W + w) * 5 * a.de, tid);
+}
+__global__ __launch_bounds__(POOL_T) void edge_pool_finish_kernel(EdgePoolArgs a, const float* __restrict__ parts, int W) {
+  __shared__ int s_nv;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) {
+    int c = 0;
+    for (int i = 0; i < a.n; ++i) c += a.mask[(long long)b * a.n + i] != 0;
+    s_nv = c;
+  }
+  __syncthreads();
+  pool_etoy_finish(parts + (size_t)b * W * 5 * a.de, W, s_nv, a.de, a.z + (long long)b * a.z_stride + a.z_offset, tid, POOL_T);
+}
+int launch_edge_pool_stats_sliced(const EdgePoolArgs& a, float* parts, int W, hipStream_t st) {
+  if (a.de > 256 || a.de % 4 != 0 || POOL_T % (a.de / 4) != 0 || a.n > 512 || W < 1 || parts == nullptr) return -1;
+  hipLaunchKernelGGL(edge_pool_part_kernel, dim3(W, a.B), dim3(POOL_T), 0, st, a, parts, W);
+  hipLaunchKernelGGL(edge_pool_finish_kernel, dim3(a.B), dim3(POOL_T), 0, st, a, parts, W);
+  return 0;
+}
+
 int launch_edge_pool_stats(const EdgePoolArgs& a, hipStream_t st) {
   if (a.de > 256 || a.de % 4 != 0 || POOL_T % (a.de / 4) != 0 || a.n > 512) return -1;
   hipLaunchKernelGGL(edge_pool_stats_kernel, dim3(a.B), dim3(POOL_T), 0, st, a);

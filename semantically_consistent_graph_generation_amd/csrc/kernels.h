@@ -123,6 +123,10 @@ struct EdgePoolArgs {     // Etoy pooling straight from a hidden (unsymmetrised)
   int B, n, de, z_stride, z_offset;
 };
 int launch_edge_pool_stats(const EdgePoolArgs& a, hipStream_t st);
+// W workgroups per graph; parts: [B][W][5][de] floats of scratch
+int launch_edge_pool_stats_sliced(const EdgePoolArgs& a, float* parts, int W, hipStream_t st);
+constexpr int POOL_SLICED_MIN_N = 64;   // graphs beyond this many nodes: several workgroups per graph for the Etoy statistics
+constexpr int POOL_SLICED_W = 32;
 
 // ---- node / global path -------------------------------------------------------------------------
 enum GemmFlags : int { GEMM_RELU = 1, GEMM_ROWMASK = 2, GEMM_ADD_ONE_COLS = 4 };

@@ -196,6 +196,116 @@ __device__ __forceinline__ void pool_etoy_graph(PoolScratch& ps, const float* Eg
   __syncthreads();
 }
 
+// The same statistics with SEVERAL workgroups per graph (few large graphs: one workgroup per graph leaves the chip idle --
+// four workgroups took 0.76 ms per layer at B = 4, n = 256).  Workgroup w of W takes the slices w S .. w S + S - 1 of the W S
+// slices of the unordered pairs, merges them as above and leaves part[5][DE] = (pairs | mean | M2 | min | max) of its pairs;
+// pool_etoy_finish merges the W parts in order (deterministic) and goes from the unordered pairs to all nv x nv entries.
+__device__ __forceinline__ void pool_etoy_part(PoolScratch& ps, const float* Eg, int n, int nv, int DE, int w, int W, float* part,
+                                               int tid) {
+  const int G4 = DE / 4, S = PS_T / G4, c4 = tid % G4, sl = tid / G4, ST = S * W, gsl = w * S + sl;
+  const float* E = Eg + 4 * c4;
+  f32x4_t k = {0.f, 0.f, 0.f, 0.f}, s1 = k, q = k, mn = {INFINITY, INFINITY, INFINITY, INFINITY},
+          mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  int cnt_t = 0;
+  {
+    int ii = 0, r = gsl;
+    bool more = true;
+    while (more) {
+      f32x4_t x[4], y[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        while (ii < nv - 1 && r >= nv - 1 - ii) { r -= nv - 1 - ii; ++ii; }
+        ok[u] = ii < nv - 1;
+        if (ok[u]) {
+          const long long i = ps.vidx[ii], j = ps.vidx[ii + 1 + r];
+          x[u] = *reinterpret_cast<const f32x4_t*>(E + (i * n + j) * DE);
+          y[u] = *reinterpret_cast<const f32x4_t*>(E + (j * n + i) * DE);
+          r += ST;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) { more = false; continue; }
+        const f32x4_t v = 0.5f * (x[u] + y[u]);
+        if (cnt_t == 0) k = v;
+        ++cnt_t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = v[e] - k[e];
+          s1[e] += d; q[e] += d * d;
+          mn[e] = fminf(mn[e], v[e]); mx[e] = fmaxf(mx[e], v[e]);
+        }
+      }
+    }
+  }
+  const float nt = (float)cnt_t, inv_nt = cnt_t > 0 ? 1.f / nt : 0.f;
+  f32x4_t mean, m2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { mean[e] = k[e] + s1[e] * inv_nt; m2[e] = q[e] - s1[e] * s1[e] * inv_nt; }
+  ps.red[0][tid] = mean; ps.red[1][tid] = m2; ps.red[2][tid] = mn;
+  __syncthreads();
+  const int np_all = nv * (nv - 1) / 2;
+  float na = nt;
+  if (sl == 0) {
+    for (int t = 1; t < S; ++t) {
+      const int g = w * S + t;
+      const int c = g < np_all ? (np_all - g + ST - 1) / ST : 0;           // pairs of slice g: g, g + ST, ...
+      if (c == 0) break;
+      const float nb = (float)c, nab = na + nb;
+      const f32x4_t mb = ps.red[0][t * G4 + c4], qb = ps.red[1][t * G4 + c4], n2 = ps.red[2][t * G4 + c4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = mb[e] - mean[e];
+        mean[e] = na == 0.f ? mb[e] : mean[e] + d * (nb / nab);
+        m2[e] = na == 0.f ? qb[e] : m2[e] + qb[e] + d * d * (na * nb / nab);
+        mn[e] = fminf(mn[e], n2[e]);
+      }
+      na = nab;
+    }
+  }
+  __syncthreads();
+  ps.red[0][tid] = mx;
+  __syncthreads();
+  if (sl == 0) {
+    for (int t = 1; t < S; ++t) {
+      const f32x4_t x2 = ps.red[0][t * G4 + c4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mx[e] = fmaxf(mx[e], x2[e]);
+    }
+    float* o = part + 4 * c4;
+    const f32x4_t cntv = {na, na, na, na};
+    *reinterpret_cast<f32x4_t*>(o) = cntv;
+    *reinterpret_cast<f32x4_t*>(o + DE) = mean;
+    *reinterpret_cast<f32x4_t*>(o + 2 * DE) = m2;
+    *reinterpret_cast<f32x4_t*>(o + 3 * DE) = mn;
+    *reinterpret_cast<f32x4_t*>(o + 4 * DE) = mx;
+  }
+}
+
+// parts [W][5][DE] of one graph -> z = [mean | min | max | biased variance] over all nv x nv entries; any number of threads
+__device__ __forceinline__ void pool_etoy_finish(const float* parts, int W, int nv, int DE, float* z, int tid, int nthreads) {
+  const float cnt = (float)nv * (float)nv, npf = (float)(nv * (nv - 1) / 2);
+  for (int c = tid; c < DE; c += nthreads) {
+    float na = 0.f, mean = 0.f, m2 = 0.f, mn = INFINITY, mx = -INFINITY;
+    for (int w = 0; w < W; ++w) {
+      const float* p = parts + (size_t)w * 5 * DE + c;
+      const float nb = p[0];
+      if (nb == 0.f) continue;
+      const float nab = na + nb, d = p[DE] - mean;
+      m2 = na == 0.f ? p[2 * DE] : m2 + p[2 * DE] + d * d * (na * nb / nab);
+      mean = na == 0.f ? p[DE] : mean + d * (nb / nab);
+      mn = fminf(mn, p[3 * DE]); mx = fmaxf(mx, p[4 * DE]);
+      na = nab;
+    }
+    if (nv > 0) { mn = fminf(mn, 0.f); mx = fmaxf(mx, 0.f); }            // the diagonal
+    const float m = cnt > 0.f ? 2.f * npf * mean / cnt : 0.f;
+    const float dm = mean - m;
+    const float qq = 2.f * (m2 + npf * dm * dm) + (float)nv * m * m;
+    z[c] = m; z[DE + c] = mn; z[2 * DE + c] = mx; z[3 * DE + c] = cnt > 0.f ? qq / cnt : 0.f;
+  }
+}
+
 // Position-aware block (pos_transformer_model.py Xtoy / Etoy inputs of the y update), one graph: Xtoy inputs of the UNMASKED
 // newX (layers.py:15: the mean's numerator runs over every row of the padded batch, the divisor, minimum, maximum and
 // variance over the valid ones) -> zx[4 dx]; Etoy inputs of Y and of dist1 from the row aggregates (every valid row holds
