@@ -268,13 +268,16 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
   // the 16 waves' partial vectors are added up afterwards).  v and p sit in registers, one quad per lane.
   float* scr = smem + lo.oZ;                           // [16][np] partial column sums; free until the inverse iteration
   const int l4 = lane * 4;
-  auto column_norm = [&](int kc) {                     // red[32 + wave] = partial sums of x_i^2, i > kc + 1; red[48] = x_{kc+1}
-    const int mc = nv - kc - 1;
+  // vv holds the raw column of the step at its top: vv[i] = A[i][k] for i > k, 0 elsewhere (written by the update of the
+  // step before, which has those elements in hand); red[32..47] the partial sums of squares below the sub-diagonal element.
+  auto column_norm = [&](int kc) {                     // the same from the stored matrix (first step, and after a dropped column)
     float x = 0.f;
-    if (t < mc) x = Ap[rs(kc + 1 + t) + kc];
-    const float sq = wave_sum(t > 0 ? x * x : 0.f);
+    if (t < np) {
+      if (t > kc && t < nv) x = Ap[rs(t) + kc];
+      vv[t] = x;
+    }
+    const float sq = wave_sum(t > kc + 1 ? x * x : 0.f);
     if (lane == 0) red[32 + wv] = sq;
-    if (t == 0) red[48] = x;
   };
   if (nv > 2) column_norm(0);
   __syncthreads();
@@ -283,10 +286,10 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
     float sig = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) sig += red[32 + w];
-    const float x0 = red[48];
+    const float x0 = vv[k + 1];
     if (sig <= tiny2) {                                // nothing to eliminate (uniform: sig comes from LDS)
       if (t == 0) { ee[k] = x0; dd[k] = Ap[rs(k) + k]; Ap[rs(k) + k] = 0.f; }
-      __syncthreads();                                 // everybody has read red[32..48]
+      __syncthreads();                                 // everybody has read red[32..47] and vv
       if (k + 3 < nv) column_norm(k + 1);
       __syncthreads();
       continue;
@@ -295,18 +298,13 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
     const float nrm = sqrtf(nrm2);
     const float alpha = x0 >= 0.f ? -nrm : nrm;
     const float tau = 1.0f / (nrm2 - alpha * x0);      // 2 / v.v
-    if (t < np) {                                      // v, zero outside rows k+1 .. nv-1
-      float v = 0.f;
-      if (t == k + 1) v = x0 - alpha;
-      else if (t > k + 1 && t < nv) v = Ap[rs(t) + k];
-      vv[t] = v;
-      if (t == k + 1) Ap[rs(t) + k] = v;               // the reflector stays in the eliminated column,
-    }
-    if (t == 0) { ee[k] = alpha; dd[k] = Ap[rs(k) + k]; Ap[rs(k) + k] = tau; }       // its tau in the diagonal slot
+    const float v0 = x0 - alpha;                       // v = column k with its first element replaced
     TRI_ST2(1);
-    __syncthreads();
     TRI_ST2(2);
-    const f32x4 vreg = l4 < np ? *reinterpret_cast<const f32x4*>(vv + l4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 vreg = l4 < np ? *reinterpret_cast<const f32x4*>(vv + l4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (l4 + e == k + 1) vreg[e] = v0;
     const int A0 = (k + 1) >> 2, A1 = (nv - 1) >> 2;
     {
       // this wave's row blocks: A0 + wv + 16 s.  Rows <= k hold reflectors and rows >= nv zeros: v is 0 there, so they add
@@ -356,12 +354,16 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
           float sacc = pp[t];
 #pragma unroll
           for (int w = 0; w < 16; ++w) sacc += scr[w * np + t];
-          sacc -= Ap[rs(t) + t] * vv[t];
+          const float vt = t == k + 1 ? v0 : vv[t];
+          sacc -= Ap[rs(t) + t] * vt;
           p = tau * sacc;
+          kp = p * vt;
         }
         pp[t] = p;
-        kp = p * vv[t];
       }
+      // the reflector stays in the eliminated column (only its head differs from what is stored), its tau in the diagonal
+      // slot of row k.  Nobody else touches these two words in this phase; the passes on either side read the quads around them.
+      if (t == 0) { ee[k] = alpha; dd[k] = Ap[rs(k) + k]; Ap[rs(k) + k] = tau; Ap[rs(k + 1) + k] = v0; }
       kp = wave_sum(kp);
       if (lane == 0) red[16 + wv] = kp;
     }
@@ -406,10 +408,10 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
       float sq = 0.f;
       {
         const int i = 4 * (A0 + wv + 16 * (lane >> 2)) + (lane & 3);
-        if (lane < 16 && i >= k + 2 && i < nv) {
-          const float nx = Ap[rs(i) + k + 1];
-          if (i == k + 2) red[48] = nx;
-          else sq = nx * nx;
+        if (lane < 16 && i > k && i < nv) {
+          const float nx = i >= k + 2 ? Ap[rs(i) + k + 1] : 0.f;             // row k + 1 leaves the active block
+          vv[i] = nx;
+          if (i > k + 2) sq = nx * nx;
         }
       }
       sq = wave_sum(sq);
