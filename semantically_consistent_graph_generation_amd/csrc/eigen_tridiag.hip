@@ -695,7 +695,7 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
     const int ai = valid ? inv[t] : -1;
     if (a.evec_feat != nullptr) {
       float* o = a.evec_feat + ((long long)b * n + t) * a.ld_vec + a.off_vec;
-      o[0] = (valid && pp[ai] != best) ? 1.f : 0.f;
+      o[0] = (valid && pp[ai] != best && ncc != 1) ? 1.f : 0.f;   // one component: constant first vector, see eigen_features.hip
       for (int s = 1; s < nsel; ++s) {
         const int c = seli[s], src = seli[8 + s];
         float v = 0.f;

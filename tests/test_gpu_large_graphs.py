@@ -72,10 +72,11 @@ def test_full_extra_features_beyond_32_nodes(name):
     evl, evc, w, vsel = ef.eigen_features(lap, m.cuda(), want_raw=True)
     torch.cuda.synchronize()
     # the tridiagonalisation kernel returns only the columns the features read: put them where eigh would have them
-    from test_gpu_eigen_tridiag import full_from_selected
+    from test_gpu_eigen_tridiag import full_from_selected, one_component_flags
     V, ncc = full_from_selected(w.cpu(), vsel.cpu(), m)
     pad = (1.0e6 + torch.arange(n, dtype=torch.float32))[None].expand(B, -1)
     oevl, oevc = XF.eigen_features(E, m, pad_noise=pad, eigh=lambda L: (w.cpu(), V))
+    one_component_flags(oevc, ncc)
     np.testing.assert_allclose(evl.cpu().numpy(), oevl.numpy(), rtol=1e-6, atol=1e-6)
     np.testing.assert_array_equal(evc.cpu().numpy(), oevc.numpy())
     np.testing.assert_array_equal(out.X[..., 3:].cpu().numpy(), oevc.numpy())
