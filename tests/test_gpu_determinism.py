@@ -81,6 +81,61 @@ def test_outputs_do_not_depend_on_what_the_workspace_held(dims_name, ind, C, n_n
         assert torch.equal(e, outs[0][0]) and torch.equal(x, outs[0][1])
 
 
+def _run_with_workspace_patterns(model, call, prepare):
+    """call() under four byte patterns in the model's workspace -> all outputs equal, none NaN."""
+    prepare()
+    (ws,) = model._ws.values()
+    outs = []
+    for byte in (0, 0xFF, 0x7F, 0x3F):
+        ws.fill_(byte)
+        out = [t.clone() for t in call()]
+        torch.cuda.synchronize()
+        assert not any(bool(torch.isnan(t).any()) for t in out)
+        outs.append(out)
+    for out in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(out, outs[0]))
+
+
+def test_3d_denoiser_and_sit_do_not_depend_on_what_the_workspace_held():
+    """The same property for the position-aware denoiser (scattered mask, empty first chunk) and the SiT coordinate model."""
+    from semantically_consistent_graph_generation_amd.pos_transformer_model import Graph3DTransformer
+    from semantically_consistent_graph_generation_amd.node_coordinate_diffusion import SiT_models
+    from semantically_consistent_graph_generation_amd.placeholder import PlaceHolder
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator().manual_seed(8)
+    dims, ind, od, L = fx.VESSEL_DIMS, (1, 5, 1, 0), (1, 5, 0, 0), 3
+    model = Graph3DTransformer(L, fx.dims_ns(*ind), dims["hidden_mlp_dims"], dims["hidden_dims"], fx.dims_ns(*od)).eval()
+    model.load_state_dict(fx.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=51))
+    model = model.cuda()
+    B, n = 5, 23
+    mask = torch.rand(B, n, generator=g) < 0.6
+    mask[0] = True
+    mask[2, :16] = False
+    mask[2, 16:] = True
+    E = fx.one_hot_edges(fx.random_labels(mask, 5, 0.2, 9), mask, 5)
+    inp = PlaceHolder(X=mask[..., None].float().to(dev), E=E.to(dev), y=torch.rand(B, 1, generator=g).to(dev),
+                      pos=torch.randn(B, n, 3, generator=g).to(dev), node_mask=mask.to(dev),
+                      radius=torch.zeros(B, n, n, 1, device=dev))
+
+    def call3d():
+        out = model(inp)
+        return out.E, out.X, out.radius
+    _run_with_workspace_patterns(model, call3d, call3d)
+
+    sit = SiT_models["SiT-T"](in_channels=3)
+    sit.load_state_dict(fx.make_state_dict({k: tuple(v.shape) for k, v in sit.state_dict().items()}, seed=604))
+    sit = sit.cuda()
+    m = fx.ragged_mask([70, 33, 1, 12])
+    x = torch.randn(*m.shape, 3, generator=g).to(dev)
+    t = torch.tensor([999, 500, 1, 3]).to(dev)
+    callsit = lambda: (sit(x, t, m.to(dev)),)
+    _run_with_workspace_patterns(sit, callsit, callsit)
+    m2 = fx.ragged_mask([30, 12, 1, 25])                                       # the matrix-pipe attention path (n <= 64)
+    x2 = torch.randn(*m2.shape, 3, generator=g).to(dev)
+    callsit2 = lambda: (sit(x2, t, m2.to(dev)),)
+    _run_with_workspace_patterns(sit, callsit2, callsit2)
+
+
 def test_reverse_step_inputs_and_logits_are_bit_reproducible():
     """The state route of one reverse step at the benchmark's dims (structural + eigen features on the side stream, then
     the forward) on a fixed state, 100 times."""

@@ -377,3 +377,51 @@ def test_fused_edge_layer_matches_the_unfused_forward_and_backward(dims_name, n_
         if err > worst[1]:
             worst = (k, err)
     assert worst[1] < 2e-4, worst
+
+
+def test_fused_training_step_does_not_depend_on_what_freed_memory_held():
+    """The fused forward / backward allocate their factor tensors and partials with torch.empty: after other work on the
+    device those blocks hold old data (NaN patterns, -1 labels).  Same step, fresh memory vs such leftovers: every gradient
+    bit for bit the same."""
+    from semantically_consistent_graph_generation_amd.training import train_forward, masked_cross_entropy
+    from semantically_consistent_graph_generation_amd.transformer_model import GraphTransformer
+    C, L = 5, 2
+    dims = dict(hidden_mlp_dims={"X": 128, "E": 128, "y": 128},
+                hidden_dims={"dx": 128, "de": 64, "dy": 64, "n_head": 4, "dim_ffX": 128, "dim_ffE": 128, "dim_ffy": 128})
+    model = GraphTransformer(L, fx.dims_ns(3, C + 2, 4), dims["hidden_mlp_dims"], dims["hidden_dims"], fx.dims_ns(1, C, 0))
+    model.load_state_dict(fx.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 77))
+    model = model.cuda().train()
+    m = fx.ragged_mask([40, 23, 33, 1])
+    m[0, 5] = m[0, 17] = False                                                 # masked nodes inside a graph
+    B, n = m.shape
+    gen = torch.Generator().manual_seed(13)
+    lab = fx.random_labels(m, C, 0.3, 4)
+    E = torch.cat([fx.one_hot_edges(lab, m, C), torch.randn(B, n, n, 2, generator=gen)], dim=-1)
+    E = (0.5 * (E + E.transpose(1, 2))).cuda()
+    X = (torch.randn(B, n, 3, generator=gen) * m[..., None]).cuda()
+    y = torch.rand(B, 4, generator=gen).cuda()
+    live = (m[:, :, None] & m[:, None, :]) & ~torch.eye(n, dtype=torch.bool)[None]
+    tgt = torch.where(live, lab, torch.full_like(lab, -1)).cuda()
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        pred = train_forward(model, X, E, y, m.cuda(), seed=5)
+        loss = masked_cross_entropy(pred.E, tgt) + 0.3 * (pred.X ** 2).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    def dirty(byte):
+        xs = [torch.full((sz,), byte, dtype=torch.uint8, device="cuda") for _ in range(40)
+              for sz in (300, 5000, 70000, 1 << 20, 1 << 22, 1 << 24, 1 << 26)]
+        torch.cuda.synchronize()
+        del xs
+
+    ref_loss, ref = step()
+    for byte in (0xFF, 0x7F, 0x01):
+        dirty(byte)
+        loss, grads = step()
+        assert loss == ref_loss
+        for k, g in grads.items():
+            assert not bool(torch.isnan(g).any()), k
+            assert torch.equal(g, ref[k]), k
