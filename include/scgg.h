@@ -441,6 +441,17 @@ int scgg_edge_block_bf16(const uint16_t* E_in, uint16_t* newE, const uint8_t* no
 int scgg_attn_merge(const float* attn_part, const uint8_t* node_mask, const float* film, float* newX_pre,
                     const int32_t* rows, const int32_t* row_count, int32_t max_rows, int32_t n, int32_t dx, void* stream);
 
+/* A Linear layer over a list of rows (torch.nn.functional.linear on the rows listed; the other rows of C are not written),
+ * fp32 results from three-term bf16 products on the matrix pipe.  Replaces the q / k / v / x_out Linears of
+ * NodeEdgeBlock.forward (transformer_model.py:178-183, :236-238) for callers outside the engines (stress.py).
+ *   image: scgg_linear_rows_image_bytes(N, K) bytes, 16-byte aligned, filled once per weight by scgg_linear_rows_pack from
+ *   W [N,K] (torch layout) and b [N].  K in {32, 64, 128, 256}.  rows / row_count: flat row indices and their number (device
+ *   scalar), max_rows an upper bound of it.  relu: 0 none, 1 ReLU, 2 tanh-GELU. */
+size_t scgg_linear_rows_image_bytes(int32_t N, int32_t K);
+int scgg_linear_rows_pack(const float* W, const float* b, int32_t N, int32_t K, void* image, void* stream);
+int scgg_linear_rows(const float* A, int32_t lda, const void* image, int32_t N, int32_t K, float* C, int32_t ldc,
+                     const int32_t* rows, const int32_t* row_count, int32_t max_rows, int32_t relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

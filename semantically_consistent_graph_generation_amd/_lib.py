@@ -104,6 +104,9 @@ SIGNATURES = {
     "scgg_edge_block_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                                        _i32, _vp]),
     "scgg_attn_merge": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "scgg_linear_rows_image_bytes": (C.c_size_t, [_i32, _i32]),
+    "scgg_linear_rows_pack": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
+    "scgg_linear_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp]),
     "scgg_dropout": (C.c_int, [_vp, _vp, _i64, C.c_double, C.c_uint64, C.c_uint32, _vp]),
     "scgg_masked_cross_entropy_blocks": (_i64, [_i64]),
     "scgg_masked_cross_entropy": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),

@@ -714,3 +714,58 @@ int launch_node_layer(const NodeLayerArgs& a, int dx, int ffx, int M, hipStream_
 }
 
 }  // namespace scgg
+
+
+// ---------------------------------------------------------------------------------------------------------
+// C ABI: a Linear over a list of rows on the bf16x3 scheme (fp32 results), for callers outside the engines (stress.py: the
+// q | k | v and x_out Linears of the bf16 NodeEdgeBlock, which went through rocBLAS until round 3).
+// image = [fp32 fragments NB KB 256 float4 | three-term bf16 image NB (K/16) 192 float4 | bias padded to 32 NB floats]
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct RowLinearImage { size_t w, w3, b, bytes; int NB, KB; };
+RowLinearImage row_linear_image(int N, int K) {
+  RowLinearImage im;
+  im.NB = (N + 31) / 32; im.KB = K / 32;
+  im.w = 0;
+  im.w3 = (size_t)im.NB * im.KB * 256 * 16;
+  im.b = im.w3 + (size_t)im.NB * (K / 16) * 192 * 16;
+  im.bytes = im.b + (size_t)im.NB * 32 * 4;
+  return im;
+}
+bool row_linear_ok(int N, int K) { return N > 0 && (K == 32 || K == 64 || K == 128 || K == 256); }
+}  // namespace
+
+extern "C" size_t scgg_linear_rows_image_bytes(int32_t N, int32_t K) { return row_linear_ok(N, K) ? row_linear_image(N, K).bytes : 0; }
+
+extern "C" int scgg_linear_rows_pack(const float* W, const float* b, int32_t N, int32_t K, void* image, void* stream) {
+  if (!W || !b || !image) return scgg::fail("linear_rows_pack: null argument");
+  if (!row_linear_ok(N, K)) return scgg::fail("linear_rows_pack: K=%d is not one of 32 / 64 / 128 / 256", K);
+  if (reinterpret_cast<uintptr_t>(image) % 16 != 0) return scgg::fail("linear_rows_pack: image must be 16-byte aligned");
+  const RowLinearImage im = row_linear_image(N, K);
+  char* base = static_cast<char*>(image);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  scgg::PackArgs pa{W, reinterpret_cast<scgg::f32x4_t*>(base + im.w), N, K, im.NB, im.KB};
+  scgg::PackArgs p3{W, reinterpret_cast<scgg::f32x4_t*>(base + im.w3), N, K, im.NB, im.KB};
+  if (scgg::launch_pack_linear(pa, st) || scgg::launch_pack_linear_x3(p3, st) ||
+      scgg::launch_pad_vec(b, reinterpret_cast<float*>(base + im.b), N, im.NB * 32, 0.f, st))
+    return scgg::fail("linear_rows_pack: launch failed");
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : scgg::fail("linear_rows_pack: %s", hipGetErrorString(e));
+}
+
+extern "C" int scgg_linear_rows(const float* A, int32_t lda, const void* image, int32_t N, int32_t K, float* C, int32_t ldc,
+                                const int32_t* rows, const int32_t* row_count, int32_t max_rows, int32_t relu, void* stream) {
+  if (!A || !image || !C || !rows || !row_count) return scgg::fail("linear_rows: null argument");
+  if (!row_linear_ok(N, K) || lda < K || ldc < N || max_rows <= 0 || relu < 0 || relu > 2) return scgg::fail("linear_rows: bad shape");
+  const RowLinearImage im = row_linear_image(N, K);
+  const char* base = static_cast<const char*>(image);
+  const int rbw = im.NB >= 24 ? 8 : (im.NB >= 4 ? 2 : 1);
+  scgg::NodeLinearArgs a{A, reinterpret_cast<const scgg::f32x4_t*>(base + im.w), reinterpret_cast<const float*>(base + im.b), C, rows,
+                         row_count, N, K, im.NB, lda, ldc, rbw, relu};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (scgg::launch_node_linear_x3(a, reinterpret_cast<const scgg::f32x4_t*>(base + im.w3), max_rows, st) != 0) {
+    if (relu > 1 || scgg::launch_node_linear(a, max_rows, st)) return scgg::fail("linear_rows: shape N=%d K=%d not covered", N, K);
+  }
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : scgg::fail("linear_rows: %s", hipGetErrorString(e));
+}

@@ -80,3 +80,31 @@ def test_bf16_block_at_1024_nodes_properties():
     sE = float(newE.abs().max())
     assert float((gE.float().cpu()[:, rows] - newE[:, rows]).abs().max()) / sE < 2e-2
     assert float((gX.cpu() - newX).abs().max()) / float(newX.abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("N,K,M,relu", [(768, 256, 300, 0), (1024, 64, 7, 0), (256, 256, 1024, 1), (384, 128, 77, 0), (96, 64, 40, 0)])
+def test_row_list_linear_matches_torch(N, K, M, relu):
+    """scgg_linear_rows (the q | k | v / FiLM / x_out Linears of the stress path): fp32 results from three-term bf16 products
+    against torch's fp32 Linear on the listed rows (1e-5 of the scale); the other rows of the destination stay untouched."""
+    import ctypes as C
+    from semantically_consistent_graph_generation_amd import _lib
+    g = torch.Generator().manual_seed(N + K)
+    W, b = torch.randn(N, K, generator=g).cuda(), torch.randn(N, generator=g).cuda()
+    A = torch.randn(M, K, generator=g).cuda()
+    keep = torch.rand(M, generator=g) < 0.7
+    keep[0] = True
+    rows = keep.nonzero().flatten().to(torch.int32).cuda()
+    cnt = torch.tensor([rows.numel()], dtype=torch.int32, device="cuda")
+    L = _lib.lib()
+    img = torch.empty(int(L.scgg_linear_rows_image_bytes(N, K)), dtype=torch.uint8, device="cuda")
+    _lib.check(L.scgg_linear_rows_pack(_lib.ptr(W), _lib.ptr(b), N, K, _lib.ptr(img), _lib.stream_ptr()), "pack")
+    out = torch.full((M, N), 7.0, device="cuda")
+    _lib.check(L.scgg_linear_rows(_lib.ptr(A), K, _lib.ptr(img), N, K, _lib.ptr(out), N, _lib.ptr(rows), _lib.ptr(cnt), int(rows.numel()),
+                                  relu, _lib.stream_ptr()), "linear_rows")
+    torch.cuda.synchronize()
+    want = torch.nn.functional.linear(A.double(), W.double(), b.double())
+    want = torch.relu(want) if relu else want
+    kc = keep.cuda()
+    assert float((out[kc].double() - want[kc]).abs().max()) / float(want.abs().max()) < 1e-5
+    assert bool((out[~kc] == 7.0).all())
+    assert L.scgg_linear_rows_image_bytes(N, 48) == 0
