@@ -417,6 +417,11 @@ int scgg_train_edge_stats(const float* E, const uint8_t* mask, int32_t B, int32_
                           int32_t* idx, void* stream);
 int64_t scgg_train_wgrad_slabs(int64_t S, int32_t slab);
 int scgg_train_wgrad(const float* G, int32_t M, const float* X, int32_t N, int64_t S, int32_t slab, float* partial, void* stream);
+/* Sum over the middle index of src [A,R,C] (fp32, C % 4 == 0): out[split][a][c] = sum of the rows of slice `split`
+ * (splits = scgg_train_sum_rows_splits(A, R, C) slices of ceil(R / splits) rows); the caller adds the few slices.  The
+ * reductions autograd would run over the backward kernel's factor tensors (dK | dV over the query rows, per-graph sums). */
+int64_t scgg_train_sum_rows_splits(int64_t A, int64_t R, int32_t C);
+int scgg_train_sum_rows(const float* src, int64_t A, int64_t R, int32_t C, int32_t splits, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Stress configuration (BASELINE.json configs[4]): NodeEdgeBlock.forward (transformer_model.py:165-248, without the y

@@ -110,6 +110,8 @@ SIGNATURES = {
     "scgg_dropout": (C.c_int, [_vp, _vp, _i64, C.c_double, C.c_uint64, C.c_uint32, _vp]),
     "scgg_masked_cross_entropy_blocks": (_i64, [_i64]),
     "scgg_masked_cross_entropy": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "scgg_train_sum_rows_splits": (_i64, [_i64, _i64, _i32]),
+    "scgg_train_sum_rows": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp]),
     "scgg_laplacian": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "scgg_eigen_features": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "scgg_eigen_features_tridiag": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),

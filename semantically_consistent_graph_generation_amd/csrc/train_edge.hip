@@ -564,6 +564,41 @@ __global__ __launch_bounds__(256) void train_edge_stats_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Sum over the middle index: out[split][a][c] = sum over the rows r of slice `split` of src[a][r][c]  (src [A,R,C] fp32,
+// C % 4 == 0).  The backward's per-key gradients (dK | dV summed over the query rows) and per-graph sums of a factor tensor
+// are reductions of this shape over hundreds of MB; torch's generic reduce kernel ran them at ~1 TB/s.  Bound: HBM.
+// Workgroup = (tile of CQ column quads, row slice, a); thread = (column quad, one of 256 / CQ row lanes), eight float4 loads
+// in flight per thread, the row lanes merged through LDS in a fixed order (deterministic).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void train_sum_rows_kernel(const float* __restrict__ src, long long R, int C4, int CQ, int rows_per_split,
+                                                             float* __restrict__ out) {
+  __shared__ f32x4 sh[256];
+  const int tid = threadIdx.x, cq = tid % CQ, rl = tid / CQ, RL = 256 / CQ;
+  const int c4 = blockIdx.x * CQ + cq;
+  const long long a = blockIdx.z, r0 = (long long)blockIdx.y * rows_per_split;
+  const long long r1 = r0 + rows_per_split < R ? r0 + rows_per_split : R;
+  f32x4 acc = splat4(0.f);
+  if (c4 < C4) {
+    const float* p = src + (a * R) * 4ll * C4 + 4ll * c4;
+    long long r = r0 + rl;
+    for (; r + 7ll * RL < r1; r += 8ll * RL) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ld4(p + (r + (long long)u * RL) * 4ll * C4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; r < r1; r += RL) acc += ld4(p + r * 4ll * C4);
+  }
+  sh[tid] = acc;
+  __syncthreads();
+  if (rl == 0 && c4 < C4) {
+    for (int t = 1; t < RL; ++t) acc += sh[t * CQ + cq];
+    *reinterpret_cast<f32x4*>(out + (((long long)blockIdx.y * gridDim.z + a) * C4 + c4) * 4ll) = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Weight gradient: C[M,N] = G^T X and c[M] = column sums of G, G [S,M] and X [S,N] row-major factors written by the
 // backward kernel, S = pair slots (the reduction index, ~2.6e5 at B = 4, n = 256).  Bound: HBM (reads (M + N) 4 bytes per
 // slot).  Grid (slabs, 64x64 output tiles); the 4 waves of a workgroup take the slots of their slab four at a time,
@@ -703,4 +738,27 @@ extern "C" int scgg_train_edge_stats(const float* E, const uint8_t* mask, int32_
   hipLaunchKernelGGL(train_edge_stats_kernel, dim3(slices, B), dim3(256), 0, static_cast<hipStream_t>(stream), E, mask, n, de, out, idx);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail("train_edge_stats: %s", hipGetErrorString(e));
+}
+
+extern "C" int64_t scgg_train_sum_rows_splits(int64_t A, int64_t R, int32_t C) {
+  if (A <= 0 || R <= 0 || C <= 0) return 0;
+  const long long tiles = ((C / 4) + 63) / 64 * A;
+  long long want = 2048 / (tiles > 0 ? tiles : 1);                       // ~8 workgroups per CU over the whole grid
+  if (want < 1) want = 1;
+  const long long by_rows = (R + 63) / 64;                              // at least 64 rows per slice
+  return want < by_rows ? want : by_rows;
+}
+
+extern "C" int scgg_train_sum_rows(const float* src, int64_t A, int64_t R, int32_t C, int32_t splits, float* out, void* stream) {
+  if (!src || !out || A <= 0 || R <= 0 || C <= 0 || splits <= 0) return fail("train_sum_rows: bad arguments");
+  if (C % 4 != 0) return fail("train_sum_rows: C must be a multiple of 4");
+  if (A > 65535 || splits > 65535) return fail("train_sum_rows: grid too large");
+  const int C4 = C / 4;
+  int CQ = 64;
+  while (CQ > 1 && CQ / 2 >= C4) CQ /= 2;                                // power of two >= min(C4, 64): the row lanes take the rest
+  const int rows_per_split = (int)((R + splits - 1) / splits);
+  hipLaunchKernelGGL(train_sum_rows_kernel, dim3((unsigned)((C4 + CQ - 1) / CQ), (unsigned)splits, (unsigned)A), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), src, (long long)R, C4, CQ, rows_per_split, out);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail("train_sum_rows: %s", hipGetErrorString(e));
 }

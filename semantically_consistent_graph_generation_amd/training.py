@@ -189,6 +189,17 @@ def _pack(W, transpose):
     return out
 
 
+def _sum_rows(t):
+    """t [A,R,C] contiguous fp32 -> [A,C], the sum over R (``scgg_train_sum_rows``: the large reductions of the backward's factor
+    tensors; a fixed order of summation, so repeated steps agree bit for bit)."""
+    A, R, Cc = t.shape
+    L = _lib.lib()
+    sp = int(L.scgg_train_sum_rows_splits(A, R, Cc))
+    out = torch.empty(sp, A, Cc, device=t.device)
+    _lib.check(L.scgg_train_sum_rows(_lib.ptr(t), A, R, Cc, sp, _lib.ptr(out), _lib.stream_ptr()), "train_sum_rows")
+    return out.sum(0) if sp > 1 else out[0]
+
+
 def _wgrad(G, X, slab=None):
     """(G^T X, G.sum(0)) for the factor tensors of the backward kernel: split over the pair slots in the library's own
     MFMA kernel (HBM-bound; the generic GEMM took 0.6 ms per call at K = 2.6e5), slabs added in a fixed order."""
@@ -363,9 +374,9 @@ class _FusedEdgeLayer(torch.autograd.Function):
             acc = parts if acc is None else [tuple(x + y for x, y in zip(pa, pb)) for pa, pb in zip(acc, parts)]
             dQ[b0:b0 + nb] = up[..., :dx].sum(2) * inv_sqrt_df
             dyem1[b0:b0 + nb] = up[..., dx:2 * dx].sum((1, 2))
-            dkv = Gn["G_dkv"].view(nb, n, nch * 16, 2 * dx).sum(1)[:, :n]
+            dkv = _sum_rows(Gn["G_dkv"].view(nb, n, nch * 16 * 2 * dx)).view(nb, nch * 16, 2 * dx)[:, :n]   # over the query rows
             dK[b0:b0 + nb], dV[b0:b0 + nb] = dkv[..., :dx], dkv[..., dx:]
-            dyea[b0:b0 + nb] = Gn["G_dnewE"].view(nb, n * nch * 16, de).sum(1) @ Ws[2]    # sum of dz = W_out^T sum of dnewE, per graph
+            dyea[b0:b0 + nb] = _sum_rows(Gn["G_dnewE"].view(nb, n * nch * 16, de)) @ Ws[2]    # sum of dz = W_out^T sum of dnewE, per graph
         (dW_ma, db_ma), (dW_out, db_out), (dW_ff1, db_ff1), (dW_ff2, db_ff2), (ln,) = acc
         dg2, db2, dg1, db1 = ln[:de], ln[de:2 * de], ln[2 * de:3 * de], ln[3 * de:]
         return (dE, dQ, dK, dV, dyea, dyem1, None, None, None, None, None, None,

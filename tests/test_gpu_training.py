@@ -425,3 +425,14 @@ def test_fused_training_step_does_not_depend_on_what_freed_memory_held():
         for k, g in grads.items():
             assert not bool(torch.isnan(g).any()), k
             assert torch.equal(g, ref[k]), k
+
+
+@pytest.mark.parametrize("A,R,Cc", [(2, 256, 65536), (2, 65536, 64), (3, 100, 20), (1, 7, 4), (4, 1000, 260)])
+def test_sum_rows_kernel_against_torch(A, R, Cc):
+    from semantically_consistent_graph_generation_amd.training import _sum_rows
+    t = torch.randn(A, R, Cc, generator=torch.Generator().manual_seed(R)).cuda()
+    got = _sum_rows(t)
+    torch.cuda.synchronize()
+    want = t.double().sum(1)
+    assert float((got.double() - want).abs().max()) / float(want.abs().max()) < 2e-6
+    assert torch.equal(got, _sum_rows(t))
