@@ -167,7 +167,7 @@ __global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
   if (a.update) {
     const int e0 = dy + 4 * a.dx;
     const bool own3 = YG == 1 && a.gm_rowagg != nullptr;
-    const bool own_x = own3 || (YG == 1 && YT == PS_T && a.pool_X != nullptr), own_e = own3 || (YG == 1 && YT == PS_T && a.pool_E != nullptr);
+    const bool own_x = own3 || (YT == PS_T && a.pool_X != nullptr), own_e = own3 || (YT == PS_T && a.pool_E != nullptr);
     for (int idx = tid; idx < YG * kcat; idx += YT) {
       const int g = idx / kcat, c = idx - g * kcat;
       const int b = min(b0 + g, a.B - 1);
@@ -189,11 +189,12 @@ __global__ __launch_bounds__(YT) void y_layer_kernel(YLayerArgs a) {
     } else if (own_x || own_e) {                                   // wave-uniform; the statistics of this graph, straight into cat
       __shared__ PoolScratch ps;
       SCGG_YSTAMP(9);
-      const int nv = pool_compact_mask(ps, a.mask + (size_t)b0 * a.n, a.n, tid);
-      SCGG_YSTAMP(10);
-      if (own_x) pool_xtoy_graph(ps, a.pool_X + (size_t)b0 * a.n * a.dx, nv, a.dx, cat + dy, tid);
-      SCGG_YSTAMP(11);
-      if (own_e) pool_etoy_graph(ps, a.pool_E + (size_t)b0 * a.n * a.n * a.de, a.n, nv, a.de, cat + e0, tid);
+      for (int g = 0; g < YG; ++g) {                                 // the workgroup's graphs in turn
+        const size_t bg = (size_t)min(b0 + g, a.B - 1);
+        const int nv = pool_compact_mask(ps, a.mask + bg * a.n, a.n, tid);
+        if (own_x) pool_xtoy_graph(ps, a.pool_X + bg * a.n * a.dx, nv, a.dx, cat + g * kcat + dy, tid);
+        if (own_e) pool_etoy_graph(ps, a.pool_E + bg * a.n * a.n * a.de, a.n, nv, a.de, cat + g * kcat + e0, tid);
+      }
       SCGG_YSTAMP(12);
     }
   }
@@ -259,8 +260,8 @@ int launch_y_layer(const YLayerArgs& a, hipStream_t st) {
   if (!y_layer_supported(a.dy, a.ffy, a.kcat)) return -1;
   if (a.gm_rowagg != nullptr && (YG != 1 || a.gm_rowaggD == nullptr || a.gm_newX == nullptr || a.mask == nullptr ||
                                  a.kcat != a.dy + 4 * a.dx + 8 * a.de)) return -1;
-  if (a.pool_X != nullptr && (YG != 1 || a.dx % 4 != 0 || a.dx > 512 || PS_T % (a.dx / 4) != 0 || a.n > 512 || a.mask == nullptr)) return -1;
-  if (a.pool_E != nullptr && (YG != 1 || a.de % 4 != 0 || a.de > 256 || PS_T % (a.de / 4) != 0 || a.n > 512 || a.mask == nullptr ||
+  if (a.pool_X != nullptr && (a.dx % 4 != 0 || a.dx > 512 || PS_T % (a.dx / 4) != 0 || a.n > 512 || a.mask == nullptr)) return -1;
+  if (a.pool_E != nullptr && (a.de % 4 != 0 || a.de > 256 || PS_T % (a.de / 4) != 0 || a.n > 512 || a.mask == nullptr ||
                               a.kcat != a.dy + 4 * a.dx + 4 * a.de)) return -1;
   const size_t lds = y_layer_lds(a.dy, a.ffy, a.kcat);
   static size_t attr_lds[MAX_DEVICES] = {};   // per device: the largest size asked for so far (engines of different widths share the kernel)
