@@ -149,6 +149,31 @@ def test_degenerate_spectra():
     check_batch(laplacians(adjs, mask), mask)
 
 
+def test_dense_and_regular_graphs():
+    """Complete graph (eigenvalue n with multiplicity n - 1), cycle (every non-zero eigenvalue double), grid, barbell, complete
+    bipartite graph: norms up to 2 (n - 1), heavy degeneracy away from zero."""
+    n = 100
+    sizes = [64, 100, 100, 60, 80]
+    mask = fx.ragged_mask(torch.tensor(sizes), n)
+    A = [torch.zeros(n, n) for _ in sizes]
+    A[0][:64, :64] = 1 - torch.eye(64)
+    for i in range(100):
+        A[1][i, (i + 1) % 100] = A[1][(i + 1) % 100, i] = 1
+    for i in range(10):
+        for j in range(10):
+            a = i * 10 + j
+            if i + 1 < 10:
+                A[2][a, a + 10] = A[2][a + 10, a] = 1
+            if j + 1 < 10:
+                A[2][a, a + 1] = A[2][a + 1, a] = 1
+    A[3][:30, :30] = 1 - torch.eye(30)
+    A[3][30:60, 30:60] = 1 - torch.eye(30)
+    A[3][29, 30] = A[3][30, 29] = 1
+    A[4][:40, 40:80] = 1
+    A[4][40:80, :40] = 1
+    check_batch(laplacians(A, mask), mask)
+
+
 def test_sparse_graphs_with_isolated_nodes_and_small_components():
     """Few random edges (the states early in a reverse chain): many exact zeros in the matrix, which rounding turns into
     1e-8 leftovers; a reflector built on such a column would have tau beyond the fp32 range."""
