@@ -15,5 +15,5 @@ for (B, n) in [(4, 256), (4, 128), (4, 64)]:
     names = ["compact", "load", "tridiag", "bisect", "select", "invit", "gs", "backtr"]
     names = ["setup", "tridiag", "bisect", "select", "invit", "gs", "backtr", "outputs"]
     print(f"n={n}: " + ", ".join(f"{k} {v / 100:.1f} us" for k, v in zip(names, w[0, :8].cpu().tolist())))
-    print("   step k=8, 10-ns ticks since its start: top done, after barrier A, symv done, after B, combine done, after C, update done:",
-          [int(v) for v in w[0, 9:16].cpu().tolist()])
+    print("   step k=8, 10-ns ticks since its start: top done, symv done, after barrier B, combine done, after barrier C, update done:",
+          [int(w[0, 8 + k].item()) for k in (1, 3, 4, 5, 6, 7)])

@@ -300,7 +300,6 @@ __global__ __launch_bounds__(TRI_THREADS) void eigen_features_tridiag_kernel(Tri
     const float tau = 1.0f / (nrm2 - alpha * x0);      // 2 / v.v
     const float v0 = x0 - alpha;                       // v = column k with its first element replaced
     TRI_ST2(1);
-    TRI_ST2(2);
     f32x4 vreg = l4 < np ? *reinterpret_cast<const f32x4*>(vv + l4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 4; ++e)
