@@ -404,24 +404,40 @@ typedef struct scgg_train_edge_args {
   uint32_t k0, k1, site1, site2, site3;
 } scgg_train_edge_args;
 int scgg_train_edge_pack(const float* W, int32_t rows, int32_t cols, int32_t transpose, float* out, void* stream);
+/* the same for up to ten matrices in one launch (a layer's five weights, plain and transposed) */
+typedef struct scgg_train_pack_list {
+  const float* W[10];
+  float* out[10];
+  int32_t rows[10], cols[10], transpose[10];
+  int32_t count;
+} scgg_train_pack_list;
+int scgg_train_edge_pack_multi(const scgg_train_pack_list* l, void* stream);
 int scgg_train_edge_forward(const scgg_train_edge_args* a, void* stream);
 int scgg_train_edge_backward(const scgg_train_edge_args* a, void* stream);
 /* the weight gradient of one Linear from the backward's factors (what autograd's `grad_out.T @ input` and
- * `grad_out.sum(0)` do for nn.Linear): G [S,M], X [S,N] -> partial [scgg_train_wgrad_slabs(S, slab)][M*N + M]; every partial
- * holds G^T X and the column sums of G over a quarter of a slab of `slab` slots; the caller adds the partials (every
- * element of every partial is written).  M, N, slab multiples of 16. */
+ * `grad_out.sum(0)` do for nn.Linear): G [S,M], X [S,N] -> partial rows r = 0 .. scgg_train_wgrad_slabs(S, slab) - 1 at
+ * partial + r * ld_partial (0: M*N + M), each [M*N | M] = G^T X and the column sums of G over a slab of `slab` slots; the
+ * caller adds the rows (every element of every row is written).  A row stride wider than M*N + M lets the partials of
+ * several products share one buffer and one final sum.  M, N, slab multiples of 16. */
 /* Etoy's pooling of the layer input for the y update (layers.py:34-41), one read of E: per graph b and slice s (rows i = s,
  * s + slices, ...) out[b][s] = [count | mean | M2 | min | max] x de and idx[b][s] = [argmin | argmax] x de (pair index i n + j);
- * the caller merges the slices (pairwise variance update). */
+ * scgg_train_edge_stats_finish merges the slices in index order (pairwise variance update; ties of an extremum: the smaller
+ * pair index) into stats [B, 4 de] = mean | min | max | var (Etoy's output) and mean / count / imn / imx [B, de] (what
+ * scgg_train_edge_backward takes as st_*). */
 int scgg_train_edge_stats(const float* E, const uint8_t* mask, int32_t B, int32_t n, int32_t de, int32_t slices, float* out,
                           int32_t* idx, void* stream);
+int scgg_train_edge_stats_finish(const float* out, const int32_t* idx, int32_t B, int32_t slices, int32_t de, float* stats,
+                                 float* mean, float* count, int32_t* imn, int32_t* imx, void* stream);
 int64_t scgg_train_wgrad_slabs(int64_t S, int32_t slab);
-int scgg_train_wgrad(const float* G, int32_t M, const float* X, int32_t N, int64_t S, int32_t slab, float* partial, void* stream);
-/* Sum over the middle index of src [A,R,C] (fp32, C % 4 == 0): out[split][a][c] = sum of the rows of slice `split`
- * (splits = scgg_train_sum_rows_splits(A, R, C) slices of ceil(R / splits) rows); the caller adds the few slices.  The
+int scgg_train_wgrad(const float* G, int32_t M, const float* X, int32_t N, int64_t S, int32_t slab, float* partial,
+                     int64_t ld_partial, void* stream);
+/* Sum over the middle index of src [A,R,C] (fp32, C % 4 == 0): out[split * ld_split + a * C + c] = sum of the rows of slice
+ * `split` (splits = scgg_train_sum_rows_splits(A, R, C) slices of ceil(R / splits) rows; ld_split 0: A * C; wider: the
+ * call fills graphs [b0, b0 + A) of a [splits, B, C] buffer); the caller adds the few slices.  The
  * reductions autograd would run over the backward kernel's factor tensors (dK | dV over the query rows, per-graph sums). */
 int64_t scgg_train_sum_rows_splits(int64_t A, int64_t R, int32_t C);
-int scgg_train_sum_rows(const float* src, int64_t A, int64_t R, int32_t C, int32_t splits, float* out, void* stream);
+int scgg_train_sum_rows(const float* src, int64_t A, int64_t R, int32_t C, int32_t splits, float* out, int64_t ld_split,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Stress configuration (BASELINE.json configs[4]): NodeEdgeBlock.forward (transformer_model.py:165-248, without the y

@@ -129,6 +129,7 @@ def main():
     t0 = time.perf_counter()
     for it in range(a.steps):
         losses.append(step(a.warmup + it))
+    host_issue = time.perf_counter() - t0                      # the host has queued every launch; the device may still run
     sync()
     if dist:
         dist.barrier()
@@ -146,7 +147,7 @@ def main():
         out = {"workload": (f"training step, vessel dims, B={a.batch}/GPU, n<={a.n}, 5 layers, C=5, extra features on, dropout 0.1 (layers), "
                             f"AdamW, {'gradient all_reduce over ' + str(world) + ' ranks' if world > 1 else 'one GPU'}"),
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "graphs_per_s": world * a.batch / ms * 1e3,
-               "scaling": "weak", "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "replicas_identical": same,
+               "host_issue_ms_per_step": host_issue * 1e3 / a.steps, "scaling": "weak", "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "replicas_identical": same,
                "data": "stub (launcher rehearsal, not a measurement)" if a.stub_gloo else "synthetic",
                "train_mode": os.environ.get("SCGG_TRAIN_MODE", "fused")}
         if not a.stub_gloo:

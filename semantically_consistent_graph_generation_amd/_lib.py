@@ -44,13 +44,20 @@ class TrainEdgeArgs(C.Structure):       # scgg_train_edge_args (include/scgg.h)
                [("inv_sqrt_df", C.c_float), ("p", C.c_float)] + [(k, C.c_uint32) for k in ("k0", "k1", "site1", "site2", "site3")]
 
 
+class TrainPackList(C.Structure):       # scgg_train_pack_list (include/scgg.h)
+    _fields_ = [("W", C.c_void_p * 10), ("out", C.c_void_p * 10), ("rows", C.c_int32 * 10), ("cols", C.c_int32 * 10),
+                ("transpose", C.c_int32 * 10), ("count", C.c_int32)]
+
+
 SIGNATURES = {
     "scgg_train_edge_pack": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "scgg_train_edge_forward": (C.c_int, [C.POINTER(TrainEdgeArgs), _vp]),
     "scgg_train_edge_backward": (C.c_int, [C.POINTER(TrainEdgeArgs), _vp]),
     "scgg_train_edge_stats": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "scgg_train_wgrad_slabs": (_i64, [_i64, _i32]),
-    "scgg_train_wgrad": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp]),
+    "scgg_train_wgrad": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _vp, _i64, _vp]),
+    "scgg_train_edge_pack_multi": (C.c_int, [C.POINTER(TrainPackList), _vp]),
+    "scgg_train_edge_stats_finish": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "scgg_version": (C.c_int, []),
     "scgg_last_error": (C.c_char_p, []),
     "scgg_denoiser_create": (_vp, [C.POINTER(DenoiserConfig)]),
@@ -111,7 +118,7 @@ SIGNATURES = {
     "scgg_masked_cross_entropy_blocks": (_i64, [_i64]),
     "scgg_masked_cross_entropy": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "scgg_train_sum_rows_splits": (_i64, [_i64, _i64, _i32]),
-    "scgg_train_sum_rows": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "scgg_train_sum_rows": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
     "scgg_laplacian": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "scgg_eigen_features": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "scgg_eigen_features_tridiag": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),

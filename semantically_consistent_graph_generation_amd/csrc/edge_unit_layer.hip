@@ -1654,7 +1654,12 @@ struct BlockGeomBF {
   static constexpr int B_CB = 4 * QE + IBE;                  // e_mul, e_add (q-major, two row blocks each), e_out slice
   static constexpr int BIAS_F4 = 64;
   static constexpr int PH_F4 = BIAS_F4 + B_CB * 64;          // one bf16 block = 64 lanes x 16 B
-  static constexpr size_t lds_bytes(int nw) { return (size_t)2 * PH_F4 * 16 + (size_t)nw * 6 * DX * 4; }   // images, row vectors, partials
+  // When all NXB phase images fit LDS beside the row vectors and partials (vessel dims: 53 + 37 KB) they are loaded once per
+  // workgroup and the unit loop has NO barrier: the waves of a SIMD drift apart, one's vector work meets another's MFMAs.
+  static constexpr bool resident(int nw) { return (size_t)NXB * PH_F4 * 16 + (size_t)nw * 6 * DX * 4 <= 144 * 1024; }
+  static constexpr size_t lds_bytes(int nw) {                // images, row vectors, partials
+    return (size_t)(resident(nw) ? NXB : 2) * PH_F4 * 16 + (size_t)nw * 6 * DX * 4;
+  }
 };
 
 __device__ __forceinline__ unsigned bf16_rn(float x) {       // round to nearest even, as torch's .to(bfloat16)
@@ -1725,8 +1730,9 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
   using G = BlockGeomBF<NXB, NEB>;
   constexpr int DX = G::DX, DE = G::DE, IBE = G::IBE, QE = G::QE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool RES = G::resident(NW);
   f32x4* wbuf = reinterpret_cast<f32x4*>(smem);
-  float* fl = reinterpret_cast<float*>(wbuf + 2 * G::PH_F4);
+  float* fl = reinterpret_cast<float*>(wbuf + (RES ? NXB : 2) * G::PH_F4);
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* vecw = fl + wave * (3 * DX);
@@ -1744,11 +1750,20 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define SCGG_BF(v) __builtin_bit_cast(bf16x8, v)
 
-  stage_phase_unit<G::PH_F4, NW>(a.phase_img, wbuf, wave, lane);
+  if (RES) {
+#pragma unroll 1
+    for (int cb = 0; cb < NXB; ++cb)
+      stage_phase_unit<G::PH_F4, NW>(a.phase_img + (size_t)cb * G::PH_F4, wbuf + cb * G::PH_F4, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                       // the only barrier of the kernel in this mode
+  } else {
+    stage_phase_unit<G::PH_F4, NW>(a.phase_img, wbuf, wave, lane);
+  }
   int cur = 0;
   for (int it = 0; it < iters; ++it) {
     const int uidx = (it * (int)gridDim.x + (int)blockIdx.x) * NW + wave;
     const bool active = uidx < count;
+    if (RES && !active) break;                             // no barrier ahead: a wave without a unit is done
     const int u = active ? __builtin_amdgcn_readfirstlane(a.units[uidx]) : 0;
     const int row = u / nch, j0 = (u - row * nch) * 16, b = row / n;
     const int j = j0 + p;
@@ -1792,11 +1807,14 @@ __global__ __launch_bounds__(NW * 64) void edge_block_bf16_kernel(EdgeBlockArgs 
     }
 #pragma unroll 1
     for (int cb = 0; cb < NXB; ++cb) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the phase image (and the unit's loads) has landed
-      __syncthreads();
-      stage_phase_unit<G::PH_F4, NW>(a.phase_img + (size_t)((cb + 1) % NXB) * G::PH_F4, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
-      const float* bias = reinterpret_cast<const float*>(wbuf + cur * G::PH_F4);
-      const u32x4* W = reinterpret_cast<const u32x4*>(wbuf + cur * G::PH_F4 + G::BIAS_F4);
+      if (!RES) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the phase image (and the unit's loads) has landed
+        __syncthreads();
+        stage_phase_unit<G::PH_F4, NW>(a.phase_img + (size_t)((cb + 1) % NXB) * G::PH_F4, wbuf + (cur ^ 1) * G::PH_F4, wave, lane);
+      }
+      const int slot = RES ? cb : cur;
+      const float* bias = reinterpret_cast<const float*>(wbuf + slot * G::PH_F4);
+      const u32x4* W = reinterpret_cast<const u32x4*>(wbuf + slot * G::PH_F4 + G::BIAS_F4);
       if (active) {
         f32x4 k[2], vn[2], a1[2], a2[2], kn[2], vnn[2];
 #pragma unroll
@@ -1988,9 +2006,8 @@ extern "C" int scgg_edge_block_bf16_pack(const float* W_mul, const float* b_mul,
   return e == hipSuccess ? 0 : fail("edge_block_bf16_pack: %s", hipGetErrorString(e));
 }
 
-template <int NXB, int NEB>
+template <int NXB, int NEB, int NW = 12>
 static int launch_edge_block_bf16(const EdgeBlockArgs& a, hipStream_t st) {
-  constexpr int NW = 12;
   const int n_cu = device_cu_count();
   if (n_cu <= 0) return fail("edge_block_bf16: device query failed");
   static LdsAttrOnce attr;

@@ -487,6 +487,25 @@ __global__ __launch_bounds__(256) void train_edge_pack_kernel(const float* W, in
   reinterpret_cast<f32x4*>(out)[idx] = v;
 }
 
+// every weight image of a layer (five matrices, plain and transposed) in ONE launch: grid (blocks of the largest, count)
+struct PackList { const float* W[10]; float* out[10]; int rows[10], cols[10], transpose[10]; int count; };
+__global__ __launch_bounds__(256) void train_edge_pack_multi_kernel(PackList l) {
+  const int t = blockIdx.y;
+  const float* W = l.W[t];
+  const int rows = l.rows[t], cols = l.cols[t], transpose = l.transpose[t];
+  const int R = transpose ? cols : rows, Cc = transpose ? rows : cols;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;          // float4 index
+  if (idx >= (long long)R * Cc / 4) return;
+  const int ln = (int)(idx & 63);
+  const long long blk = idx >> 6;
+  const int CB = Cc / 16, rb = (int)(blk / CB), cb = (int)(blk - (long long)rb * CB);
+  const int r = 16 * rb + (ln & 15), c0 = 16 * cb + 4 * (ln >> 4);
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = transpose ? W[(size_t)(c0 + e) * cols + r] : W[(size_t)r * cols + c0 + e];
+  reinterpret_cast<f32x4*>(l.out[t])[idx] = v;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Etoy's pooled statistics of the layer input (layers.py:34-41) for the y update: per graph and channel, over the pairs of
 // valid nodes (zero diagonal included): count, mean, M2 = sum (v - mean)^2, min, max and the flat pair index (i n + j) of
@@ -563,6 +582,37 @@ __global__ __launch_bounds__(256) void train_edge_stats_kernel(const float* __re
   }
 }
 
+// The slices of train_edge_stats_kernel merged per (graph, channel), slices in index order (pairwise update of mean / M2;
+// ties of an extremum go to the smaller pair index, the rule inside a slice): stats [B, 4 de] = mean | min | max | var,
+// what Etoy hands to the y update, and what the backward needs: mean, count, arg-extrema [B, de] each.
+__global__ __launch_bounds__(256) void train_edge_stats_finish_kernel(const float* __restrict__ so, const int* __restrict__ si, int B,
+                                                                      int slices, int DE, float* __restrict__ stats,
+                                                                      float* __restrict__ mean_o, float* __restrict__ tot_o,
+                                                                      int* __restrict__ imn_o, int* __restrict__ imx_o) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * DE) return;
+  const int b = idx / DE, c = idx - b * DE;
+  float ca = 0.f, mean = 0.f, M2 = 0.f, mn = INFINITY, mx = -INFINITY;
+  int imn = 0, imx = 0;
+  for (int s = 0; s < slices; ++s) {
+    const float* o = so + ((size_t)b * slices + s) * 5 * DE + c;
+    const int* oi = si + ((size_t)b * slices + s) * 2 * DE + c;
+    const float cb = o[0];
+    if (cb == 0.f) continue;
+    const float mb = o[DE], Mb = o[2 * DE], nb = o[3 * DE], xb = o[4 * DE];
+    const float tot = ca + cb, d = mb - mean;
+    M2 = ca == 0.f ? Mb : M2 + Mb + d * d * (ca * cb / tot);
+    mean = ca == 0.f ? mb : mean + d * (cb / tot);
+    if (nb < mn || (nb == mn && oi[0] < imn)) { mn = nb; imn = oi[0]; }
+    if (xb > mx || (xb == mx && oi[DE] < imx)) { mx = xb; imx = oi[DE]; }
+    ca = tot;
+  }
+  const float tot = ca < 1.f ? 1.f : ca;
+  float* st = stats + (size_t)b * 4 * DE + c;
+  st[0] = mean; st[DE] = mn; st[2 * DE] = mx; st[3 * DE] = M2 / tot;
+  mean_o[idx] = mean; tot_o[idx] = tot; imn_o[idx] = imn; imx_o[idx] = imx;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Sum over the middle index: out[split][a][c] = sum over the rows r of slice `split` of src[a][r][c]  (src [A,R,C] fp32,
 // C % 4 == 0).  The backward's per-key gradients (dK | dV summed over the query rows) and per-graph sums of a factor tensor
@@ -571,7 +621,7 @@ __global__ __launch_bounds__(256) void train_edge_stats_kernel(const float* __re
 // in flight per thread, the row lanes merged through LDS in a fixed order (deterministic).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void train_sum_rows_kernel(const float* __restrict__ src, long long R, int C4, int CQ, int rows_per_split,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, long long ld_split) {
   __shared__ f32x4 sh[256];
   const int tid = threadIdx.x, cq = tid % CQ, rl = tid / CQ, RL = 256 / CQ;
   const int c4 = blockIdx.x * CQ + cq;
@@ -594,7 +644,7 @@ __global__ __launch_bounds__(256) void train_sum_rows_kernel(const float* __rest
   __syncthreads();
   if (rl == 0 && c4 < C4) {
     for (int t = 1; t < RL; ++t) acc += sh[t * CQ + cq];
-    *reinterpret_cast<f32x4*>(out + (((long long)blockIdx.y * gridDim.z + a) * C4 + c4) * 4ll) = acc;
+    *reinterpret_cast<f32x4*>(out + (long long)blockIdx.y * ld_split + (a * C4 + c4) * 4ll) = acc;
   }
 }
 
@@ -602,15 +652,17 @@ __global__ __launch_bounds__(256) void train_sum_rows_kernel(const float* __rest
 // Weight gradient: C[M,N] = G^T X and c[M] = column sums of G, G [S,M] and X [S,N] row-major factors written by the
 // backward kernel, S = pair slots (the reduction index, ~2.6e5 at B = 4, n = 256).  Bound: HBM (reads (M + N) 4 bytes per
 // slot).  Grid (slabs, 64x64 output tiles); the 4 waves of a workgroup take the slots of their slab four at a time,
-// interleaved, and each wave writes its OWN partial tile (partial index 4 slab + wave): the host adds the partials in a
-// fixed order (deterministic, no atomics, no LDS).
+// interleaved, their tiles are added through LDS in the fixed order (w0 + w2) + (w1 + w3), and the workgroup writes ONE
+// partial (row `slab index` of a [slabs, ld] buffer: the caller adds the rows in a fixed order -- deterministic, no atomics;
+// one partial per wave, as first built, made the partials a larger stream than the factors themselves).
 // Operand trick: lane (m = l & 15, k = l >> 4) loads ONE float4 = G[s0 + k][64 mt + 4m .. 4m+3] (a slot's 64 channels are 256
 // contiguous bytes over the 16 lanes) and register j of that float4 is the A operand of MFMA j: its row m then stands for
 // channel 4m + j.  X likewise as B.  The 16 MFMAs (j, j') of a step cover the 64 x 64 tile over 4 slots from two 1-KiB loads.
 // The bias sums ride along as a B operand of ones (column 0), for tile column 0 only.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void train_wgrad_kernel(const float* __restrict__ G, int M, const float* __restrict__ X, int N,
-                                                          long long S, int slab, float* __restrict__ partial) {
+                                                          long long S, int slab, float* __restrict__ partial, long long ld) {
+  __shared__ f32x4 red[2][20][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, k = lane >> 4;
   const int ntn = (N + 63) / 64;
   const int mt = blockIdx.y / ntn, nt = blockIdx.y - mt * ntn;
@@ -642,8 +694,32 @@ __global__ __launch_bounds__(256) void train_wgrad_kernel(const float* __restric
       if (bias) accb[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[j], ok ? one : 0.f, accb[j], 0, 0, 0);
     }
   }
+  // the four waves' tiles -> wave 0, through LDS, in two rounds: (w0 += w2, w1 += w3), then w0 += w1
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    const int first_writer = round == 0 ? 2 : 1, writers = round == 0 ? 2 : 1;
+    if (wave >= first_writer && wave < first_writer + writers) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave - first_writer][4 * j + i][lane] = acc[j][i];
+        red[wave - first_writer][16 + j][lane] = accb[j];
+      }
+    }
+    __syncthreads();
+    if (wave < writers) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] += red[wave][4 * j + i][lane];
+        accb[j] += red[wave][16 + j][lane];
+      }
+    }
+    __syncthreads();
+  }
+  if (wave != 0) return;
   // acc[j][i][e]: row (4 k + e) of MFMA (j, i) = G channel 64 mt + 4 (4k + e) + j; column m = X channel 64 nt + 4 m + i
-  float* out = partial + ((size_t)blockIdx.x * 4 + wave) * ((size_t)M * N + M);
+  float* out = partial + (size_t)blockIdx.x * (size_t)ld;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -692,6 +768,25 @@ extern "C" int scgg_train_edge_pack(const float* W, int32_t rows, int32_t cols, 
   return e == hipSuccess ? 0 : fail("train_edge_pack: %s", hipGetErrorString(e));
 }
 
+extern "C" int scgg_train_edge_pack_multi(const scgg_train_pack_list* l, void* stream) {
+  if (!l || l->count <= 0 || l->count > 10) return fail("train_edge_pack_multi: 1 .. 10 matrices");
+  PackList k;
+  long long most = 0;
+  for (int t = 0; t < l->count; ++t) {
+    if (!l->W[t] || !l->out[t] || l->rows[t] <= 0 || l->cols[t] <= 0 || l->rows[t] % 16 != 0 || l->cols[t] % 16 != 0)
+      return fail("train_edge_pack_multi: bad matrix %d", t);
+    k.W[t] = l->W[t]; k.out[t] = l->out[t]; k.rows[t] = l->rows[t]; k.cols[t] = l->cols[t]; k.transpose[t] = l->transpose[t];
+    const long long f4 = (long long)l->rows[t] * l->cols[t] / 4;
+    most = f4 > most ? f4 : most;
+  }
+  for (int t = l->count; t < 10; ++t) { k.W[t] = nullptr; k.out[t] = nullptr; k.rows[t] = k.cols[t] = k.transpose[t] = 0; }
+  k.count = l->count;
+  hipLaunchKernelGGL(train_edge_pack_multi_kernel, dim3((unsigned)((most + 255) / 256), (unsigned)l->count), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), k);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail("train_edge_pack_multi: %s", hipGetErrorString(e));
+}
+
 extern "C" int scgg_train_edge_forward(const scgg_train_edge_args* a, void* stream) {
   if (check_args(a, false)) return -1;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -716,17 +811,19 @@ extern "C" int scgg_train_edge_backward(const scgg_train_edge_args* a, void* str
   return e == hipSuccess ? 0 : fail("train_edge_backward: %s", hipGetErrorString(e));
 }
 
-extern "C" int64_t scgg_train_wgrad_slabs(int64_t S, int32_t slab) { return (S <= 0 || slab <= 0) ? 0 : 4 * ((S + slab - 1) / slab); }
+extern "C" int64_t scgg_train_wgrad_slabs(int64_t S, int32_t slab) { return (S <= 0 || slab <= 0) ? 0 : (S + slab - 1) / slab; }
 
 extern "C" int scgg_train_wgrad(const float* G, int32_t M, const float* X, int32_t N, int64_t S, int32_t slab, float* partial,
-                                void* stream) {
+                                int64_t ld_partial, void* stream) {
   if (!G || !X || !partial || S <= 0) return fail("train_wgrad: bad arguments");
+  if (ld_partial == 0) ld_partial = (int64_t)M * N + M;
+  if (ld_partial < (int64_t)M * N + M || ld_partial % 4 != 0) return fail("train_wgrad: ld_partial must be a multiple of 4, at least M N + M");
   if (M < 16 || M % 16 != 0 || N < 16 || N % 16 != 0 || slab < 16 || slab % 16 != 0) return fail("train_wgrad: M, N, slab must be multiples of 16");
   const long long nsl = (S + slab - 1) / slab;
   const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
   if (nsl > 0x7fffffffLL || tiles > 65535) return fail("train_wgrad: too many slabs / tiles");
   hipLaunchKernelGGL(train_wgrad_kernel, dim3((unsigned)nsl, (unsigned)tiles), dim3(256), 0, static_cast<hipStream_t>(stream), G, (int)M, X,
-                     (int)N, (long long)S, (int)slab, partial);
+                     (int)N, (long long)S, (int)slab, partial, (long long)ld_partial);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail("train_wgrad: %s", hipGetErrorString(e));
 }
@@ -740,17 +837,30 @@ extern "C" int scgg_train_edge_stats(const float* E, const uint8_t* mask, int32_
   return e == hipSuccess ? 0 : fail("train_edge_stats: %s", hipGetErrorString(e));
 }
 
+extern "C" int scgg_train_edge_stats_finish(const float* out, const int32_t* idx, int32_t B, int32_t slices, int32_t de, float* stats,
+                                            float* mean, float* count, int32_t* imn, int32_t* imx, void* stream) {
+  if (!out || !idx || !stats || !mean || !count || !imn || !imx || B <= 0 || slices <= 0 || de <= 0)
+    return fail("train_edge_stats_finish: bad arguments");
+  hipLaunchKernelGGL(train_edge_stats_finish_kernel, dim3((unsigned)((B * de + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), out, idx, B, slices, de, stats, mean, count, imn, imx);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail("train_edge_stats_finish: %s", hipGetErrorString(e));
+}
+
 extern "C" int64_t scgg_train_sum_rows_splits(int64_t A, int64_t R, int32_t C) {
   if (A <= 0 || R <= 0 || C <= 0) return 0;
   const long long tiles = ((C / 4) + 63) / 64 * A;
-  long long want = 2048 / (tiles > 0 ? tiles : 1);                       // ~8 workgroups per CU over the whole grid
+  long long want = tiles >= 512 ? 1 : 2048 / (tiles > 0 ? tiles : 1);   // ~8 workgroups per CU over the grid; 2+ per CU: no split
   if (want < 1) want = 1;
   const long long by_rows = (R + 63) / 64;                              // at least 64 rows per slice
   return want < by_rows ? want : by_rows;
 }
 
-extern "C" int scgg_train_sum_rows(const float* src, int64_t A, int64_t R, int32_t C, int32_t splits, float* out, void* stream) {
+extern "C" int scgg_train_sum_rows(const float* src, int64_t A, int64_t R, int32_t C, int32_t splits, float* out, int64_t ld_split,
+                                   void* stream) {
   if (!src || !out || A <= 0 || R <= 0 || C <= 0 || splits <= 0) return fail("train_sum_rows: bad arguments");
+  if (ld_split == 0) ld_split = A * C;
+  if (ld_split < A * C || ld_split % 4 != 0) return fail("train_sum_rows: ld_split must be a multiple of 4, at least A C");
   if (C % 4 != 0) return fail("train_sum_rows: C must be a multiple of 4");
   if (A > 65535 || splits > 65535) return fail("train_sum_rows: grid too large");
   const int C4 = C / 4;
@@ -758,7 +868,7 @@ extern "C" int scgg_train_sum_rows(const float* src, int64_t A, int64_t R, int32
   while (CQ > 1 && CQ / 2 >= C4) CQ /= 2;                                // power of two >= min(C4, 64): the row lanes take the rest
   const int rows_per_split = (int)((R + splits - 1) / splits);
   hipLaunchKernelGGL(train_sum_rows_kernel, dim3((unsigned)((C4 + CQ - 1) / CQ), (unsigned)splits, (unsigned)A), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), src, (long long)R, C4, CQ, rows_per_split, out);
+                     static_cast<hipStream_t>(stream), src, (long long)R, C4, CQ, rows_per_split, out, (long long)ld_split);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail("train_sum_rows: %s", hipGetErrorString(e));
 }

@@ -88,13 +88,24 @@ class NoiseModel:
         self.X_classes = self.E_classes = self.charges_classes = self.y_classes = None
         self.X_marginals = self.E_marginals = self.charges_marginals = self.y_marginals = None
         self._dev_tables = {}
+        self._dev_cache = {}
+
+    def _on(self, t, device):
+        """A host table on ``device``, copied once per (table, device).  A copy from pageable host memory makes the host wait
+        for everything queued on the stream: six of them per apply_noise kept the training loop from ever running ahead of
+        the device."""
+        k = (id(t), str(device))
+        hit = self._dev_cache.get(k)
+        if hit is None or hit[0] is not t:
+            hit = self._dev_cache[k] = (t, t.to(device))
+        return hit[1]
 
     # ---- tables ------------------------------------------------------------------------------------------
     def _get(self, series, t_normalized=None, t_int=None, key=None):
         assert (t_normalized is None) != (t_int is None)
         if t_int is None:
             t_int = torch.round(t_normalized * self.T)
-        att = series.to(t_int.device)[t_int.long()]
+        att = self._on(series, t_int.device)[t_int.long()]
         return att.float() if key is None else att[..., self.inverse_mapping[key]].float()
 
     def get_beta(self, t_normalized=None, t_int=None, key=None):
@@ -117,7 +128,7 @@ class NoiseModel:
 
     def _P(self, marg, device):
         c = marg.numel()
-        return marg.float().to(device)[None, None, :].expand(1, c, c)
+        return self._on(marg, device).float()[None, None, :].expand(1, c, c)
 
     def get_Qt(self, t_int):
         """one-step transition matrices (reference :101-125): beta_t * 1 m^T + (1 - beta_t) * I."""
@@ -204,7 +215,7 @@ class NoiseModel:
             labels = torch.where(live, 0, -1).to(torch.int8).contiguous()
             cands = torch.zeros(B, n, n, top_k, dtype=torch.int8, device=dev) if top_k > 1 else None
         else:
-            prob = self.E_marginals.float().to(dev).expand(B, n, n, -1).contiguous()
+            prob = self._on(self.E_marginals, dev).float().expand(B, n, n, -1).contiguous()
             zr = self._fresh_rng() if rng is None else rng
             zr = Rng(seed=zr.seed, step=self.T + 1, graph_id_base=zr.graph_id_base)
             labels, cands = self.sample_edges_from_probs(prob, node_mask, top_k if top_k > 1 else 0, zr)

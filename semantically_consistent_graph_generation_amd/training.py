@@ -189,15 +189,52 @@ def _pack(W, transpose):
     return out
 
 
-def _sum_rows(t):
-    """t [A,R,C] contiguous fp32 -> [A,C], the sum over R (``scgg_train_sum_rows``: the large reductions of the backward's factor
-    tensors; a fixed order of summation, so repeated steps agree bit for bit)."""
+def _pack_layer(Ws):
+    """Fragment images of a layer's five weights, plain and transposed, in one launch: (five forward images, five backward)."""
+    L = _lib.lib()
+    sizes = [W.numel() for W in Ws]
+    flat = torch.empty(2 * sum(sizes), device=Ws[0].device)
+    pl = _lib.TrainPackList()
+    views, off = [], 0
+    for t in range(10):
+        W = Ws[t % 5]
+        v = flat[off:off + W.numel()]
+        off += W.numel()
+        pl.W[t], pl.out[t], pl.rows[t], pl.cols[t], pl.transpose[t] = W.data_ptr(), v.data_ptr(), W.shape[0], W.shape[1], int(t >= 5)
+        views.append(v)
+    pl.count = 10
+    _lib.check(L.scgg_train_edge_pack_multi(C.byref(pl), _lib.stream_ptr()), "train_edge_pack_multi")
+    return views[:5], views[5:]
+
+
+def _sum_rows(t, out=None, splits=None):
+    """t [A,R,C] contiguous fp32 -> the sum over R (``scgg_train_sum_rows``: the large reductions of the backward's factor
+    tensors; a fixed order of summation, so repeated steps agree bit for bit).  Without ``out``: returns [A,C].  With
+    ``out`` [splits, B', C] (B' >= A, a slice [:, b0:b0+A] of a larger buffer is fine): fills it and leaves the sum over the
+    leading index to the caller (one per layer instead of one per call)."""
     A, R, Cc = t.shape
     L = _lib.lib()
-    sp = int(L.scgg_train_sum_rows_splits(A, R, Cc))
-    out = torch.empty(sp, A, Cc, device=t.device)
-    _lib.check(L.scgg_train_sum_rows(_lib.ptr(t), A, R, Cc, sp, _lib.ptr(out), _lib.stream_ptr()), "train_sum_rows")
-    return out.sum(0) if sp > 1 else out[0]
+    sp = int(L.scgg_train_sum_rows_splits(A, R, Cc)) if splits is None else int(splits)
+    if out is None:
+        o = torch.empty(sp, A, Cc, device=t.device)
+        _lib.check(L.scgg_train_sum_rows(_lib.ptr(t), A, R, Cc, sp, _lib.ptr(o), 0, _lib.stream_ptr()), "train_sum_rows")
+        return o.sum(0) if sp > 1 else o[0]
+    assert out.shape[0] == sp and out.shape[1] == A and out.shape[2] == Cc and out.stride(2) == 1 and out.stride(1) == Cc
+    _lib.check(L.scgg_train_sum_rows(_lib.ptr(t), A, R, Cc, sp, out.data_ptr(), out.stride(0) if sp > 1 else 0, _lib.stream_ptr()),
+               "train_sum_rows")
+    return out
+
+
+WGRAD_SLAB = 256
+
+
+def _wgrad_into(G, X, partial, row0, col0, slab=WGRAD_SLAB):
+    """Partials of (G^T X | G.sum(0)) into rows [row0, row0 + slabs) of ``partial`` [rows, ld] at column col0."""
+    S, M = G.shape
+    N = X.shape[1]
+    ld = partial.shape[1]
+    _lib.check(_lib.lib().scgg_train_wgrad(_lib.ptr(G), M, _lib.ptr(X), N, S, slab, partial.data_ptr() + 4 * (row0 * ld + col0), ld,
+                                           _lib.stream_ptr()), "train_wgrad")
 
 
 def _wgrad(G, X, slab=None):
@@ -210,10 +247,11 @@ def _wgrad(G, X, slab=None):
         tiles = ((M + 63) // 64) * ((N + 63) // 64)
         slab = max(256, min(4096, (S * tiles // 1024) // 16 * 16))
     nsl = int(L.scgg_train_wgrad_slabs(S, slab))
-    partial = torch.empty(nsl, M * N + M, device=G.device)
-    _lib.check(L.scgg_train_wgrad(_lib.ptr(G), M, _lib.ptr(X), N, S, slab, _lib.ptr(partial), _lib.stream_ptr()), "train_wgrad")
-    tot = partial.sum(0)
-    return tot[: M * N].view(M, N), tot[M * N:]
+    ld = (M * N + M + 3) // 4 * 4
+    partial = torch.empty(nsl, ld, device=G.device)
+    _wgrad_into(G, X, partial, 0, 0, slab)
+    tot = _sum_rows(partial.view(1, nsl, ld))[0] if nsl >= 64 else partial.sum(0)
+    return tot[: M * N].view(M, N), tot[M * N: M * N + M]
 
 
 class _PairLinear(torch.autograd.Function):
@@ -260,8 +298,8 @@ class _FusedEdgeLayer(torch.autograd.Function):
         nch = (n + 15) // 16
         E, Q, K, V, yea, yem1 = (t.detach().float().contiguous() for t in (E, Q, K, V, yea, yem1))
         vecs = [t.detach().float().contiguous() for t in (b_mul, b_add, b_out, g1, b1, b_ff1, b_ff2, g2, b2)]
-        Ws = (W_mul, W_add, W_out, W_ff1, W_ff2)
-        F_fwd = [_pack(W, False) for W in Ws]
+        Ws = [W.detach().float().contiguous() for W in (W_mul, W_add, W_out, W_ff1, W_ff2)]
+        F_fwd, F_bwd = _pack_layer(Ws)                 # the backward's transposed images too: one launch, ~0.3 MB kept
         a = _lib.TrainEdgeArgs()
         keep = [E, Q, K, V, yea, yem1, mask_u8] + vecs + F_fwd
         for k, t in zip(("E", "Q", "K", "V", "yea", "yem1", "mask"), (E, Q, K, V, yea, yem1, mask_u8)):
@@ -283,26 +321,25 @@ class _FusedEdgeLayer(torch.autograd.Function):
         _lib.check(_lib.lib().scgg_train_edge_forward(C.byref(a), _lib.stream_ptr()), "train_edge_forward")
         del keep
         # Etoy's pooled statistics of the layer INPUT (they feed the y update): one more read of E, merged over the slices
-        stats = torch.zeros(B, 4 * de, device=E.device)
-        st_keep = [torch.zeros(0, device=E.device)] * 2 + [torch.zeros(0, dtype=torch.int32, device=E.device)] * 2
-        if with_stats:
+        stats = None
+        st_keep = [torch.empty(0, device=E.device)] * 2 + [torch.empty(0, dtype=torch.int32, device=E.device)] * 2
+        if not with_stats:
+            stats = torch.zeros(B, 4 * de, device=E.device)
+        else:
             slices = max(1, min(n, 256 // max(B, 1)))
             so = torch.empty(B, slices, 5, de, device=E.device)
             si = torch.empty(B, slices, 2, de, dtype=torch.int32, device=E.device)
             _lib.check(_lib.lib().scgg_train_edge_stats(_lib.ptr(E), _lib.ptr(mask_u8), B, n, de, slices, _lib.ptr(so), _lib.ptr(si),
                                                         _lib.stream_ptr()), "train_edge_stats")
-            cnt, mean_s, M2_s = so[:, :, 0], so[:, :, 1], so[:, :, 2]
-            tot = cnt.sum(1).clamp(min=1.0)
-            mean = (cnt * mean_s).sum(1) / tot
-            M2 = M2_s.sum(1) + (cnt * (mean_s - mean[:, None]) ** 2).sum(1)
-            mn, amn = so[:, :, 3].min(1)
-            mx, amx = so[:, :, 4].max(1)
-            imn = si[:, :, 0].gather(1, amn[:, None]).squeeze(1).contiguous()
-            imx = si[:, :, 1].gather(1, amx[:, None]).squeeze(1).contiguous()
-            stats = torch.cat([mean, mn, mx, M2 / tot], dim=1)
-            st_keep = [mean.contiguous(), tot.contiguous(), imn, imx]
+            stats = torch.empty(B, 4 * de, device=E.device)
+            mt = torch.empty(2, B, de, device=E.device)
+            ix = torch.empty(2, B, de, dtype=torch.int32, device=E.device)
+            _lib.check(_lib.lib().scgg_train_edge_stats_finish(_lib.ptr(so), _lib.ptr(si), B, slices, de, _lib.ptr(stats), _lib.ptr(mt[0]),
+                                                               _lib.ptr(mt[1]), _lib.ptr(ix[0]), _lib.ptr(ix[1]), _lib.stream_ptr()),
+                       "train_edge_stats_finish")
+            st_keep = [mt[0], mt[1], ix[0], ix[1]]
         ctx.with_stats = bool(with_stats)
-        ctx.save_for_backward(E, Q, K, V, yea, yem1, mask_u8, wV, lse, *vecs, *[W.detach() for W in Ws], *st_keep)
+        ctx.save_for_backward(E, Q, K, V, yea, yem1, mask_u8, wV, lse, *vecs, *Ws, *st_keep, *F_fwd, *F_bwd)
         ctx.cfg = (float(inv_sqrt_df), a.p, sd, tuple(int(v) for v in sites))
         ctx.mark_non_differentiable(lse)
         return E_out, wV, lse, stats
@@ -313,19 +350,15 @@ class _FusedEdgeLayer(torch.autograd.Function):
         vecs = list(ctx.saved_tensors[9:18])
         Ws = list(ctx.saved_tensors[18:23])
         st_mean, st_tot, st_imn, st_imx = ctx.saved_tensors[23:27]
+        F_fwd, F_bwd = ctx.saved_tensors[27:32], ctx.saved_tensors[32:37]
         inv_sqrt_df, p, sd, sites = ctx.cfg
         B, n, _, de = E.shape
         dx, ffe = Q.shape[-1], Ws[3].shape[0]
         nch = (n + 15) // 16
         dev = E.device
-        S = B * n * nch * 16
         dOut = torch.zeros_like(E) if dOut is None else dOut.float().contiguous()
         dwV = torch.zeros_like(wV) if dwV is None else dwV.float().contiguous()
-        F_fwd = [_pack(W, False) for W in Ws]
-        F_bwd = [_pack(W, True) for W in Ws]
         a = _lib.TrainEdgeArgs()
-        for k, t in zip(("E", "Q", "K", "V", "yea", "yem1", "mask"), (E, Q, K, V, yea, yem1, mask_u8)):
-            setattr(a, k, t.data_ptr())
         for k, t in zip(("F_mul", "F_add", "F_out", "F_ff1", "F_ff2"), F_fwd):
             setattr(a, k, t.data_ptr())
         for k, t in zip(("F_mulT", "F_addT", "F_outT", "F_ff1T", "F_ff2T"), F_bwd):
@@ -338,13 +371,16 @@ class _FusedEdgeLayer(torch.autograd.Function):
             gm, gmi, gma, gv = (t.contiguous() for t in dstats.float().split(de, dim=1))
             st = [st_mean, (gm / st_tot).contiguous(), (2.0 * gv / st_tot).contiguous(), gmi, gma]
         # The factor tensors are the backward's transient memory (4.3 KB per pair slot): the batch is walked in chunks of
-        # graphs so that they stay below ~0.6 GB; gradients of shared parameters add up over the chunks.
+        # graphs so that they stay below ~0.6 GB.  What the chunks leave behind is summed ONCE per layer: the partials of the
+        # four weight-gradient products of every chunk share one buffer (rows = chunk x slab, columns = product), and so do
+        # the per-graph sums; with per-chunk sums and adds the tail of a chunk was ~35 small launches.
         per_graph = n * nch * 16 * (4 * de + 2 * ffe + 5 * dx) * 4
         Bc = max(1, min(B, int(0.6 * 2 ** 30) // max(per_graph, 1)))
         Sc = Bc * n * nch * 16
         G = {k: torch.empty(Sc, w, device=dev) for k, w in (("G_e", de), ("G_da", 2 * dx), ("G_z", dx), ("G_dnewE", de), ("G_h1", de),
                                                            ("G_df", ffe), ("G_f", ffe), ("G_do", de), ("G_dkv", 2 * dx))}
-        upart = torch.empty(Bc * n * nch, 2 * dx + 4 * de, device=dev)
+        UW = 2 * dx + 4 * de
+        upart = torch.empty(Bc * n * nch, UW, device=dev)
         for k, t in G.items():
             setattr(a, k, t.data_ptr())
         a.upart = upart.data_ptr()
@@ -352,10 +388,21 @@ class _FusedEdgeLayer(torch.autograd.Function):
         a.inv_sqrt_df, a.p = inv_sqrt_df, p
         a.k0, a.k1 = sd & 0xFFFFFFFF, (sd >> 32) & 0xFFFFFFFF
         a.site1, a.site2, a.site3 = sites
-        acc = None
-        dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
-        dyea, dyem1 = torch.empty_like(yea), torch.empty_like(yem1)
-        for b0 in range(0, B, Bc):
+        L = _lib.lib()
+        prods = (("G_da", "G_e"), ("G_dnewE", "G_z"), ("G_df", "G_h1"), ("G_do", "G_f"))     # [2dx,de] = d e_mul | d e_add weights, ...
+        widths = [G[g].shape[1] * G[x].shape[1] + G[g].shape[1] for g, x in prods]
+        cols = [sum(widths[:i]) for i in range(5)]
+        chunks = list(range(0, B, Bc))
+        nsl = int(L.scgg_train_wgrad_slabs(Sc, WGRAD_SLAB))
+        P = torch.zeros(len(chunks) * nsl, cols[4], device=dev) if B % Bc else torch.empty(len(chunks) * nsl, cols[4], device=dev)
+        sp_u = int(L.scgg_train_sum_rows_splits(Bc, n, UW))
+        sp_e = int(L.scgg_train_sum_rows_splits(Bc, n * nch * 16, de))
+        U2 = torch.empty(sp_u, B, UW, device=dev)                   # per graph: . | d yem1 | LayerNorm parameter gradients
+        Sd = torch.empty(sp_e, B, de, device=dev)                   # per graph: sum of dnewE over the pairs
+        dQ = torch.empty_like(Q)
+        direct_kv = nch * 16 == n and int(L.scgg_train_sum_rows_splits(Bc, n, n * 2 * dx)) == 1
+        dKV = torch.empty(B, n, 2 * dx, device=dev)
+        for ci, b0 in enumerate(chunks):
             nb = min(Bc, B - b0)
             for k, t in (("E", E), ("Q", Q), ("K", K), ("V", V), ("yea", yea), ("yem1", yem1), ("mask", mask_u8), ("dOut", dOut),
                          ("dwV", dwV), ("wV", wV), ("lse", lse), ("dE", dE)):
@@ -364,22 +411,30 @@ class _FusedEdgeLayer(torch.autograd.Function):
                 a.st_mean, a.st_cm, a.st_cv, a.st_gmi, a.st_gma = (t[b0:].data_ptr() for t in st)
                 a.st_imn, a.st_imx = st_imn[b0:].data_ptr(), st_imx[b0:].data_ptr()
             a.B, a.b0 = nb, b0
-            _lib.check(_lib.lib().scgg_train_edge_backward(C.byref(a), _lib.stream_ptr()), "train_edge_backward")
+            _lib.check(L.scgg_train_edge_backward(C.byref(a), _lib.stream_ptr()), "train_edge_backward")
             Sn = nb * n * nch * 16
-            Gn = {k: t[:Sn] for k, t in G.items()}
-            parts = [_wgrad(Gn["G_da"], Gn["G_e"]),              # [2dx, de] = d e_mul.weight | d e_add.weight
-                     _wgrad(Gn["G_dnewE"], Gn["G_z"]), _wgrad(Gn["G_df"], Gn["G_h1"]), _wgrad(Gn["G_do"], Gn["G_f"])]
-            up = upart[: nb * n * nch].view(nb, n, nch, -1)
-            parts.append((up[..., 2 * dx:].sum((0, 1, 2)),))
-            acc = parts if acc is None else [tuple(x + y for x, y in zip(pa, pb)) for pa, pb in zip(acc, parts)]
-            dQ[b0:b0 + nb] = up[..., :dx].sum(2) * inv_sqrt_df
-            dyem1[b0:b0 + nb] = up[..., dx:2 * dx].sum((1, 2))
-            dkv = _sum_rows(Gn["G_dkv"].view(nb, n, nch * 16 * 2 * dx)).view(nb, nch * 16, 2 * dx)[:, :n]   # over the query rows
-            dK[b0:b0 + nb], dV[b0:b0 + nb] = dkv[..., :dx], dkv[..., dx:]
-            dyea[b0:b0 + nb] = _sum_rows(Gn["G_dnewE"].view(nb, n * nch * 16, de)) @ Ws[2]    # sum of dz = W_out^T sum of dnewE, per graph
-        (dW_ma, db_ma), (dW_out, db_out), (dW_ff1, db_ff1), (dW_ff2, db_ff2), (ln,) = acc
+            for (g, x), c0 in zip(prods, cols):
+                _wgrad_into(G[g][:Sn], G[x][:Sn], P, ci * nsl, c0)
+            U1 = _sum_rows(upart[: nb * n * nch].view(nb * n, nch, UW), splits=1).view(nb, n, UW)     # over the key chunks
+            torch.mul(U1[..., :dx], inv_sqrt_df, out=dQ[b0:b0 + nb])
+            _sum_rows(U1, out=U2[:, b0:b0 + nb], splits=sp_u)                                          # over the query rows
+            kv = G["G_dkv"][:Sn].view(nb, n, nch * 16 * 2 * dx)                                        # dK | dV: over the query rows
+            if direct_kv:
+                _sum_rows(kv, out=dKV[b0:b0 + nb].view(1, nb, n * 2 * dx), splits=1)
+            else:
+                dKV[b0:b0 + nb] = _sum_rows(kv).view(nb, nch * 16, 2 * dx)[:, :n]
+            _sum_rows(G["G_dnewE"][:Sn].view(nb, n * nch * 16, de), out=Sd[:, b0:b0 + nb], splits=sp_e)
+        rows = P.shape[0]
+        tot = _sum_rows(P.view(1, rows, cols[4]))[0] if rows >= 64 else P.sum(0)
+        dWs = [(tot[c0:c0 + G[g].shape[1] * G[x].shape[1]].view(G[g].shape[1], G[x].shape[1]), tot[c0 + w - G[g].shape[1]:c0 + w])
+               for (g, x), c0, w in zip(prods, cols, widths)]
+        (dW_ma, db_ma), (dW_out, db_out), (dW_ff1, db_ff1), (dW_ff2, db_ff2) = dWs
+        U = U2.sum(0) if sp_u > 1 else U2[0]
+        dyem1 = U[:, dx:2 * dx]
+        ln = U[:, 2 * dx:].sum(0)
+        dyea = (Sd.sum(0) if sp_e > 1 else Sd[0]) @ Ws[2]           # sum of dz = W_out^T sum of dnewE, per graph
         dg2, db2, dg1, db1 = ln[:de], ln[de:2 * de], ln[2 * de:3 * de], ln[3 * de:]
-        return (dE, dQ, dK, dV, dyea, dyem1, None, None, None, None, None, None,
+        return (dE, dQ, dKV[..., :dx], dKV[..., dx:], dyea, dyem1, None, None, None, None, None, None,
                 dW_ma[:dx], db_ma[:dx], dW_ma[dx:], db_ma[dx:], dW_out, db_out, dg1, db1, dW_ff1, db_ff1, dW_ff2, db_ff2, dg2, db2)
 
 

@@ -436,3 +436,78 @@ def test_sum_rows_kernel_against_torch(A, R, Cc):
     want = t.double().sum(1)
     assert float((got.double() - want).abs().max()) / float(want.abs().max()) < 2e-6
     assert torch.equal(got, _sum_rows(t))
+
+
+def test_sum_rows_into_a_slice_of_a_larger_buffer():
+    from semantically_consistent_graph_generation_amd.training import _sum_rows
+    t = torch.randn(2, 300, 64, generator=torch.Generator().manual_seed(5)).cuda()
+    out = torch.full((3, 5, 64), float("nan"), device="cuda")
+    _sum_rows(t, out=out[:, 1:3], splits=3)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out[:, 0]).all()) and bool(torch.isnan(out[:, 3:]).all())
+    want = t.double().sum(1)
+    assert float((out[:, 1:3].double().sum(0) - want).abs().max()) / float(want.abs().max()) < 2e-6
+
+
+def test_wgrad_products_share_one_partial_buffer():
+    """Two products, two chunks of slots each, into one [rows, ld] buffer; one sum over the rows gives both gradients."""
+    from semantically_consistent_graph_generation_amd import _lib
+    from semantically_consistent_graph_generation_amd.training import _wgrad, _wgrad_into, _sum_rows
+    g = torch.Generator().manual_seed(3)
+    S, slab = 5000, 256
+    Ga, Xa = torch.randn(2 * S, 128, generator=g).cuda(), torch.randn(2 * S, 64, generator=g).cuda()
+    Gb, Xb = torch.randn(2 * S, 64, generator=g).cuda(), torch.randn(2 * S, 32, generator=g).cuda()
+    wa, wb = 128 * 64 + 128, 64 * 32 + 64
+    nsl = int(_lib.lib().scgg_train_wgrad_slabs(S, slab))
+    assert nsl == (S + slab - 1) // slab
+    P = torch.full((2 * nsl, wa + wb), float("nan"), device="cuda")
+    for c in range(2):
+        _wgrad_into(Ga[c * S:(c + 1) * S], Xa[c * S:(c + 1) * S], P, c * nsl, 0, slab)
+        _wgrad_into(Gb[c * S:(c + 1) * S], Xb[c * S:(c + 1) * S], P, c * nsl, wa, slab)
+    tot = _sum_rows(P.view(1, 2 * nsl, wa + wb))[0]
+    torch.cuda.synchronize()
+    for G_, X_, c0, M, N in ((Ga, Xa, 0, 128, 64), (Gb, Xb, wa, 64, 32)):
+        dW, db = tot[c0:c0 + M * N].view(M, N), tot[c0 + M * N:c0 + M * N + M]
+        want_W, want_b = G_.double().t() @ X_.double(), G_.double().sum(0)
+        assert float((dW.double() - want_W).abs().max()) / float(want_W.abs().max()) < 1e-5
+        assert float((db.double() - want_b).abs().max()) / float(want_b.abs().max()) < 1e-5
+        dW1, db1 = _wgrad(G_, X_)                                      # the one-product helper agrees
+        assert float((dW1 - dW).abs().max()) / float(want_W.abs().max()) < 1e-5
+        assert float((db1 - db).abs().max()) / float(want_b.abs().max()) < 1e-5
+
+
+def test_pack_layer_matches_single_packs():
+    from semantically_consistent_graph_generation_amd.training import _pack, _pack_layer
+    g = torch.Generator().manual_seed(2)
+    Ws = [torch.randn(r, c, generator=g).cuda() for r, c in ((128, 64), (128, 64), (64, 128), (128, 64), (64, 128))]
+    fwd, bwd = _pack_layer(Ws)
+    for W, f, b in zip(Ws, fwd, bwd):
+        assert torch.equal(f, _pack(W, False)) and torch.equal(b, _pack(W, True))
+
+
+def test_edge_stats_finish_matches_the_tensor_op_merge():
+    from semantically_consistent_graph_generation_amd import _lib
+    B, n, de, slices = 3, 40, 64, 8
+    g = torch.Generator().manual_seed(9)
+    E = torch.randn(B, n, n, de, generator=g).cuda()
+    mask = (torch.arange(n)[None] < torch.tensor([40, 33, 17])[:, None]).cuda()
+    m8 = mask.view(torch.uint8).contiguous()
+    L = _lib.lib()
+    so = torch.empty(B, slices, 5, de, device="cuda")
+    si = torch.empty(B, slices, 2, de, dtype=torch.int32, device="cuda")
+    _lib.check(L.scgg_train_edge_stats(_lib.ptr(E), _lib.ptr(m8), B, n, de, slices, _lib.ptr(so), _lib.ptr(si), _lib.stream_ptr()), "stats")
+    stats = torch.empty(B, 4 * de, device="cuda")
+    mean, cnt = torch.empty(B, de, device="cuda"), torch.empty(B, de, device="cuda")
+    imn, imx = torch.empty(B, de, dtype=torch.int32, device="cuda"), torch.empty(B, de, dtype=torch.int32, device="cuda")
+    _lib.check(L.scgg_train_edge_stats_finish(_lib.ptr(so), _lib.ptr(si), B, slices, de, _lib.ptr(stats), _lib.ptr(mean), _lib.ptr(cnt),
+                                              _lib.ptr(imn), _lib.ptr(imx), _lib.stream_ptr()), "finish")
+    torch.cuda.synchronize()
+    pm = (mask[:, :, None] & mask[:, None, :])
+    for b in range(B):
+        v = E[b][pm[b]].double()                                       # [pairs, de]
+        want = torch.cat([v.mean(0), v.min(0)[0], v.max(0)[0], v.var(0, unbiased=False)])
+        assert float((stats[b].double() - want).abs().max()) < 1e-5
+        assert float(cnt[b, 0]) == v.shape[0]
+        flat = E[b].reshape(n * n, de)
+        assert torch.equal(flat.gather(0, imn[b].long()[None])[0], stats[b, de:2 * de])
+        assert torch.equal(flat.gather(0, imx[b].long()[None])[0], stats[b, 2 * de:3 * de])
