@@ -650,74 +650,89 @@ __global__ __launch_bounds__(256) void train_sum_rows_kernel(const float* __rest
 
 // ---------------------------------------------------------------------------------------------------------
 // Weight gradient: C[M,N] = G^T X and c[M] = column sums of G, G [S,M] and X [S,N] row-major factors written by the
-// backward kernel, S = pair slots (the reduction index, ~2.6e5 at B = 4, n = 256).  Bound: HBM (reads (M + N) 4 bytes per
-// slot).  Grid (slabs, 64x64 output tiles); the 4 waves of a workgroup take the slots of their slab four at a time,
-// interleaved, their tiles are added through LDS in the fixed order (w0 + w2) + (w1 + w3), and the workgroup writes ONE
-// partial (row `slab index` of a [slabs, ld] buffer: the caller adds the rows in a fixed order -- deterministic, no atomics;
-// one partial per wave, as first built, made the partials a larger stream than the factors themselves).
+// backward kernel, S = pair slots (the reduction index, ~2.6e5 at B = 4, n = 256).  Bound: HBM and the fp32 matrix pipe
+// about equally ((M + N) 4 bytes and 2 M N flop per slot: 30-50 flop/B against a ridge of ~25).
+// Grid (slabs, groups of TPW <= 4 output tiles of 64x64); a workgroup owns a slab of slots for ALL tiles of its group, so the
+// operand shared by those tiles is fetched from HBM once (its other readers hit L1 / L2): wave w works on tile w / tw of the
+// group and, when tw = 4 / TPW > 1 waves share a tile, on every tw-th step of the slab; such waves add their tiles through
+// LDS in a fixed order.  One partial per workgroup and tile: row `slab index` of a [slabs, ld] buffer, added by the caller in
+// a fixed order (deterministic, no atomics).
 // Operand trick: lane (m = l & 15, k = l >> 4) loads ONE float4 = G[s0 + k][64 mt + 4m .. 4m+3] (a slot's 64 channels are 256
 // contiguous bytes over the 16 lanes) and register j of that float4 is the A operand of MFMA j: its row m then stands for
-// channel 4m + j.  X likewise as B.  The 16 MFMAs (j, j') of a step cover the 64 x 64 tile over 4 slots from two 1-KiB loads.
-// The bias sums ride along as a B operand of ones (column 0), for tile column 0 only.
+// channel 4m + j.  X likewise as B.  The 16 MFMAs (j, j') of a step cover the 64 x 64 tile over 4 slots from two 1-KiB loads;
+// four steps of operands are in flight ahead of the MFMAs (two waves per SIMD at this register count: the loads in flight,
+// not the occupancy, have to cover the HBM latency).  The column sums of G are vector adds on the operand registers.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void train_wgrad_kernel(const float* __restrict__ G, int M, const float* __restrict__ X, int N,
-                                                          long long S, int slab, float* __restrict__ partial, long long ld) {
-  __shared__ f32x4 red[2][20][64];
+                                                          long long S, int slab, float* __restrict__ partial, long long ld, int TPW) {
+  __shared__ f32x4 red[2][17][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, k = lane >> 4;
-  const int ntn = (N + 63) / 64;
-  const int mt = blockIdx.y / ntn, nt = blockIdx.y - mt * ntn;
+  const int ntn = (N + 63) / 64, tiles = ((M + 63) / 64) * ntn;
+  const int tw = 4 / TPW, tslot = wave / tw, sub = wave - tslot * tw;
+  const int tile = blockIdx.y * TPW + tslot;
+  const bool live = tile < tiles;                            // wave-uniform; a wave without a tile still meets the barriers
+  const int mt = tile / ntn, nt = tile - mt * ntn;
   const long long s_begin = (long long)blockIdx.x * slab;
   const long long s_end = s_begin + slab < S ? s_begin + slab : S;
   const int gc = 64 * mt + 4 * m, xc = 64 * nt + 4 * m;
-  const bool g_ok = gc < M, x_ok = xc < N;                   // widths are multiples of 16 >= 16: a float4 is in or out as a whole
-  f32x4 acc[4][4], accb[4];
+  const bool g_ok = live && gc < M, x_ok = live && xc < N;   // widths are multiples of 16 >= 16: a float4 is in or out as a whole
+  f32x4 acc[4][4], gs = splat4(0.f);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    accb[j] = splat4(0.f);
+  for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[j][i] = splat4(0.f);
-  }
-  const float one = m == 0 ? 1.0f : 0.f;
-  const bool bias = nt == 0;
+  const bool bias = live && nt == 0;
   const float* Gp = G + gc;
   const float* Xp = X + xc;
-#pragma unroll 2
-  for (long long s0 = s_begin + 4 * wave; s0 < s_end; s0 += 16) {
+  const int STEP = 4 * tw;
+  auto fetch = [&](long long s0, f32x4& gv, f32x4& xv) {
     const long long slot = s0 + k;
     const bool ok = slot < s_end;
-    const f32x4 gv = (ok && g_ok) ? ld4(Gp + slot * M) : splat4(0.f);
-    const f32x4 xv = (ok && x_ok) ? ld4(Xp + slot * N) : splat4(0.f);
+    gv = (ok && g_ok) ? ld4(Gp + slot * M) : splat4(0.f);
+    xv = (ok && x_ok) ? ld4(Xp + slot * N) : splat4(0.f);
+  };
+  auto step = [&](const f32x4& gv, const f32x4& xv) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[j], xv[i], acc[j][i], 0, 0, 0);
-      if (bias) accb[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[j], ok ? one : 0.f, accb[j], 0, 0, 0);
-    }
-  }
-  // the four waves' tiles -> wave 0, through LDS, in two rounds: (w0 += w2, w1 += w3), then w0 += w1
+    gs += gv;
+  };
+  if (live) {
+    long long s0 = s_begin + 4 * sub;
+    f32x4 gq[4], xq[4];
 #pragma unroll
-  for (int round = 0; round < 2; ++round) {
-    const int first_writer = round == 0 ? 2 : 1, writers = round == 0 ? 2 : 1;
-    if (wave >= first_writer && wave < first_writer + writers) {
+    for (int u = 0; u < 4; ++u) fetch(s0 + (long long)u * STEP, gq[u], xq[u]);
+    for (; s0 < s_end; s0 += 4ll * STEP) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) red[wave - first_writer][4 * j + i][lane] = acc[j][i];
-        red[wave - first_writer][16 + j][lane] = accb[j];
+      for (int u = 0; u < 4; ++u) {
+        step(gq[u], xq[u]);
+        fetch(s0 + (long long)(4 + u) * STEP, gq[u], xq[u]);
       }
     }
+  }
+  // waves sharing a tile: tw = 4: (w0 += w2, w1 += w3), then w0 += w1; tw = 2: the pair; tw = 1: nothing to add
+  for (int half = tw >> 1; half >= 1; half >>= 1) {
+    if (sub >= half && sub < 2 * half) {
+      f32x4(*r)[64] = red[tslot * half + sub - half];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[4 * j + i][lane] = acc[j][i];
+      r[16][lane] = gs;
+    }
     __syncthreads();
-    if (wave < writers) {
+    if (sub < half) {
+      f32x4(*r)[64] = red[tslot * half + sub];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] += red[wave][4 * j + i][lane];
-        accb[j] += red[wave][16 + j][lane];
-      }
+        for (int i = 0; i < 4; ++i) acc[j][i] += r[4 * j + i][lane];
+      gs += r[16][lane];
     }
     __syncthreads();
   }
-  if (wave != 0) return;
+  if (sub != 0 || !live) return;
   // acc[j][i][e]: row (4 k + e) of MFMA (j, i) = G channel 64 mt + 4 (4k + e) + j; column m = X channel 64 nt + 4 m + i
   float* out = partial + (size_t)blockIdx.x * (size_t)ld;
 #pragma unroll
@@ -732,8 +747,15 @@ __global__ __launch_bounds__(256) void train_wgrad_kernel(const float* __restric
         for (int i = 0; i < 4; ++i) v[i] = acc[j][i][e];
         *reinterpret_cast<f32x4*>(out + (size_t)row * N + xc) = v;
       }
-      if (bias && m == 0) out[(size_t)M * N + row] = accb[j][e];
     }
+  if (bias) {                                                // column sums: the four slot groups of a step, then one store per channel quad
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      gs[e] += __shfl_xor(gs[e], 16);
+      gs[e] += __shfl_xor(gs[e], 32);
+    }
+    if (k == 0 && g_ok) *reinterpret_cast<f32x4*>(out + (size_t)M * N + gc) = gs;
+  }
 }
 
 int check_args(const TArgs* a, bool bwd) {
@@ -821,9 +843,11 @@ extern "C" int scgg_train_wgrad(const float* G, int32_t M, const float* X, int32
   if (M < 16 || M % 16 != 0 || N < 16 || N % 16 != 0 || slab < 16 || slab % 16 != 0) return fail("train_wgrad: M, N, slab must be multiples of 16");
   const long long nsl = (S + slab - 1) / slab;
   const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
-  if (nsl > 0x7fffffffLL || tiles > 65535) return fail("train_wgrad: too many slabs / tiles");
-  hipLaunchKernelGGL(train_wgrad_kernel, dim3((unsigned)nsl, (unsigned)tiles), dim3(256), 0, static_cast<hipStream_t>(stream), G, (int)M, X,
-                     (int)N, (long long)S, (int)slab, partial, (long long)ld_partial);
+  const int tpw = tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1);     // output tiles per workgroup
+  const int groups = (tiles + tpw - 1) / tpw;
+  if (nsl > 0x7fffffffLL || groups > 65535) return fail("train_wgrad: too many slabs / tiles");
+  hipLaunchKernelGGL(train_wgrad_kernel, dim3((unsigned)nsl, (unsigned)groups), dim3(256), 0, static_cast<hipStream_t>(stream), G, (int)M,
+                     X, (int)N, (long long)S, (int)slab, partial, (long long)ld_partial, tpw);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail("train_wgrad: %s", hipGetErrorString(e));
 }
