@@ -359,6 +359,9 @@ int64_t scgg_projector_counter(const scgg_projector* p);
  * elsewhere (grad_scale is a device scalar: lambda / count * upstream gradient, so no host sync is needed).
  * ---------------------------------------------------------------------------------------------------------- */
 int scgg_dropout(const float* x, float* out, int64_t numel, double p, uint64_t seed, uint32_t site, void* stream);
+/* the same with the key (seed & 0xffffffff, seed >> 32) read from device memory when the kernel runs: the form a captured
+ * HIP graph needs, whose kernel arguments are frozen at capture time */
+int scgg_dropout_devkey(const float* x, float* out, int64_t numel, double p, const uint32_t* key_dev, uint32_t site, void* stream);
 int64_t scgg_masked_cross_entropy_blocks(int64_t rows);
 int scgg_masked_cross_entropy(const float* logits, const int8_t* target, int64_t rows, int32_t C, float* partial,
                               float* grad, const float* grad_scale, void* stream);
@@ -402,6 +405,8 @@ typedef struct scgg_train_edge_args {
   int32_t b0;   /* the call covers graphs [b0, b0 + B) of a larger batch (all pointers already offset): only the dropout stream sees it */
   float inv_sqrt_df, p;
   uint32_t k0, k1, site1, site2, site3;
+  const uint32_t* key_dev;   /* optional: (k0, k1) read from device memory when the kernel RUNS (a captured HIP graph then replays
+                                with whatever key the caller has written there); NULL: k0 / k1 above */
 } scgg_train_edge_args;
 int scgg_train_edge_pack(const float* W, int32_t rows, int32_t cols, int32_t transpose, float* out, void* stream);
 /* the same for up to ten matrices in one launch (a layer's five weights, plain and transposed) */

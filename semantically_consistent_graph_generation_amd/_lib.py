@@ -41,7 +41,8 @@ class TrainEdgeArgs(C.Structure):       # scgg_train_edge_args (include/scgg.h)
              "lse_out", "dOut", "dwV", "wV", "lse", "dE", "G_e", "G_da", "G_z", "G_dnewE", "G_h1", "G_df", "G_f", "G_do", "G_dkv",
              "upart", "st_mean", "st_cm", "st_cv", "st_gmi", "st_gma", "st_imn", "st_imx")
     _fields_ = [(k, C.c_void_p) for k in _PTRS] + [(k, C.c_int32) for k in ("B", "n", "nch", "dx", "de", "ffe", "b0")] + \
-               [("inv_sqrt_df", C.c_float), ("p", C.c_float)] + [(k, C.c_uint32) for k in ("k0", "k1", "site1", "site2", "site3")]
+               [("inv_sqrt_df", C.c_float), ("p", C.c_float)] + [(k, C.c_uint32) for k in ("k0", "k1", "site1", "site2", "site3")] + \
+               [("key_dev", C.c_void_p)]
 
 
 class TrainPackList(C.Structure):       # scgg_train_pack_list (include/scgg.h)
@@ -115,6 +116,7 @@ SIGNATURES = {
     "scgg_linear_rows_pack": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "scgg_linear_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp]),
     "scgg_dropout": (C.c_int, [_vp, _vp, _i64, C.c_double, C.c_uint64, C.c_uint32, _vp]),
+    "scgg_dropout_devkey": (C.c_int, [_vp, _vp, _i64, C.c_double, _vp, C.c_uint32, _vp]),
     "scgg_masked_cross_entropy_blocks": (_i64, [_i64]),
     "scgg_masked_cross_entropy": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "scgg_train_sum_rows_splits": (_i64, [_i64, _i64, _i32]),

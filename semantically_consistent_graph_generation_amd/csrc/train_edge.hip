@@ -229,7 +229,9 @@ __device__ __forceinline__ void load_tile(const TArgs& a, const UnitId& u, f32x4
 // padding mask are the caller's, transformer_model.py:99,110-112) and the unit's softmax partials [max | sum p | sum p V].
 // ---------------------------------------------------------------------------------------------------------
 template <int IBE, int IBF>
-__global__ __launch_bounds__(256) void train_edge_fwd_kernel(TArgs a) {
+__global__ __launch_bounds__(256) void train_edge_fwd_kernel(TArgs a_in) {
+  TArgs a = a_in;
+  if (a.key_dev != nullptr) { a.k0 = a.key_dev[0]; a.k1 = a.key_dev[1]; }   // dropout key read at run time (graph replay)
   const int lane = threadIdx.x & 63, g = lane >> 4;
   const long long total = (long long)a.B * a.n * a.nch;
   if ((long long)blockIdx.x * 4 + (threadIdx.x >> 6) >= total) return;
@@ -302,7 +304,9 @@ __device__ __forceinline__ void zero_rows_rt(float* base, long long slot, int wi
 }
 
 template <int IBE, int IBF>
-__global__ __launch_bounds__(256) void train_edge_bwd_kernel(TArgs a) {
+__global__ __launch_bounds__(256) void train_edge_bwd_kernel(TArgs a_in) {
+  TArgs a = a_in;
+  if (a.key_dev != nullptr) { a.k0 = a.key_dev[0]; a.k1 = a.key_dev[1]; }   // dropout key read at run time (graph replay)
   constexpr int DE = 16 * IBE, FFE = 16 * IBF;
   const int lane = threadIdx.x & 63, p = lane & 15, g = lane >> 4;
   const long long total = (long long)a.B * a.n * a.nch;

@@ -20,9 +20,11 @@
 namespace scgg {
 
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ out, long long numel,
-                                                      float p, float denom, uint32_t k0, uint32_t k1, uint32_t site) {
+                                                      float p, float denom, uint32_t k0, uint32_t k1, uint32_t site,
+                                                      const uint32_t* __restrict__ key_dev) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= numel) return;
+  if (key_dev != nullptr) { k0 = key_dev[0]; k1 = key_dev[1]; }   // the key read at RUN time: a captured graph replays with new masks
   uint32_t r[4];
   const long long c = idx >> 2;                        // four consecutive elements share one Philox call (train_edge.hip: a lane's f32x4)
   philox4x32_10((uint32_t)(c & 0xffffffffll), (uint32_t)(c >> 32), site, 0xD0u, k0, k1, r);
@@ -76,9 +78,23 @@ extern "C" int scgg_dropout(const float* x, float* out, int64_t numel, double p,
   const long long nb = (numel + 255) / 256;
   if (nb > 0x7fffffffLL) return fail("dropout: tensor too large for one launch");
   hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, (long long)numel,
-                     (float)p, (float)(1.0 - p), (uint32_t)(seed & 0xffffffffull), (uint32_t)(seed >> 32), site);
+                     (float)p, (float)(1.0 - p), (uint32_t)(seed & 0xffffffffull), (uint32_t)(seed >> 32), site,
+                     static_cast<const uint32_t*>(nullptr));
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail("dropout: %s", hipGetErrorString(e));
+}
+
+extern "C" int scgg_dropout_devkey(const float* x, float* out, int64_t numel, double p, const uint32_t* key_dev, uint32_t site,
+                                   void* stream) {
+  if (!x || !out || !key_dev) return fail("dropout_devkey: null argument");
+  if (numel < 0 || !(p >= 0.0) || !(p < 1.0)) return fail("dropout_devkey: bad numel or p");
+  if (numel == 0) return 0;
+  const long long nb = (numel + 255) / 256;
+  if (nb > 0x7fffffffLL) return fail("dropout_devkey: tensor too large for one launch");
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, (long long)numel,
+                     (float)p, (float)(1.0 - p), 0u, 0u, site, key_dev);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail("dropout_devkey: %s", hipGetErrorString(e));
 }
 
 extern "C" int64_t scgg_masked_cross_entropy_blocks(int64_t rows) { return rows <= 0 ? 0 : (rows + 255) / 256; }

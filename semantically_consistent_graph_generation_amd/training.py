@@ -29,21 +29,40 @@ from .placeholder import PlaceHolder
 
 
 # ------------------------------------------------------------------------------------------------- kernels under autograd
+def _is_device_key(seed):
+    """A dropout seed held in device memory: one int64 (or two int32 words, low first) on the GPU.  The kernels read it when
+    they RUN, so a captured HIP graph draws new masks on every replay once the caller has written a new seed there."""
+    return isinstance(seed, torch.Tensor)
+
+
+def _check_device_key(seed):
+    if not (seed.is_cuda and seed.is_contiguous() and seed.numel() * seed.element_size() == 8):
+        raise _lib.ScggError("a device-resident dropout seed is one int64 (or two int32) on the GPU")
+    return seed
+
+
+def _dropout_launch(x, out, p, seed, site, what):
+    if _is_device_key(seed):
+        _lib.check(_lib.lib().scgg_dropout_devkey(_lib.ptr(x), _lib.ptr(out), x.numel(), p, _check_device_key(seed).data_ptr(), site,
+                                                  _lib.stream_ptr()), what)
+    else:
+        _lib.check(_lib.lib().scgg_dropout(_lib.ptr(x), _lib.ptr(out), x.numel(), p, int(seed), site, _lib.stream_ptr()), what)
+
+
 class _Dropout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p, seed, site):
         ctx.p, ctx.seed, ctx.site = p, seed, site
         x = x.contiguous()
         out = torch.empty_like(x)
-        _lib.check(_lib.lib().scgg_dropout(_lib.ptr(x), _lib.ptr(out), x.numel(), p, seed, site, _lib.stream_ptr()), "dropout")
+        _dropout_launch(x, out, p, seed, site, "dropout")
         return out
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
         out = torch.empty_like(g)
-        _lib.check(_lib.lib().scgg_dropout(_lib.ptr(g), _lib.ptr(out), g.numel(), ctx.p, ctx.seed, ctx.site, _lib.stream_ptr()),
-                   "dropout (backward)")
+        _dropout_launch(g, out, ctx.p, ctx.seed, ctx.site, "dropout (backward)")
         return out, None, None, None
 
 
@@ -60,7 +79,7 @@ class DropoutSites:
             return x
         if not x.is_cuda or x.dtype != torch.float32:
             raise _lib.ScggError("dropout runs on the MI355X in fp32 only")
-        return _Dropout.apply(x, self.p, int(self.seed), s)
+        return _Dropout.apply(x, self.p, self.seed if _is_device_key(self.seed) else int(self.seed), s)
 
 
 class _MaskedCE(torch.autograd.Function):
@@ -315,8 +334,10 @@ class _FusedEdgeLayer(torch.autograd.Function):
         a.E_out, a.part, a.wV_out, a.lse_out = E_out.data_ptr(), part.data_ptr(), wV.data_ptr(), lse.data_ptr()
         a.B, a.n, a.nch, a.dx, a.de, a.ffe = B, n, nch, dx, de, ffe
         a.inv_sqrt_df, a.p = float(inv_sqrt_df), float(p) if seed is not None else 0.0
-        sd = int(seed) if seed is not None else 0
+        key = _check_device_key(seed) if _is_device_key(seed) else None
+        sd = int(seed) if seed is not None and key is None else 0
         a.k0, a.k1 = sd & 0xFFFFFFFF, (sd >> 32) & 0xFFFFFFFF
+        a.key_dev = key.data_ptr() if key is not None else None
         a.site1, a.site2, a.site3 = (int(v) for v in sites)
         _lib.check(_lib.lib().scgg_train_edge_forward(C.byref(a), _lib.stream_ptr()), "train_edge_forward")
         del keep
@@ -341,6 +362,7 @@ class _FusedEdgeLayer(torch.autograd.Function):
         ctx.with_stats = bool(with_stats)
         ctx.save_for_backward(E, Q, K, V, yea, yem1, mask_u8, wV, lse, *vecs, *Ws, *st_keep, *F_fwd, *F_bwd)
         ctx.cfg = (float(inv_sqrt_df), a.p, sd, tuple(int(v) for v in sites))
+        ctx.key = key
         ctx.mark_non_differentiable(lse)
         return E_out, wV, lse, stats
 
@@ -387,6 +409,7 @@ class _FusedEdgeLayer(torch.autograd.Function):
         a.n, a.nch, a.dx, a.de, a.ffe = n, nch, dx, de, ffe
         a.inv_sqrt_df, a.p = inv_sqrt_df, p
         a.k0, a.k1 = sd & 0xFFFFFFFF, (sd >> 32) & 0xFFFFFFFF
+        a.key_dev = ctx.key.data_ptr() if ctx.key is not None else None
         a.site1, a.site2, a.site3 = sites
         L = _lib.lib()
         prods = (("G_da", "G_e"), ("G_dnewE", "G_z"), ("G_df", "G_h1"), ("G_do", "G_f"))     # [2dx,de] = d e_mul | d e_add weights, ...
@@ -651,6 +674,61 @@ def training_step(model, noise_model, extra_features, dense_data, true_E_labels,
         pred = train_forward(model, X, E, y, z_t.node_mask, seed=dropout_seed)
         loss = loss_fn(pred, true_X, true_E_labels, z_t.node_mask)
     return loss, pred, z_t
+
+
+class CapturedTrainingStep:
+    """``training_step`` + ``loss.backward()`` + ``optimizer.step()`` recorded ONCE into a HIP graph and replayed: the step is
+    ~1 200 small launches and, issued from Python, as slow as the host can queue them; a replay costs the host one call.
+
+    What capture needs and how it is met: (1) nothing may change between replays except memory contents, so the batch lives
+    in the tensors handed in (copy the next batch INTO them: ``dense_data.E.copy_(...)``, ``true_E_labels.copy_(...)``) and
+    the shapes are fixed; (2) kernel arguments are frozen, so everything random comes from device memory: the diffusion
+    time ``t_int`` and the uniforms of ``apply_noise`` are drawn by torch's graph-safe generator into ``self.t_int`` /
+    ``self.u0`` inside the graph, and the dropout kernels read their Philox key from ``self.seed`` (incremented inside the
+    graph; ``scgg_dropout_devkey``, ``scgg_train_edge_args.key_dev``); (3) the optimizer must be built with
+    ``capturable=True``; (4) no host synchronisation inside the step (``apply_noise``'s tables are device-resident).
+    The ``warmup`` iterations run eagerly and ARE training steps.  After a replay ``self.t_int``, ``self.u0``
+    and ``self.seed`` hold what that step used (the tests re-run it eagerly from them).  One process, one GPU: with
+    ``GradientBuckets`` the all-reduce is not part of the graph."""
+
+    def __init__(self, model, noise_model, extra_features, dense_data, true_E_labels, optimizer, seed=0, loss_fn=None, warmup=3):
+        from .noise_model import Rng
+        dev = dense_data.X.device
+        if dev.type != "cuda":
+            raise _lib.ScggError("CapturedTrainingStep needs the MI355X")
+        for grp in optimizer.param_groups:
+            if not grp.get("capturable", False):
+                raise _lib.ScggError("build the optimizer with capturable=True: its step counters must live on the device")
+        B, n = dense_data.node_mask.shape
+        self.seed = torch.full((1,), int(seed), dtype=torch.int64, device=dev)
+        self.t_int = torch.zeros(B, 1, dtype=torch.int64, device=dev)
+        self.u0 = torch.zeros(B, n, n, device=dev)
+        self.optimizer, self.model = optimizer, model
+        T = noise_model.T
+        loss_fn = loss_fn or TrainLoss()
+
+        def body():
+            self.seed.add_(1)
+            self.t_int.random_(1, T + 1)
+            self.u0.uniform_()
+            loss = training_step(model, noise_model, extra_features, dense_data, true_E_labels, loss_fn, t_int=self.t_int,
+                                 rng=Rng(u0=self.u0), dropout_seed=self.seed)[0]
+            loss.backward()
+            optimizer.step()
+            return loss.detach()
+
+        for _ in range(max(1, warmup)):                # lazy initialisations, device tables, library handles: outside the graph
+            optimizer.zero_grad(set_to_none=True)      # (on the caller's stream: the package creates no streams of its own, DESIGN 4.4;
+            body()                                     # the capture stream is torch's)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)          # the graph's backward then OWNS the gradient tensors and rewrites them per replay
+        with torch.cuda.graph(self.graph):
+            self.loss = body()
+
+    def __call__(self):
+        self.graph.replay()
+        return self.loss
 
 
 # ------------------------------------------------------------------------------------------------- data-parallel gradients
