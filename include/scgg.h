@@ -361,6 +361,17 @@ int64_t scgg_projector_counter(const scgg_projector* p);
 int scgg_dropout(const float* x, float* out, int64_t numel, double p, uint64_t seed, uint32_t site, void* stream);
 /* the same with the key (seed & 0xffffffff, seed >> 32) read from device memory when the kernel runs: the form a captured
  * HIP graph needs, whose kernel arguments are frozen at capture time */
+/* out[b,i,j,:] = 0.5 (R[b,i,j,:] + R[b,j,i,:]) on pairs of valid nodes i != j, 0 elsewhere (transformer_model.py:108-112
+ * followed by PlaceHolder.mask, utils.py:160-164, with the zero diagonal of :389): one pass over [B,n,n,C] fp32; out != R.
+ * Linear and self-adjoint: the backward of the training path is the same call on the gradient. */
+int scgg_sym_mask(const float* R, const uint8_t* mask, int32_t B, int32_t n, int32_t C, float* out, void* stream);
+/* Xtoy's pooling (layers.py:12-21) under autograd, one launch each way: out [B, 4 dx] = mean | min | max | var exactly as the
+ * reference forms them (sums over all n rows / number of valid nodes; +-1e5 on masked rows for the extrema); aux [B, 3 dx] and
+ * arg [B, 2 dx] (rows of the extrema) are what the backward needs; dX [B,n,dx] from g [B, 4 dx]. */
+int scgg_train_node_stats(const float* X, const uint8_t* mask, int32_t B, int32_t n, int32_t dx, float* out, float* aux, int32_t* arg,
+                          void* stream);
+int scgg_train_node_stats_backward(const float* X, const uint8_t* mask, int32_t B, int32_t n, int32_t dx, const float* g,
+                                   const float* aux, const int32_t* arg, float* dX, void* stream);
 int scgg_dropout_devkey(const float* x, float* out, int64_t numel, double p, const uint32_t* key_dev, uint32_t site, void* stream);
 int64_t scgg_masked_cross_entropy_blocks(int64_t rows);
 int scgg_masked_cross_entropy(const float* logits, const int8_t* target, int64_t rows, int32_t C, float* partial,

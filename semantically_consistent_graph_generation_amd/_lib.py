@@ -116,6 +116,9 @@ SIGNATURES = {
     "scgg_linear_rows_pack": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "scgg_linear_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp]),
     "scgg_dropout": (C.c_int, [_vp, _vp, _i64, C.c_double, C.c_uint64, C.c_uint32, _vp]),
+    "scgg_train_node_stats": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "scgg_train_node_stats_backward": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "scgg_sym_mask": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "scgg_dropout_devkey": (C.c_int, [_vp, _vp, _i64, C.c_double, _vp, C.c_uint32, _vp]),
     "scgg_masked_cross_entropy_blocks": (_i64, [_i64]),
     "scgg_masked_cross_entropy": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),

@@ -586,35 +586,64 @@ __global__ __launch_bounds__(256) void train_edge_stats_kernel(const float* __re
   }
 }
 
-// The slices of train_edge_stats_kernel merged per (graph, channel), slices in index order (pairwise update of mean / M2;
-// ties of an extremum go to the smaller pair index, the rule inside a slice): stats [B, 4 de] = mean | min | max | var,
-// what Etoy hands to the y update, and what the backward needs: mean, count, arg-extrema [B, de] each.
-__global__ __launch_bounds__(256) void train_edge_stats_finish_kernel(const float* __restrict__ so, const int* __restrict__ si, int B,
-                                                                      int slices, int DE, float* __restrict__ stats,
-                                                                      float* __restrict__ mean_o, float* __restrict__ tot_o,
-                                                                      int* __restrict__ imn_o, int* __restrict__ imx_o) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= B * DE) return;
-  const int b = idx / DE, c = idx - b * DE;
-  float ca = 0.f, mean = 0.f, M2 = 0.f, mn = INFINITY, mx = -INFINITY;
-  int imn = 0, imx = 0;
-  for (int s = 0; s < slices; ++s) {
-    const float* o = so + ((size_t)b * slices + s) * 5 * DE + c;
-    const int* oi = si + ((size_t)b * slices + s) * 2 * DE + c;
-    const float cb = o[0];
-    if (cb == 0.f) continue;
-    const float mb = o[DE], Mb = o[2 * DE], nb = o[3 * DE], xb = o[4 * DE];
-    const float tot = ca + cb, d = mb - mean;
-    M2 = ca == 0.f ? Mb : M2 + Mb + d * d * (ca * cb / tot);
-    mean = ca == 0.f ? mb : mean + d * (cb / tot);
-    if (nb < mn || (nb == mn && oi[0] < imn)) { mn = nb; imn = oi[0]; }
-    if (xb > mx || (xb == mx && oi[DE] < imx)) { mx = xb; imx = oi[DE]; }
-    ca = tot;
+// The slices of train_edge_stats_kernel merged per (graph, channel) by the pairwise update of mean / M2; ties of an extremum go
+// to the smaller pair index, the rule inside a slice.  stats [B, 4 de] = mean | min | max | var, what Etoy hands to the y update,
+// and what the backward needs: mean, count, arg-extrema [B, de] each.  One workgroup per graph, thread = (channel, one of QL
+// slice lanes): a lane folds the slices sl, sl + QL, ... (a fixed order; as one thread per channel walking all slices it was a
+// chain of ~64 dependent round trips, 80 us), lane 0 then folds the QL lane results in lane order.
+struct StatAcc { float ca, mean, M2, mn, mx; int imn, imx; };
+__device__ __forceinline__ void stat_fold(StatAcc& a, float cb, float mb, float Mb, float nb, float xb, int inb, int ixb) {
+  if (cb == 0.f) return;
+  const float tot = a.ca + cb, d = mb - a.mean;
+  a.M2 = a.ca == 0.f ? Mb : a.M2 + Mb + d * d * (a.ca * cb / tot);
+  a.mean = a.ca == 0.f ? mb : a.mean + d * (cb / tot);
+  if (nb < a.mn || (nb == a.mn && inb < a.imn)) { a.mn = nb; a.imn = inb; }
+  if (xb > a.mx || (xb == a.mx && ixb < a.imx)) { a.mx = xb; a.imx = ixb; }
+  a.ca = tot;
+}
+__global__ __launch_bounds__(1024) void train_edge_stats_finish_kernel(const float* __restrict__ so, const int* __restrict__ si,
+                                                                       int slices, int DE, int QL, float* __restrict__ stats,
+                                                                       float* __restrict__ mean_o, float* __restrict__ tot_o,
+                                                                       int* __restrict__ imn_o, int* __restrict__ imx_o) {
+  __shared__ float shf[5][1024];
+  __shared__ int shi[2][1024];
+  const int b = blockIdx.x, tid = threadIdx.x, c = tid % DE, sl = tid / DE;
+  StatAcc a{0.f, 0.f, 0.f, INFINITY, -INFINITY, 0, 0};
+  const float* ob = so + (size_t)b * slices * 5 * DE + c;
+  const int* ib = si + (size_t)b * slices * 2 * DE + c;
+  int s = sl;
+  for (; s + 3 * QL < slices; s += 4 * QL) {           // four slices' worth of loads in flight
+    float v[4][5];
+    int ix[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* o = ob + (size_t)(s + u * QL) * 5 * DE;
+      const int* oi = ib + (size_t)(s + u * QL) * 2 * DE;
+#pragma unroll
+      for (int f = 0; f < 5; ++f) v[u][f] = o[f * DE];
+      ix[u][0] = oi[0]; ix[u][1] = oi[DE];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) stat_fold(a, v[u][0], v[u][1], v[u][2], v[u][3], v[u][4], ix[u][0], ix[u][1]);
   }
-  const float tot = ca < 1.f ? 1.f : ca;
+  for (; s < slices; s += QL) {
+    const float* o = ob + (size_t)s * 5 * DE;
+    const int* oi = ib + (size_t)s * 2 * DE;
+    stat_fold(a, o[0], o[DE], o[2 * DE], o[3 * DE], o[4 * DE], oi[0], oi[DE]);
+  }
+  shf[0][tid] = a.ca; shf[1][tid] = a.mean; shf[2][tid] = a.M2; shf[3][tid] = a.mn; shf[4][tid] = a.mx;
+  shi[0][tid] = a.imn; shi[1][tid] = a.imx;
+  __syncthreads();
+  if (sl != 0) return;
+  for (int q = 1; q < QL; ++q) {
+    const int o = q * DE + c;
+    stat_fold(a, shf[0][o], shf[1][o], shf[2][o], shf[3][o], shf[4][o], shi[0][o], shi[1][o]);
+  }
+  const float tot = a.ca < 1.f ? 1.f : a.ca;
   float* st = stats + (size_t)b * 4 * DE + c;
-  st[0] = mean; st[DE] = mn; st[2 * DE] = mx; st[3 * DE] = M2 / tot;
-  mean_o[idx] = mean; tot_o[idx] = tot; imn_o[idx] = imn; imx_o[idx] = imx;
+  st[0] = a.mean; st[DE] = a.mn; st[2 * DE] = a.mx; st[3 * DE] = a.M2 / tot;
+  const int idx = b * DE + c;
+  mean_o[idx] = a.mean; tot_o[idx] = tot; imn_o[idx] = a.imn; imx_o[idx] = a.imx;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -869,8 +898,12 @@ extern "C" int scgg_train_edge_stats_finish(const float* out, const int32_t* idx
                                             float* mean, float* count, int32_t* imn, int32_t* imx, void* stream) {
   if (!out || !idx || !stats || !mean || !count || !imn || !imx || B <= 0 || slices <= 0 || de <= 0)
     return fail("train_edge_stats_finish: bad arguments");
-  hipLaunchKernelGGL(train_edge_stats_finish_kernel, dim3((unsigned)((B * de + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), out, idx, B, slices, de, stats, mean, count, imn, imx);
+  if (de > 1024) return fail("train_edge_stats_finish: de = %d beyond 1024", de);
+  int ql = 256 / de;                                                     // slice lanes per channel
+  if (ql < 1) ql = 1;
+  if (ql > slices) ql = slices;
+  hipLaunchKernelGGL(train_edge_stats_finish_kernel, dim3((unsigned)B), dim3((unsigned)(de * ql)), 0, static_cast<hipStream_t>(stream), out,
+                     idx, slices, de, ql, stats, mean, count, imn, imx);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail("train_edge_stats_finish: %s", hipGetErrorString(e));
 }

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -150,11 +151,72 @@ def _ln(m, x):
     return F.layer_norm(x, m.normalized_shape, m.weight, m.bias, m.eps)
 
 
+class _SymMask(torch.autograd.Function):
+    """E -> 0.5 (E + E^T) on the pairs of valid nodes i != j, 0 elsewhere (transformer_model.py:108-112 + PlaceHolder.mask) in
+    one pass (``scgg_sym_mask``); the map is linear and self-adjoint, so the backward is the same call on the gradient.  The
+    same bits as the tensor ops it replaces (a scale by 0.5 is exact, the mask is 0 / 1)."""
+
+    @staticmethod
+    def forward(ctx, R, mask_u8):
+        ctx.save_for_backward(mask_u8)
+        R = R.contiguous()
+        out = torch.empty_like(R)
+        B, n, _, Cc = R.shape
+        _lib.check(_lib.lib().scgg_sym_mask(_lib.ptr(R), _lib.ptr(mask_u8), B, n, Cc, _lib.ptr(out), _lib.stream_ptr()), "sym_mask")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask_u8,) = ctx.saved_tensors
+        g = g.contiguous()
+        out = torch.empty_like(g)
+        B, n, _, Cc = g.shape
+        _lib.check(_lib.lib().scgg_sym_mask(_lib.ptr(g), _lib.ptr(mask_u8), B, n, Cc, _lib.ptr(out), _lib.stream_ptr()), "sym_mask (backward)")
+        return out, None
+
+
+def _sym_mask(E, mask_u8):
+    if E.is_cuda and E.dtype == torch.float32 and os.environ.get("SCGG_TRAIN_MODE", "fused") != "eager":
+        return _SymMask.apply(E, mask_u8)
+    m = mask_u8.to(E.dtype)
+    n = E.shape[1]
+    w = m[:, :, None] * m[:, None, :] * (1.0 - torch.eye(n, dtype=E.dtype, device=E.device))[None]
+    return (0.5 * (E + E.transpose(1, 2))) * w[..., None]
+
+
 def _mask_xe(X, E, m, offdiag):
     return X * m[:, :, None], E * (m[:, :, None] * m[:, None, :] * offdiag)[..., None]
 
 
-def _node_stats(X, m):
+class _NodeStats(torch.autograd.Function):
+    """Xtoy's pooled statistics (layers.py:12-21) as one kernel each way (``scgg_train_node_stats``)."""
+
+    @staticmethod
+    def forward(ctx, X, mask_u8):
+        X = X.contiguous()
+        B, n, dx = X.shape
+        out = torch.empty(B, 4 * dx, device=X.device)
+        aux = torch.empty(B, 3 * dx, device=X.device)
+        arg = torch.empty(B, 2 * dx, dtype=torch.int32, device=X.device)
+        _lib.check(_lib.lib().scgg_train_node_stats(_lib.ptr(X), _lib.ptr(mask_u8), B, n, dx, _lib.ptr(out), _lib.ptr(aux), _lib.ptr(arg),
+                                                    _lib.stream_ptr()), "train_node_stats")
+        ctx.save_for_backward(X, mask_u8, aux, arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        X, mask_u8, aux, arg = ctx.saved_tensors
+        B, n, dx = X.shape
+        dX = torch.empty_like(X)
+        _lib.check(_lib.lib().scgg_train_node_stats_backward(_lib.ptr(X), _lib.ptr(mask_u8), B, n, dx, _lib.ptr(g.float().contiguous()),
+                                                             _lib.ptr(aux), _lib.ptr(arg), _lib.ptr(dX), _lib.stream_ptr()),
+                   "train_node_stats_backward")
+        return dX, None
+
+
+def _node_stats(X, m, mask_u8=None):
+    if mask_u8 is not None and X.is_cuda and X.dtype == torch.float32 and os.environ.get("SCGG_TRAIN_MODE", "fused") != "eager":
+        return _NodeStats.apply(X, mask_u8)
     w = m[:, :, None]
     cnt = w.sum(dim=1)
     mean = X.sum(dim=1) / cnt
@@ -475,20 +537,18 @@ def _layer_fused(layer, hX, hE, hy, m, node_mask, mask_u8, offdiag, dl, base):
     newX = _lin(a.x_out, _lin(a.y_x_add, hy)[:, None, :] + (_lin(a.y_x_mul, hy)[:, None, :] + 1.0) * wV) * xm
     new_y = None
     if a.predicts_y:
-        z = _lin(a.y_y, hy) + _lin(a.x_y.lin, _node_stats(hX, m)) + _lin(a.e_y.lin, e_stats)
+        z = _lin(a.y_y, hy) + _lin(a.x_y.lin, _node_stats(hX, m, mask_u8)) + _lin(a.e_y.lin, e_stats)
         new_y = _lin(a.y_out[2], torch.relu(_lin(a.y_out[0], z)))
     dl.site = base
     hX = _ln(layer.normX1, hX + dl(newX))
     hX = _ln(layer.normX2, hX + dl(_lin(layer.linX2, dl(torch.relu(_lin(layer.linX1, hX))))))
-    hE = 0.5 * (E_raw + E_raw.transpose(1, 2))
     if layer.predicts_y:
         dl.site = base + 6
         hy = _ln(layer.norm_y1, hy + dl(new_y))
         hy = _ln(layer.norm_y2, hy + dl(_lin(layer.lin_y2, dl(torch.relu(_lin(layer.lin_y1, hy))))))
     else:
         hy = None
-    hX, hE = _mask_xe(hX, hE, m, offdiag)
-    return hX, hE, hy
+    return hX * xm, _sym_mask(E_raw, mask_u8), hy
 
 
 def train_forward(model, X, E, y, node_mask, seed=None, p_layer=None):
@@ -515,12 +575,10 @@ def train_forward(model, X, E, y, node_mask, seed=None, p_layer=None):
 
     def mlp_out(seq, x, lin=_lin):
         return lin(seq[3], dio(torch.relu(lin(seq[0], x))))
-    hE = mlp_in(model.mlp_in_E, E, plin)
-    hE = (hE + hE.transpose(1, 2)) / 2
-    hX = mlp_in(model.mlp_in_X, X)
-    hy = mlp_in(model.mlp_in_y, y)
-    hX, hE = _mask_xe(hX, hE, m, offdiag)
     mask_u8 = node_mask.contiguous().view(torch.uint8)
+    hE = _sym_mask(mlp_in(model.mlp_in_E, E, plin), mask_u8)
+    hX = mlp_in(model.mlp_in_X, X) * m[:, :, None]
+    hy = mlp_in(model.mlp_in_y, y)
     for l, layer in enumerate(model.tf_layers):
         dl.site = 100 + 16 * l
         if fused_edge_supported(hX.shape[-1], hE.shape[-1], layer.linE1.weight.shape[0]):
@@ -540,10 +598,9 @@ def train_forward(model, X, E, y, node_mask, seed=None, p_layer=None):
         hX, hE = _mask_xe(hX, hE, m, offdiag)
     dio.site = 50
     oX = mlp_out(model.mlp_out_X, hX) + X[..., :oXc]
-    oE = (mlp_out(model.mlp_out_E, hE, plin) + E[..., : model.out_dim_E]) * offdiag[..., None]
-    oE = 0.5 * (oE + oE.transpose(1, 2))
+    oE = _sym_mask(mlp_out(model.mlp_out_E, hE, plin) + E[..., : model.out_dim_E], mask_u8)    # :386-389: off-diagonal, symmetric, masked
     oy = mlp_out(model.mlp_out_y, hy) + y[..., : model.out_dim_y] if model.predicts_final_y else None
-    oX, oE = _mask_xe(oX, oE, m, offdiag)
+    oX = oX * m[:, :, None]
     return PlaceHolder(X=oX[..., : model.out_dim_X], charges=oX[..., model.out_dim_X:], E=oE, y=oy, node_mask=node_mask)
 
 

@@ -571,3 +571,37 @@ def test_captured_step_replays_what_the_eager_step_computes():
             assert float((p.grad - q.grad).abs().max()) <= 1e-6 * max(scale, 1e-12), k
     assert losses[0][2] + 1 == losses[1][2]                       # the key moved on
     assert not torch.equal(losses[0][1], losses[1][1]) or losses[0][0] != losses[1][0]
+
+
+@pytest.mark.parametrize("Cc", [64, 5])
+def test_sym_mask_kernel_equals_the_tensor_ops_it_replaces(Cc):
+    from semantically_consistent_graph_generation_amd.training import _SymMask
+    B, n = 3, 37
+    g = torch.Generator().manual_seed(Cc)
+    R = torch.randn(B, n, n, Cc, generator=g).cuda().requires_grad_(True)
+    mask = (torch.arange(n)[None] < torch.tensor([37, 20, 1])[:, None]).cuda()
+    m = mask.float()
+    w = (m[:, :, None] * m[:, None, :] * (1.0 - torch.eye(n, device="cuda"))[None])[..., None]
+    want = (0.5 * (R + R.transpose(1, 2))) * w
+    got = _SymMask.apply(R, mask.view(torch.uint8).contiguous())
+    assert torch.equal(got, want)
+    go = torch.randn(B, n, n, Cc, generator=g).cuda()
+    (gw,) = torch.autograd.grad(want, R, go, retain_graph=True)
+    (gg,) = torch.autograd.grad(got, R, go)
+    assert torch.equal(gg, gw)
+
+
+def test_node_stats_kernel_matches_the_tensor_ops():
+    from semantically_consistent_graph_generation_amd.training import _NodeStats, _node_stats
+    B, n, dx = 3, 45, 128
+    g = torch.Generator().manual_seed(8)
+    mask = (torch.arange(n)[None] < torch.tensor([45, 17, 2])[:, None]).cuda()
+    m = mask.float()
+    X = (torch.randn(B, n, dx, generator=g).cuda() * m[:, :, None]).requires_grad_(True)
+    want = _node_stats(X, m)
+    got = _NodeStats.apply(X, mask.view(torch.uint8).contiguous())
+    assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    go = torch.randn(B, 4 * dx, generator=g).cuda()
+    (gw,) = torch.autograd.grad(want, X, go, retain_graph=True)
+    (gg,) = torch.autograd.grad(got, X, go)
+    assert float((gg - gw).abs().max()) <= 2e-6 * float(gw.abs().max())
