@@ -365,6 +365,32 @@ int scgg_dropout(const float* x, float* out, int64_t numel, double p, uint64_t s
  * followed by PlaceHolder.mask, utils.py:160-164, with the zero diagonal of :389): one pass over [B,n,n,C] fp32; out != R.
  * Linear and self-adjoint: the backward of the training path is the same call on the gradient. */
 int scgg_sym_mask(const float* R, const uint8_t* mask, int32_t B, int32_t n, int32_t C, float* out, void* stream);
+/* The global-feature (y) path of one XEyTransformerLayer in training mode (transformer_model.py:229-246 and :100-105): under
+ * autograd eleven Linears on [B, dy] vectors with LayerNorms, ReLUs and three dropout sites, ~120 launches per layer and step;
+ * here a forward kernel, a backward kernel (data gradients; recomputes the chain from the inputs) and ONE kernel for all
+ * weight gradients.  hy [B,dy], xstats [B,dx4] (Xtoy, dx4 = 4 dx), estats [B,de4] (Etoy); weights row-major [out,in] as
+ * nn.Linear holds them; out = the layer's new y.  Dropout: p, key (k0, k1) or key_dev, sites of y1 / y2-inner / y2-outer (the
+ * stream of scgg_dropout on [B, width] tensors).  Backward: dout [B,dy] -> dhy, dxstats, destats and `save`
+ * [B, scgg_train_y_save_width(dy, ffy)] for scgg_train_y_wgrad, which writes the 18 parameter gradients in the order of the
+ * parameters below.  dy <= 256. */
+typedef struct scgg_train_y_args {
+  const float *hy, *xstats, *estats;
+  const float *W_yy, *b_yy, *W_xy, *b_xy, *W_ey, *b_ey, *W_o0, *b_o0, *W_o2, *b_o2, *g1, *be1, *W_1, *b_1, *W_2, *b_2, *g2, *be2;
+  float* out;
+  const float* dout;
+  float *dhy, *dxstats, *destats, *save;
+  int32_t B, dy, dx4, de4, ffy;
+  float p;
+  uint32_t k0, k1, site1, site2, site3;
+  const uint32_t* key_dev;
+  float* fsave;   /* optional [B, scgg_train_y_keep_width(dy, ffy)]: the forward leaves its intermediates there and a backward
+                     given the same buffer reads them instead of recomputing the chain */
+} scgg_train_y_args;
+int64_t scgg_train_y_save_width(int32_t dy, int32_t ffy);
+int64_t scgg_train_y_keep_width(int32_t dy, int32_t ffy);
+int scgg_train_y_forward(const scgg_train_y_args* a, void* stream);
+int scgg_train_y_backward(const scgg_train_y_args* a, void* stream);
+int scgg_train_y_wgrad(const scgg_train_y_args* a, float* const* grads, void* stream);
 /* Xtoy's pooling (layers.py:12-21) under autograd, one launch each way: out [B, 4 dx] = mean | min | max | var exactly as the
  * reference forms them (sums over all n rows / number of valid nodes; +-1e5 on masked rows for the extrema); aux [B, 3 dx] and
  * arg [B, 2 dx] (rows of the extrema) are what the backward needs; dX [B,n,dx] from g [B, 4 dx]. */

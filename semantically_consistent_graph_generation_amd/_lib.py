@@ -45,6 +45,13 @@ class TrainEdgeArgs(C.Structure):       # scgg_train_edge_args (include/scgg.h)
                [("key_dev", C.c_void_p)]
 
 
+class TrainYArgs(C.Structure):          # scgg_train_y_args (include/scgg.h)
+    _PTRS = ("hy", "xstats", "estats", "W_yy", "b_yy", "W_xy", "b_xy", "W_ey", "b_ey", "W_o0", "b_o0", "W_o2", "b_o2", "g1", "be1",
+             "W_1", "b_1", "W_2", "b_2", "g2", "be2", "out", "dout", "dhy", "dxstats", "destats", "save")
+    _fields_ = [(k, C.c_void_p) for k in _PTRS] + [(k, C.c_int32) for k in ("B", "dy", "dx4", "de4", "ffy")] + [("p", C.c_float)] + \
+               [(k, C.c_uint32) for k in ("k0", "k1", "site1", "site2", "site3")] + [("key_dev", C.c_void_p), ("fsave", C.c_void_p)]
+
+
 class TrainPackList(C.Structure):       # scgg_train_pack_list (include/scgg.h)
     _fields_ = [("W", C.c_void_p * 10), ("out", C.c_void_p * 10), ("rows", C.c_int32 * 10), ("cols", C.c_int32 * 10),
                 ("transpose", C.c_int32 * 10), ("count", C.c_int32)]
@@ -116,6 +123,11 @@ SIGNATURES = {
     "scgg_linear_rows_pack": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "scgg_linear_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp]),
     "scgg_dropout": (C.c_int, [_vp, _vp, _i64, C.c_double, C.c_uint64, C.c_uint32, _vp]),
+    "scgg_train_y_save_width": (_i64, [_i32, _i32]),
+    "scgg_train_y_keep_width": (_i64, [_i32, _i32]),
+    "scgg_train_y_forward": (C.c_int, [C.POINTER(TrainYArgs), _vp]),
+    "scgg_train_y_backward": (C.c_int, [C.POINTER(TrainYArgs), _vp]),
+    "scgg_train_y_wgrad": (C.c_int, [C.POINTER(TrainYArgs), C.POINTER(C.c_void_p), _vp]),
     "scgg_train_node_stats": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "scgg_train_node_stats_backward": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "scgg_sym_mask": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),

@@ -523,6 +523,68 @@ class _FusedEdgeLayer(torch.autograd.Function):
                 dW_ma[:dx], db_ma[:dx], dW_ma[dx:], db_ma[dx:], dW_out, db_out, dg1, db1, dW_ff1, db_ff1, dW_ff2, db_ff2, dg2, db2)
 
 
+class _YRound(torch.autograd.Function):
+    """The y path of one XEyTransformerLayer in training mode (transformer_model.py:229-246 + :100-105) as three kernels
+    (csrc/train_y.hip): (hy, Xtoy statistics, Etoy statistics) -> the layer's new y.  Saves its inputs and the chain's
+    intermediates (a few vectors per graph); one more kernel forms all 18 parameter gradients."""
+
+    NAMES = ("W_yy", "b_yy", "W_xy", "b_xy", "W_ey", "b_ey", "W_o0", "b_o0", "W_o2", "b_o2", "g1", "be1", "W_1", "b_1", "W_2", "b_2", "g2", "be2")
+
+    @staticmethod
+    def _args(hy, xs, es, params, p, seed, sites):
+        a = _lib.TrainYArgs()
+        a.hy, a.xstats, a.estats = hy.data_ptr(), xs.data_ptr(), es.data_ptr()
+        for k, t in zip(_YRound.NAMES, params):
+            setattr(a, k, t.data_ptr())
+        a.B, a.dy, a.dx4, a.de4, a.ffy = hy.shape[0], hy.shape[1], xs.shape[1], es.shape[1], params[12].shape[0]
+        key = _check_device_key(seed) if _is_device_key(seed) else None
+        sd = int(seed) if seed is not None and key is None else 0
+        a.p = float(p) if seed is not None else 0.0
+        a.k0, a.k1 = sd & 0xFFFFFFFF, (sd >> 32) & 0xFFFFFFFF
+        a.key_dev = key.data_ptr() if key is not None else None
+        a.site1, a.site2, a.site3 = (int(v) for v in sites)
+        return a
+
+    @staticmethod
+    def forward(ctx, hy, xs, es, p, seed, sites, *params):
+        hy, xs, es = (t.detach().float().contiguous() for t in (hy, xs, es))
+        params = [t.detach().float().contiguous() for t in params]
+        a = _YRound._args(hy, xs, es, params, p, seed, sites)
+        out = torch.empty_like(hy)
+        keep = torch.empty(hy.shape[0], int(_lib.lib().scgg_train_y_keep_width(a.dy, a.ffy)), device=hy.device)
+        a.out, a.fsave = out.data_ptr(), keep.data_ptr()
+        _lib.check(_lib.lib().scgg_train_y_forward(C.byref(a), _lib.stream_ptr()), "train_y_forward")
+        ctx.save_for_backward(hy, xs, es, keep, *params)
+        ctx.cfg = (p, seed, tuple(int(v) for v in sites))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        hy, xs, es, keep = ctx.saved_tensors[:4]
+        params = list(ctx.saved_tensors[4:])
+        p, seed, sites = ctx.cfg
+        L = _lib.lib()
+        a = _YRound._args(hy, xs, es, params, p, seed, sites)
+        a.fsave = keep.data_ptr()
+        dout = dout.float().contiguous()
+        dhy, dxs, des = torch.empty_like(hy), torch.empty_like(xs), torch.empty_like(es)
+        save = torch.empty(hy.shape[0], int(L.scgg_train_y_save_width(a.dy, a.ffy)), device=hy.device)
+        a.dout, a.dhy, a.dxstats, a.destats, a.save = dout.data_ptr(), dhy.data_ptr(), dxs.data_ptr(), des.data_ptr(), save.data_ptr()
+        _lib.check(L.scgg_train_y_backward(C.byref(a), _lib.stream_ptr()), "train_y_backward")
+        flat = torch.empty(sum(t.numel() for t in params), device=hy.device)          # one allocation for the 18 gradients
+        grads, off = [], 0
+        for t in params:
+            grads.append(flat[off:off + t.numel()].view(t.shape))
+            off += t.numel()
+        ptrs = (C.c_void_p * 18)(*[g.data_ptr() for g in grads])
+        _lib.check(L.scgg_train_y_wgrad(C.byref(a), ptrs, _lib.stream_ptr()), "train_y_wgrad")
+        return (dhy, dxs, des, None, None, None, *grads)
+
+
+def y_round_supported(dy):
+    return dy <= 256 and os.environ.get("SCGG_TRAIN_MODE", "fused") != "eager" and os.environ.get("SCGG_TRAIN_Y", "fused") != "ops"
+
+
 def _layer_fused(layer, hX, hE, hy, m, node_mask, mask_u8, offdiag, dl, base):
     """One XEyTransformerLayer in training mode with the [B,n,n,.] part in the fused kernels; the X / y paths and the pooled
     statistics stay tensor ops (O(n dx^2) and O(n^2 de) work).  Dropout sites as in train_forward."""
@@ -535,14 +597,24 @@ def _layer_fused(layer, hX, hE, hy, m, node_mask, mask_u8, offdiag, dl, base):
         layer.normE1.weight, layer.normE1.bias, layer.linE1.weight, layer.linE1.bias, layer.linE2.weight, layer.linE2.bias,
         layer.normE2.weight, layer.normE2.bias)
     newX = _lin(a.x_out, _lin(a.y_x_add, hy)[:, None, :] + (_lin(a.y_x_mul, hy)[:, None, :] + 1.0) * wV) * xm
-    new_y = None
-    if a.predicts_y:
+    new_y = hy_next = None
+    y_fused = bool(a.predicts_y and layer.predicts_y and hy.is_cuda and y_round_supported(hy.shape[-1]))
+    if y_fused:
+        ps = dl.seed if dl.p > 0.0 else None
+        hy_next = _YRound.apply(hy, _node_stats(hX, m, mask_u8), e_stats, dl.p, ps, (base + 6, base + 7, base + 8),
+                                a.y_y.weight, a.y_y.bias, a.x_y.lin.weight, a.x_y.lin.bias, a.e_y.lin.weight, a.e_y.lin.bias,
+                                a.y_out[0].weight, a.y_out[0].bias, a.y_out[2].weight, a.y_out[2].bias, layer.norm_y1.weight, layer.norm_y1.bias,
+                                layer.lin_y1.weight, layer.lin_y1.bias, layer.lin_y2.weight, layer.lin_y2.bias, layer.norm_y2.weight,
+                                layer.norm_y2.bias)
+    elif a.predicts_y:
         z = _lin(a.y_y, hy) + _lin(a.x_y.lin, _node_stats(hX, m, mask_u8)) + _lin(a.e_y.lin, e_stats)
         new_y = _lin(a.y_out[2], torch.relu(_lin(a.y_out[0], z)))
     dl.site = base
     hX = _ln(layer.normX1, hX + dl(newX))
     hX = _ln(layer.normX2, hX + dl(_lin(layer.linX2, dl(torch.relu(_lin(layer.linX1, hX))))))
-    if layer.predicts_y:
+    if y_fused:
+        hy = hy_next
+    elif layer.predicts_y:
         dl.site = base + 6
         hy = _ln(layer.norm_y1, hy + dl(new_y))
         hy = _ln(layer.norm_y2, hy + dl(_lin(layer.lin_y2, dl(torch.relu(_lin(layer.lin_y1, hy))))))

@@ -605,3 +605,37 @@ def test_node_stats_kernel_matches_the_tensor_ops():
     (gw,) = torch.autograd.grad(want, X, go, retain_graph=True)
     (gg,) = torch.autograd.grad(got, X, go)
     assert float((gg - gw).abs().max()) <= 2e-6 * float(gw.abs().max())
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_y_round_kernels_match_the_tensor_ops(p, monkeypatch):
+    """The y path of a layer as three kernels against the same layer through tensor ops under autograd (SCGG_TRAIN_Y=ops):
+    logits and every gradient of a two-layer network at vessel widths, dim_ffy = 2048 as the reference hard-wires it."""
+    from types import SimpleNamespace
+    from semantically_consistent_graph_generation_amd.training import train_forward
+    from semantically_consistent_graph_generation_amd.transformer_model import GraphTransformer
+    ns = lambda X, E, y: SimpleNamespace(X=X, E=E, y=y, charges=0)
+    torch.manual_seed(3)
+    dims = dict(hidden_mlp_dims={"X": 64, "E": 32, "y": 32},
+                hidden_dims={"dx": 64, "de": 32, "dy": 64, "n_head": 4, "dim_ffX": 64, "dim_ffE": 64, "dim_ffy": 2048})
+    model = GraphTransformer(3, ns(9, 5, 12), dims["hidden_mlp_dims"], dims["hidden_dims"], ns(1, 5, 0)).cuda().train()
+    B, n = 5, 21
+    g = torch.Generator().manual_seed(1)
+    mask = (torch.arange(n)[None] < torch.tensor([21, 20, 9, 2, 14])[:, None]).cuda()
+    X = torch.randn(B, n, 9, generator=g).cuda()
+    E = torch.randn(B, n, n, 5, generator=g).cuda()
+    E = 0.5 * (E + E.transpose(1, 2))
+    y = torch.randn(B, 12, generator=g).cuda()
+    out = {}
+    for mode in ("fused", "ops"):
+        monkeypatch.setenv("SCGG_TRAIN_Y", mode)
+        model.zero_grad(set_to_none=True)
+        pred = train_forward(model, X, E, y, mask, seed=123 if p > 0 else None, p_layer=p)
+        (pred.E.square().mean() + pred.X.square().mean()).backward()
+        out[mode] = (pred.E.detach().clone(), {k: q.grad.clone() for k, q in model.named_parameters() if q.grad is not None})
+    assert float((out["fused"][0] - out["ops"][0]).abs().max()) <= 1e-5 * float(out["ops"][0].abs().max())
+    assert out["fused"][1].keys() == out["ops"][1].keys()
+    for k, gq in out["ops"][1].items():
+        scale = float(gq.abs().max())
+        assert float((out["fused"][1][k] - gq).abs().max()) <= 2e-4 * max(scale, 1e-8), k
+    assert any("lin_y1" in k for k in out["ops"][1])
