@@ -54,7 +54,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--stub-gloo", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="capture the step in a HIP graph (training.CapturedTrainingStep) and time replays")
     a = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:          # before anything touches the GPU
         import bench
@@ -106,8 +105,7 @@ def main():
 
         def loss_of(it):
             return training_step(model, nm, ef, dense, labd, rng=Rng(seed=11 + rank, step=it), dropout_seed=1000 + it + 7919 * rank)[0]
-    use_graph = a.graph and not a.stub_gloo and world == 1
-    opt = torch.optim.AdamW(model.parameters(), lr=2e-4, amsgrad=True, weight_decay=1e-12, **({"capturable": True} if use_graph else {}))
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-4, amsgrad=True, weight_decay=1e-12)
     gb = GradientBuckets(list(model.parameters()), hook=True) if world > 1 else None
     losses = []
 
@@ -122,13 +120,7 @@ def main():
             gb.finish()                                        # averaged gradients; parameters unused on every rank keep grad None
         opt.step()
         return loss.detach()
-    if use_graph:
-        from semantically_consistent_graph_generation_amd.training import CapturedTrainingStep
-        captured = CapturedTrainingStep(model, nm, ef, dense, labd, opt, seed=1000, warmup=max(1, a.warmup))
-
-        def step(it):                                          # noqa: F811  (one graph launch per step)
-            return captured().clone()
-    for it in range(0 if use_graph else a.warmup):
+    for it in range(a.warmup):
         step(it)
     sync()
     if dist:
@@ -157,7 +149,7 @@ def main():
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "graphs_per_s": world * a.batch / ms * 1e3,
                "host_issue_ms_per_step": host_issue * 1e3 / a.steps, "scaling": "weak", "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "replicas_identical": same,
                "data": "stub (launcher rehearsal, not a measurement)" if a.stub_gloo else "synthetic",
-               "train_mode": os.environ.get("SCGG_TRAIN_MODE", "fused"), "hip_graph": bool(use_graph)}
+               "train_mode": os.environ.get("SCGG_TRAIN_MODE", "fused")}
         if not a.stub_gloo:
             out["peak_mem_GB"] = torch.cuda.max_memory_allocated() / 2 ** 30
         print(json.dumps(out), flush=True)

@@ -805,61 +805,6 @@ def training_step(model, noise_model, extra_features, dense_data, true_E_labels,
     return loss, pred, z_t
 
 
-class CapturedTrainingStep:
-    """``training_step`` + ``loss.backward()`` + ``optimizer.step()`` recorded ONCE into a HIP graph and replayed: the step is
-    ~1 200 small launches and, issued from Python, as slow as the host can queue them; a replay costs the host one call.
-
-    What capture needs and how it is met: (1) nothing may change between replays except memory contents, so the batch lives
-    in the tensors handed in (copy the next batch INTO them: ``dense_data.E.copy_(...)``, ``true_E_labels.copy_(...)``) and
-    the shapes are fixed; (2) kernel arguments are frozen, so everything random comes from device memory: the diffusion
-    time ``t_int`` and the uniforms of ``apply_noise`` are drawn by torch's graph-safe generator into ``self.t_int`` /
-    ``self.u0`` inside the graph, and the dropout kernels read their Philox key from ``self.seed`` (incremented inside the
-    graph; ``scgg_dropout_devkey``, ``scgg_train_edge_args.key_dev``); (3) the optimizer must be built with
-    ``capturable=True``; (4) no host synchronisation inside the step (``apply_noise``'s tables are device-resident).
-    The ``warmup`` iterations run eagerly and ARE training steps.  After a replay ``self.t_int``, ``self.u0``
-    and ``self.seed`` hold what that step used (the tests re-run it eagerly from them).  One process, one GPU: with
-    ``GradientBuckets`` the all-reduce is not part of the graph."""
-
-    def __init__(self, model, noise_model, extra_features, dense_data, true_E_labels, optimizer, seed=0, loss_fn=None, warmup=3):
-        from .noise_model import Rng
-        dev = dense_data.X.device
-        if dev.type != "cuda":
-            raise _lib.ScggError("CapturedTrainingStep needs the MI355X")
-        for grp in optimizer.param_groups:
-            if not grp.get("capturable", False):
-                raise _lib.ScggError("build the optimizer with capturable=True: its step counters must live on the device")
-        B, n = dense_data.node_mask.shape
-        self.seed = torch.full((1,), int(seed), dtype=torch.int64, device=dev)
-        self.t_int = torch.zeros(B, 1, dtype=torch.int64, device=dev)
-        self.u0 = torch.zeros(B, n, n, device=dev)
-        self.optimizer, self.model = optimizer, model
-        T = noise_model.T
-        loss_fn = loss_fn or TrainLoss()
-
-        def body():
-            self.seed.add_(1)
-            self.t_int.random_(1, T + 1)
-            self.u0.uniform_()
-            loss = training_step(model, noise_model, extra_features, dense_data, true_E_labels, loss_fn, t_int=self.t_int,
-                                 rng=Rng(u0=self.u0), dropout_seed=self.seed)[0]
-            loss.backward()
-            optimizer.step()
-            return loss.detach()
-
-        for _ in range(max(1, warmup)):                # lazy initialisations, device tables, library handles: outside the graph
-            optimizer.zero_grad(set_to_none=True)      # (on the caller's stream: the package creates no streams of its own, DESIGN 4.4;
-            body()                                     # the capture stream is torch's)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        optimizer.zero_grad(set_to_none=True)          # the graph's backward then OWNS the gradient tensors and rewrites them per replay
-        with torch.cuda.graph(self.graph):
-            self.loss = body()
-
-    def __call__(self):
-        self.graph.replay()
-        return self.loss
-
-
 # ------------------------------------------------------------------------------------------------- data-parallel gradients
 class GradientBuckets:
     """Average the gradients of ``params`` over the ranks of ``group``: parameters in reverse registration order (the order
