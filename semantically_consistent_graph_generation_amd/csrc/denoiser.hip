@@ -560,7 +560,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
       if (fused_y) {
         YLayerArgs ya{};
         ya.y = w.y; ya.Wt_film = L.Wt_film; ya.b_film = L.bfilm; ya.film = film;
-        ya.B = B; ya.dy = dy; ya.ffy = c.dim_ffy; ya.kcat = kcat; ya.dx = dx; ya.update = 0;
+        ya.B = B; ya.dy = dy; ya.ffy = c.dim_ffy; ya.kcat = kcat; ya.dx = dx; ya.update = 0; ya.pair = 1;
         // y on the caller's stream: what that stream needs from the second one before edge kernel 0 is X(0) and q|k|v(0);
         // the event goes directly behind those kernels, then the second stream waits for y(0)
         if (launch_y_layer(ya, st)) return fail("y_layer launch failed");
@@ -612,6 +612,7 @@ int run_forward(scgg_denoiser* h, const float* X, const float* E, const float* y
         ya.y = w.y; ya.ycat = w.ycat; ya.etoy = w.epool + (size_t)(l & 1) * B * 4 * de;
         ya.B = B; ya.dy = dy; ya.ffy = c.dim_ffy; ya.kcat = kcat; ya.dx = dx;
         ya.update = L.predicts_y ? 1 : 0;
+        ya.pair = 1;
         if (y_pools && L.predicts_y) {
           ya.pool_X = Xcur; ya.pool_E = Ecur; ya.mask = mask; ya.n = n; ya.de = de;
           if (n > POOL_SLICED_MIN_N) {   // few large graphs: the pooled E statistics by W workgroups per graph, the y round reads them

@@ -271,6 +271,8 @@ struct YLayerArgs {       // fused global-feature part of one layer (y_layer.hip
   const float* gm_rowagg;   // [B*n, 8 de]
   const float* gm_rowaggD;  // [B*n, 4 de]
   const float* gm_newX;     // [B,n,dx]
+  int pair;                 // 1: two graphs per workgroup (y_layer_kernel<2,512>; the 2D engine sets it for every y launch so that
+                            // its schedule switches stay bit-identical to one another); 0: one (the position-aware engine)
 };
 
 bool y_layer_supported(int dy, int ffy, int kcat);
